@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Run in the build container only (``/root/reference`` does not exist on the GPU
+box):  ``python tests/golden/make_golden.py``
+
+The reference's Python files are loaded by path with small stub modules for the
+third-party packages that are absent here (cv2, torchvision, llava, ...).  The
+``cv2.remap`` stub records the float32 maps the reference hands to OpenCV; the
+resample itself is not available (OpenCV is neither vendored nor installed), so
+no golden exists for it -- "parity unpinned" at that boundary.
+
+Only inputs and the reference's outputs are stored (data, never source).
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from PIL import Image
+
+REF = os.environ.get("ATTWARP_REFERENCE", "/root/reference")
+AGW = os.path.join(REF, "Attention Guided Warping")
+MN = os.path.join(REF, "model", "marginalnet_full_dataset")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+CAPTURED = {}
+
+
+def _install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR = 1
+    cv2.INTER_NEAREST = 0
+    cv2.BORDER_REPLICATE = 1
+    cv2.COLOR_RGB2BGR = 4
+    cv2.COLOR_BGR2RGB = 4
+    cv2.COLOR_GRAY2BGR = 8
+    cv2.COLOR_BGR2GRAY = 6
+    cv2.COLORMAP_JET = 2
+    cv2.NORM_MINMAX = 32
+
+    def remap(img, map_x, map_y, interpolation=None, borderMode=None):
+        CAPTURED["map_x"] = np.array(map_x)
+        CAPTURED["map_y"] = np.array(map_y)
+        shape = map_x.shape + (img.shape[2:] if img.ndim == 3 else ())
+        return np.zeros(shape, dtype=img.dtype)
+
+    def cvtColor(img, code):
+        return img[..., ::-1].copy() if img.ndim == 3 and img.shape[2] == 3 else img
+
+    cv2.remap = remap
+    cv2.cvtColor = cvtColor
+    cv2.imwrite = lambda *a, **k: True
+    cv2.imread = lambda *a, **k: None
+    cv2.resize = lambda img, size, interpolation=None: img
+    sys.modules["cv2"] = cv2
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class ToPILImage:
+        def __call__(self, pic):
+            if pic.is_floating_point():
+                pic = pic.mul(255).byte()
+            return Image.fromarray(pic.squeeze(0).numpy(), mode="L")
+
+    tvt.ToPILImage = ToPILImage
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+
+    for name in ["llava", "llava.constants", "llava.conversation", "llava.model", "llava.model.builder",
+                 "llava.utils", "llava.mm_utils", "requests"]:
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+    sys.modules["llava.constants"].IMAGE_TOKEN_INDEX = -200
+    sys.modules["llava.constants"].DEFAULT_IMAGE_TOKEN = "<image>"
+    sys.modules["llava.constants"].DEFAULT_IM_START_TOKEN = "<im_start>"
+    sys.modules["llava.constants"].DEFAULT_IM_END_TOKEN = "<im_end>"
+    sys.modules["llava.constants"].IMAGE_PLACEHOLDER = "<image-placeholder>"
+    sys.modules["llava.conversation"].conv_templates = {}
+    sys.modules["llava.conversation"].SeparatorStyle = type("SeparatorStyle", (), {"TWO": 2})
+    sys.modules["llava.model.builder"].load_pretrained_model = lambda *a, **k: None
+    sys.modules["llava.utils"].disable_torch_init = lambda: None
+    for fn in ["process_images", "tokenizer_image_token", "get_model_name_from_path", "KeywordsStoppingCriteria"]:
+        setattr(sys.modules["llava.mm_utils"], fn, lambda *a, **k: None)
+    # transformers 5.x dropped MaxNewTokensCriteria (reference pins 4.37.2): stub the module
+    m = types.ModuleType("transformers.generation.stopping_criteria")
+    m.StoppingCriteria = object
+    m.MaxNewTokensCriteria = object
+    sys.modules["transformers.generation.stopping_criteria"] = m
+
+
+def pool_input(S: int) -> np.ndarray:
+    """Deterministic [2,1,S,S] float32 attention used for the pooling goldens
+    (tests import this recipe instead of storing megabytes)."""
+    rng = np.random.default_rng(1300 + S)
+    A = rng.random((2, 1, S, S), dtype=np.float32)
+    A[0, 0, S // 3: S // 3 + S // 8, S // 2: S // 2 + S // 8] += np.float32(5.0)
+    return A
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    _install_stubs()
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+
+    new_method = _load("ref_new_method", os.path.join(AGW, "new_method.py"))
+    ckpt = _load("ref_checkpoint_utils", os.path.join(MN, "checkpoint_utils.py"))
+    model = _load("ref_model", os.path.join(MN, "model.py"))
+    sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
+    llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
+
+    # ---------------- A1 / A2: attention aggregation -----------------------
+    g = torch.Generator().manual_seed(11)
+    B, T, heads, kv = 3, 4, 32, 640
+    starts = [35, 37, 41]
+    ends = [s + 576 for s in starts]
+    steps_in = []
+    logger = llava.BatchMaskHookLogger(model=None, device="cpu", layer_index=20)
+    logger.set_batch_image_token_ranges(starts, ends)
+    for t in range(T):
+        q = 5 if t == 0 else 1
+        a = torch.softmax(torch.randn(B, heads, q, kv, generator=g), dim=-1)
+        steps_in.append(a.numpy())
+        logger._process_attention(a)
+    step_out = [s.numpy() for s in logger.step_attentions]
+    final = torch.stack(logger.finalize_batch()).numpy()
+    # fp16 variant (what LLaVA actually produces)
+    logger16 = llava.BatchMaskHookLogger(model=None, device="cpu", layer_index=20)
+    logger16.set_batch_image_token_ranges(starts, ends)
+    for a in steps_in:
+        logger16._process_attention(torch.from_numpy(a).half())
+    step_out16 = [s.numpy() for s in logger16.step_attentions]
+    final16 = torch.stack(logger16.finalize_batch()).numpy()
+    empty = llava.BatchMaskHookLogger(model=None, device="cpu")
+    empty.set_batch_image_token_ranges([1, 2], [577, 578])
+    empty_out = torch.stack(empty.finalize_batch()).numpy()
+    np.savez_compressed(os.path.join(OUT, "attn_reduce.npz"),
+                        starts=np.array(starts), ends=np.array(ends),
+                        **{f"step_in_{t}": steps_in[t][:, :, -1:, :] for t in range(T)},
+                        **{f"step_out_{t}": step_out[t] for t in range(T)},
+                        **{f"step_out16_{t}": step_out16[t] for t in range(T)},
+                        final=final, final16=final16, empty=empty_out)
+
+    # ---------------- A3: mask post-processing ------------------------------
+    g = torch.Generator().manual_seed(12)
+    masks = torch.rand(4, 24, 24, generator=g) / 576.0
+    masks[1, 5:8, 9:12] *= 100.0                     # peaked attention
+    masks[3] = final_t = torch.from_numpy(final[0])  # a realistic aggregated map
+    revised = torch.stack([llava.revise_mask(m.float(), kernel_size=3, enhance_coe=10) for m in masks])
+    revised = revised.detach().reshape(4, 24, 24).numpy()
+    revised5 = llava.revise_mask(masks[0].float(), kernel_size=5, enhance_coe=4).detach().reshape(24, 24).numpy()
+    # A4: ToPILImage truncation + Pillow LANCZOS (real Pillow, third-party)
+    u8 = np.stack([np.array(llava.toImg(torch.from_numpy(r).reshape(1, 24, 24))) for r in revised])
+    lanczos = {}
+    for (w, h) in [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24)]:
+        lanczos[f"lanczos_{w}x{h}"] = np.stack(
+            [np.array(Image.fromarray(m, mode="L").resize((w, h), Image.LANCZOS)) for m in u8[:2]])
+    np.savez_compressed(os.path.join(OUT, "mask_postproc.npz"), masks=masks.numpy(), revised=revised,
+                        mask0_k5_c4=revised5, u8=u8, pillow_version=np.array(Image.__version__), **lanczos)
+
+    # ---------------- A5/A6/A7 ---------------------------------------------
+    # Big inputs are NOT stored: the tests regenerate them with the same numpy
+    # Generator recipe (PCG64 streams are stable across numpy versions).
+    pool = {}
+    for S in (336, 512, 1024):
+        A = pool_input(S)
+        P = torch.nn.functional.adaptive_avg_pool2d(torch.from_numpy(A), (24, 24))
+        pool[f"P_{S}"] = P.numpy()
+        px, py = ckpt.gt_marginals(P)
+        pool[f"px_{S}"] = px.numpy(); pool[f"py_{S}"] = py.numpy()
+    g = torch.Generator().manual_seed(13)
+    # non-square + negative values for gt_marginals at "full resolution"
+    Afull = torch.randn(2, 1, 40, 56, generator=g)
+    pxf, pyf = ckpt.gt_marginals(Afull)
+    logits = torch.randn(5, 24, generator=g) * 4
+    logits[1, 3] = float("nan"); logits[2, 7] = float("inf"); logits[3, :] = -float("inf")
+    sm = model.safe_softmax(logits.clone(), dim=1, eps=1e-6)
+    np.savez_compressed(os.path.join(OUT, "pool_marginals.npz"), **pool,
+                        Afull=Afull.numpy(), pxf=pxf.numpy(), pyf=pyf.numpy(),
+                        logits=logits.numpy(), safe_softmax=sm.numpy())
+
+    # ---------------- A8/A9/A10 --------------------------------------------
+    g = torch.Generator().manual_seed(14)
+    y = torch.softmax(torch.randn(3, 24, generator=g) * 2, dim=1)
+    a8 = {"y": y.numpy()}
+    for L in (336, 500, 512, 1024):
+        x = ckpt.upsample_pdf_right_inverse(y, L)
+        a8[f"x_{L}"] = x.numpy()
+        a8[f"cdf_{L}"] = ckpt.cdf_from_density(x.clamp_min(0)).numpy()
+    a8["x1d_336"] = ckpt.upsample_pdf_right_inverse(y[0], 336).numpy()
+    a8["x3d_336"] = ckpt.upsample_pdf_right_inverse(y.reshape(1, 3, 24), 336).numpy()
+    p_bad = torch.rand(3, 50, generator=g)
+    p_bad[0, 3] = float("nan"); p_bad[1, 4] = -2.0; p_bad[1, 9] = float("inf"); p_bad[2] = 0.0
+    a8["p_bad"] = p_bad.numpy()
+    a8["cdf_bad"] = ckpt.cdf_from_density(p_bad.clone()).numpy()
+    Fc = torch.cumsum(torch.softmax(torch.randn(3, 24, generator=g), dim=1), dim=1)
+    Fc[1, 5:9] = Fc[1, 5]                      # plateau
+    Fc[2, 10] = float("nan"); Fc[2, 3] = Fc[2, 2] - 0.05   # nan + decreasing
+    a8["F24"] = Fc.numpy()
+    a8["msi"] = ckpt._make_strictly_increasing(Fc.clone()).numpy()
+    for L in (336, 1024):
+        a8[f"resample_{L}"] = ckpt.resample_cdf(Fc.clone(), L).numpy()
+    np.savez_compressed(os.path.join(OUT, "pdf_cdf.npz"), **a8)
+
+    # ---------------- A11: maps from CDFs (torch variant) -------------------
+    g = torch.Generator().manual_seed(15)
+    a11 = {}
+    cases = {
+        "sq336": (336, 336, None),
+        "rect": (48, 64, (40, 72)),
+        "to500": (336, 336, (500, 500)),
+        "sq1024": (1024, 1024, None),
+    }
+    for name, (H, W, out_size) in cases.items():
+        px = torch.softmax(torch.randn(2, 24, generator=g) * 2, dim=1)
+        py = torch.softmax(torch.randn(2, 24, generator=g) * 2, dim=1)
+        Fx = ckpt.cdf_from_density(ckpt.upsample_pdf_right_inverse(px, W).clamp_min(0))
+        Fy = ckpt.cdf_from_density(ckpt.upsample_pdf_right_inverse(py, H).clamp_min(0))
+        img = torch.zeros(2, 3, H, W)
+        mxs, mys = [], []
+        for b in range(2):
+            ckpt.warp_from_cdf_torch(img[b:b + 1], Fx[b:b + 1], Fy[b:b + 1], out_size)
+            mxs.append(CAPTURED["map_x"][0].copy()); mys.append(CAPTURED["map_y"][:, 0].copy())
+            assert np.all(CAPTURED["map_x"] == CAPTURED["map_x"][0:1])       # separable
+            assert np.all(CAPTURED["map_y"] == CAPTURED["map_y"][:, 0:1])
+        a11[f"{name}_Fx"] = Fx.numpy(); a11[f"{name}_Fy"] = Fy.numpy()
+        a11[f"{name}_mx"] = np.stack(mxs); a11[f"{name}_my"] = np.stack(mys)
+        a11[f"{name}_out"] = np.array(out_size if out_size else (H, W))
+    # ties: zero-density stretches -> flat CDF -> tie-break ramp branch
+    p = torch.rand(2, 64, generator=g); p[0, 10:30] = 0; p[1, :8] = 0; p[1, 60:] = 0
+    Ft = ckpt.cdf_from_density(p)
+    img = torch.zeros(2, 1, 64, 64)
+    mxs, mys = [], []
+    for b in range(2):
+        ckpt.warp_from_cdf_torch(img[b:b + 1], Ft[b:b + 1], Ft[b:b + 1].flip(0), (80, 96))
+        mxs.append(CAPTURED["map_x"][0].copy()); mys.append(CAPTURED["map_y"][:, 0].copy())
+    a11["ties_F"] = Ft.numpy(); a11["ties_mx"] = np.stack(mxs); a11["ties_my"] = np.stack(mys)
+    a11["ties_out"] = np.array((80, 96))
+    np.savez_compressed(os.path.join(OUT, "maps_from_cdf.npz"), **a11)
+
+    # ---------------- A13: maps from attention (numpy float64 variant) -----
+    rng = np.random.default_rng(16)
+    a13 = {}
+    att_u8 = np.array(Image.fromarray(u8[1], mode="L").resize((336, 336), Image.LANCZOS))
+    att_f = rng.random((60, 84)).astype(np.float32)
+    att_f[20:30, 40:60] *= 20
+    att_neg = (rng.standard_normal((32, 48))).astype(np.float64)
+    a13["att_u8"] = att_u8; a13["att_f"] = att_f; a13["att_neg"] = att_neg
+    a13["att_zero"] = np.zeros((24, 40), dtype=np.uint8)
+    combos = []
+    for aname, att in [("att_u8", att_u8), ("att_f", att_f), ("att_neg", att_neg), ("att_zero", a13["att_zero"])]:
+        for tr in ["identity", "square", "sqrt", "exp", "log", "bogus"]:
+            for inv in (False, True):
+                for (nw, nh) in [(500, 500), (att.shape[1], att.shape[0])]:
+                    if aname == "att_u8" and tr == "exp":
+                        es, ed = 0.01, 2.0
+                    else:
+                        es, ed = 1.0, 1.0
+                    new_method.set_transform_function(tr, es, ed, inv)
+                    img = np.zeros(att.shape + (3,), dtype=np.uint8)
+                    with np.errstate(all="ignore"):
+                        new_method.warp_image_by_attention(img, att, nw, nh)
+                    key = f"{aname}|{tr}|{int(inv)}|{nw}x{nh}|{es}|{ed}"
+                    combos.append(key)
+                    a13[f"mx|{key}"] = CAPTURED["map_x"][0].copy()
+                    a13[f"my|{key}"] = CAPTURED["map_y"][:, 0].copy()
+    a13["combos"] = np.array(combos)
+    np.savez_compressed(os.path.join(OUT, "maps_from_attention.npz"), **a13)
+
+    # ---------------- MarginalNet (next-row producer) -----------------------
+    torch.manual_seed(17)
+    net = model.MarginalNet(d_vis_in=32, d_txt_in=48, hidden=16).eval()
+    fmap = torch.randn(2, 32, 24, 24); ttok = torch.randn(2, 7, 48)
+    tmask = torch.ones(2, 7, 1); tmask[1, 4:] = 0
+    with torch.no_grad():
+        px, py = net(fmap, 24, 24, ttok, tmask)
+    sd = {k: v.numpy() for k, v in net.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "marginalnet.npz"), fmap=fmap.numpy(), ttok=ttok.numpy(),
+                        tmask=tmask.numpy(), px=px.numpy(), py=py.numpy(),
+                        **{"sd|" + k: v for k, v in sd.items()})
+    n_full = sum(p.numel() for p in model.MarginalNet(1024, 4096, 256).parameters())
+    print("MarginalNet(1024,4096,256) params:", n_full)
+
+    tot = 0
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            sz = os.path.getsize(os.path.join(OUT, f)); tot += sz
+            print(f"{f:32s} {sz/1024:8.1f} KiB")
+    print("total", tot / 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,260 @@
+"""Pin the CPU oracle (oracle/warp_oracle.py) to the golden vectors captured
+from the reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import warp_oracle as O
+from conftest import pool_input
+
+
+def ulps(a, b):
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    return np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+
+
+# ---- A1 / A2 ---------------------------------------------------------------
+def test_attn_reduce_steps_fp32(golden):
+    g = golden("attn_reduce")
+    starts, ends = g["starts"], g["ends"]
+    steps = []
+    for t in range(4):
+        out = O.attn_reduce_step(g[f"step_in_{t}"], starts, ends)
+        steps.append(out)
+        ref = g[f"step_out_{t}"]
+        assert out.shape == ref.shape == (3, 576)
+        # torch's float32 sum order is implementation defined: a few ulps
+        np.testing.assert_allclose(out, ref, rtol=3e-7, atol=0)
+    fin = O.attn_finalize(steps).reshape(3, 24, 24)
+    np.testing.assert_allclose(fin, g["final"], rtol=3e-7, atol=0)
+
+
+def test_attn_reduce_steps_fp16(golden):
+    g = golden("attn_reduce")
+    starts, ends = g["starts"], g["ends"]
+    steps = []
+    for t in range(4):
+        out = O.attn_reduce_step(g[f"step_in_{t}"].astype(np.float16), starts, ends)
+        assert out.dtype == np.float16
+        steps.append(out)
+        ref = g[f"step_out16_{t}"]
+        # fp16: one ulp = 2^-10 relative
+        np.testing.assert_allclose(out.astype(np.float32), ref.astype(np.float32), rtol=2e-3, atol=0)
+    fin = O.attn_finalize(steps).reshape(3, 24, 24)
+    np.testing.assert_allclose(fin.astype(np.float32), g["final16"].astype(np.float32), rtol=2e-3)
+
+
+def test_attn_stack_equals_steps(golden):
+    g = golden("attn_reduce")
+    rows = np.stack([g[f"step_in_{t}"][:, :, -1, :] for t in range(4)])
+    fused = O.attn_reduce_stack(rows, g["starts"])
+    steps = [O.attn_reduce_step(g[f"step_in_{t}"], g["starts"], g["ends"]) for t in range(4)]
+    assert np.array_equal(fused, O.attn_finalize(steps))
+
+
+def test_attn_empty_uniform(golden):
+    g = golden("attn_reduce")
+    out = O.attn_finalize([], batch_size=2)
+    assert np.array_equal(out, g["empty"])
+    assert out.shape == (2, 576)          # flat, NOT reshaped (reference llava.py:404-408)
+
+
+# ---- A3 / A4 ---------------------------------------------------------------
+def test_revise_mask(golden):
+    g = golden("mask_postproc")
+    out = O.revise_mask(g["masks"], 3, 10)
+    np.testing.assert_allclose(out, g["revised"], rtol=0, atol=5e-7)
+    out5 = O.revise_mask(g["masks"][0], 5, 4)
+    np.testing.assert_allclose(out5, g["mask0_k5_c4"], rtol=0, atol=5e-7)
+
+
+def test_mask_to_u8(golden):
+    g = golden("mask_postproc")
+    assert np.array_equal(O.mask_to_u8(g["revised"]), g["u8"])
+
+
+@pytest.mark.parametrize("wh", [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24)])
+def test_lanczos_bit_exact_vs_pillow(golden, wh):
+    g = golden("mask_postproc")
+    w, h = wh
+    ref = g[f"lanczos_{w}x{h}"]
+    for i in range(2):
+        out = O.lanczos_resize_u8(g["u8"][i], w, h)
+        assert out.shape == (h, w)
+        assert np.array_equal(out, ref[i])
+
+
+# ---- A5 / A6 / A7 ----------------------------------------------------------
+@pytest.mark.parametrize("S", [336, 512, 1024])
+def test_pool24_and_marginals(golden, S):
+    g = golden("pool_marginals")
+    A = pool_input(S)
+    P = O.adaptive_avg_pool24(A)
+    # ATen accumulates each window sequentially in float32 (up to 44*44 terms);
+    # the oracle accumulates in float64 and rounds once.
+    np.testing.assert_allclose(P, g[f"P_{S}"], rtol=3e-6, atol=0)
+    px, py = O.gt_marginals(g[f"P_{S}"])
+    np.testing.assert_allclose(px, g[f"px_{S}"], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(py, g[f"py_{S}"], rtol=3e-7, atol=1e-9)
+
+
+def test_gt_marginals_fullres_negative(golden):
+    g = golden("pool_marginals")
+    px, py = O.gt_marginals(g["Afull"])
+    np.testing.assert_allclose(px, g["pxf"], rtol=5e-7, atol=1e-9)
+    np.testing.assert_allclose(py, g["pyf"], rtol=5e-7, atol=1e-9)
+
+
+def test_safe_softmax(golden):
+    g = golden("pool_marginals")
+    out = O.safe_softmax(g["logits"])
+    np.testing.assert_allclose(out, g["safe_softmax"], rtol=5e-7, atol=1e-12)
+    assert np.all(np.isfinite(out))
+
+
+# ---- A8 / A9 / A10 ---------------------------------------------------------
+@pytest.mark.parametrize("L", [336, 500, 512, 1024])
+def test_right_inverse_and_cdf(golden, L):
+    g = golden("pdf_cdf")
+    x = O.upsample_pdf_right_inverse(g["y"], L)
+    ref = g[f"x_{L}"]
+    # the reference solves with float32 LU (LAPACK): agreement to a few float32 ulps of the peak
+    np.testing.assert_allclose(x, ref, rtol=0, atol=4e-7 * np.abs(ref).max())
+    # docstring invariant (MN/checkpoint_utils.py:70-72): pooling x back gives y
+    A = O.pooling_matrix(24, L, np.float64)
+    np.testing.assert_allclose(x.astype(np.float64) @ A.T, g["y"], rtol=0, atol=2e-6)
+    # CDF from the REFERENCE's own x: isolates the A9 stage
+    # torch's float32 row sum (the normaliser) is up to 4 ulps off the exactly
+    # rounded sum the oracle uses; the cumulative sum itself matches bit-for-bit
+    # (float64 accumulate), so the whole CDF scales by that factor.
+    F = O.cdf_from_density(np.maximum(ref, 0))
+    np.testing.assert_allclose(F, g[f"cdf_{L}"], rtol=6e-7, atol=0)
+    assert np.all(np.diff(F, axis=1) >= 0) and np.all(F[:, -1] == 1.0)
+
+
+def test_right_inverse_shapes(golden):
+    g = golden("pdf_cdf")
+    x1 = O.upsample_pdf_right_inverse(g["y"][0], 336)
+    assert x1.shape == (336,)
+    np.testing.assert_allclose(x1, g["x1d_336"], rtol=0, atol=4e-7 * g["x1d_336"].max())
+    x3 = O.upsample_pdf_right_inverse(g["y"].reshape(1, 3, 24), 336)
+    assert x3.shape == (1, 3, 336)
+    np.testing.assert_allclose(x3, g["x3d_336"], rtol=0, atol=4e-7 * g["x3d_336"].max())
+    with pytest.raises(ValueError):
+        O.upsample_pdf_right_inverse(np.zeros((1, 1, 1, 24), np.float32), 336)
+
+
+def test_cdf_from_density_bad_values(golden):
+    g = golden("pdf_cdf")
+    F = O.cdf_from_density(g["p_bad"])
+    assert ulps(F, g["cdf_bad"]).max() <= 2
+
+
+def test_make_strictly_increasing_and_resample(golden):
+    g = golden("pdf_cdf")
+    m = O.make_strictly_increasing(g["F24"])
+    assert ulps(m, g["msi"]).max() <= 2
+    for L in (336, 1024):
+        r = O.resample_cdf(g["F24"], L)
+        np.testing.assert_allclose(r, g[f"resample_{L}"], rtol=0, atol=3e-7)
+
+
+# ---- A11 -------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["sq336", "rect", "to500", "sq1024", "ties"])
+def test_maps_from_cdf_bit_exact(golden, case):
+    g = golden("maps_from_cdf")
+    if case == "ties":
+        Fx = g["ties_F"]; Fy = g["ties_F"]
+    else:
+        Fx = g[f"{case}_Fx"]; Fy = g[f"{case}_Fy"]
+    out = tuple(int(v) for v in g[f"{case}_out"])
+    mx, my = O.maps_from_cdf(Fx, Fy, out)
+    assert np.array_equal(mx, g[f"{case}_mx"])
+    assert np.array_equal(my, g[f"{case}_my"])
+
+
+# ---- A13 -------------------------------------------------------------------
+def test_maps_from_attention_bit_exact(golden):
+    g = golden("maps_from_attention")
+    combos = [str(c) for c in g["combos"]]
+    assert len(combos) == 4 * 6 * 2 * 2
+    for key in combos:
+        aname, tr, inv, wh, es, ed = key.split("|")
+        nw, nh = (int(v) for v in wh.split("x"))
+        mx, my = O.maps_from_attention(g[aname], nw, nh, tr, float(es), float(ed), bool(int(inv)))
+        assert np.array_equal(mx, g[f"mx|{key}"], equal_nan=True), key
+        assert np.array_equal(my, g[f"my|{key}"], equal_nan=True), key
+
+
+# ---- properties the reference's docstrings promise --------------------------
+def test_uniform_attention_is_identity_map():
+    mx, my = O.maps_from_attention(np.ones((48, 64), np.uint8), 64, 48)
+    np.testing.assert_allclose(mx, np.arange(64), atol=1e-4)
+    np.testing.assert_allclose(my, np.arange(48), atol=1e-4)
+    mx, my = O.maps_from_attention(np.ones((48, 64), np.uint8), 128, 24)
+    np.testing.assert_allclose(mx, np.arange(128) * 0.5, atol=1e-4)
+    np.testing.assert_allclose(my, np.arange(24) * 2.0, atol=1e-4)
+
+
+def test_remap_exact_identity_and_border():
+    rng = np.random.default_rng(0)
+    img = rng.random((20, 30, 3), dtype=np.float32)
+    out = O.remap_bilinear(img, np.arange(30, dtype=np.float32), np.arange(20, dtype=np.float32))
+    assert np.array_equal(out, img)
+    # coordinates beyond the edge replicate the border pixel
+    out = O.remap_bilinear(img, np.array([-3.5, 29.0, 29.75, 40.0], np.float32), np.array([-1.0, 19.5], np.float32))
+    assert np.array_equal(out[0, 0], img[0, 0]) and np.array_equal(out[0, 1], img[0, 29])
+    assert np.array_equal(out[1, 3], img[19, 29])
+    u8 = (img * 255).astype(np.uint8)
+    out8 = O.remap_bilinear(u8, np.arange(30, dtype=np.float32) + 0.5, np.arange(20, dtype=np.float32))
+    assert out8.dtype == np.uint8
+
+
+def test_remap_matches_torch_grid_sample():
+    """Cross-check of the exact-bilinear stand-in: grid_sample with
+    border padding / align_corners=True on pixel coordinates."""
+    import torch
+    rng = np.random.default_rng(1)
+    H, W = 37, 53
+    img = rng.random((H, W, 3), dtype=np.float32)
+    mx = np.sort(rng.random(64).astype(np.float32) * (W + 2) - 1)
+    my = np.sort(rng.random(40).astype(np.float32) * (H + 2) - 1)
+    out = O.remap_bilinear(img, mx, my)
+    gx = 2 * torch.from_numpy(mx) / (W - 1) - 1
+    gy = 2 * torch.from_numpy(my) / (H - 1) - 1
+    grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1)[None]
+    ref = torch.nn.functional.grid_sample(torch.from_numpy(img).permute(2, 0, 1)[None], grid, mode="bilinear",
+                                          padding_mode="border", align_corners=True)[0].permute(1, 2, 0).numpy()
+    assert np.abs(out - ref).max() < 5e-5
+
+
+def test_cv2_compat_mode_close_to_exact():
+    rng = np.random.default_rng(2)
+    img = rng.random((16, 16, 3), dtype=np.float32)
+    mx = np.linspace(0, 15, 40, dtype=np.float32); my = np.linspace(0, 15, 24, dtype=np.float32)
+    a = O.remap_bilinear(img, mx, my, "exact"); b = O.remap_bilinear(img, mx, my, "cv2")
+    assert np.abs(a - b).max() < 1.0 / 32 + 1e-6
+    u8 = (img * 255).astype(np.uint8)
+    a8 = O.remap_bilinear(u8, mx, my, "exact").astype(int); b8 = O.remap_bilinear(u8, mx, my, "cv2").astype(int)
+    assert np.abs(a8 - b8).max() <= 9
+    # integer coordinates: both modes return the source pixels exactly
+    ix = np.arange(16, dtype=np.float32)
+    assert np.array_equal(O.remap_bilinear(u8, ix, ix, "cv2"), u8)
+    assert np.array_equal(O.remap_bilinear(img, ix, ix, "cv2"), img)
+
+
+def test_pool_recipe_matches_golden(golden):
+    # guards the duplicated input recipe in conftest.py
+    g = golden("pool_marginals")
+    P = O.adaptive_avg_pool24(pool_input(336))
+    assert np.abs(P - g["P_336"]).max() < 1e-5
+
+
+def test_warp_from_cdf_validation():
+    img = np.zeros((1, 3, 8, 8), np.float32)
+    F = np.linspace(1 / 8, 1, 8, dtype=np.float32)[None]
+    with pytest.raises(ValueError):
+        O.warp_from_cdf(img, F[:, :7], F)
+    with pytest.raises(AssertionError):
+        O.warp_from_cdf(img[0], F, F)
+    out = O.warp_from_cdf(img + 0.25, F, F)
+    assert out.shape == (1, 3, 8, 8) and np.allclose(out, 0.25)
