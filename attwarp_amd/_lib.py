@@ -1,0 +1,131 @@
+"""ctypes binding of libattwarp_hip.so (C ABI declared in include/attwarp.h).
+
+The HIP library is the product: there is NO CPU fallback.  Importing this module
+on a machine without the built library raises ImportError; calling any op on a
+non-GPU tensor raises.  Build with ``python __graft_entry__.py`` or
+``make -C attwarp_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p, c_char_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libattwarp_hip.so")
+
+# enums of include/attwarp.h
+F32, F16, BF16, U8, F64 = 0, 1, 2, 3, 4
+HWC, CHW = 0, 1
+EXACT, CV2 = 0, 1
+TRANSFORM_IDS = {"identity": 0, "square": 1, "sqrt": 2, "exp": 3, "log": 4}
+MODE_IDS = {"exact": EXACT, "cv2": CV2}
+
+_DTYPE_IDS = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torch.uint8: U8, torch.float64: F64}
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "attwarp_version": (c_int, []),
+    "attwarp_last_error": (c_char_p, []),
+    "attwarp_attn_reduce_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
+                                          c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "attwarp_attn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_attn_reduce_stack_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "attwarp_attn_reduce_stack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                           c_void_p, c_void_p]),
+    "attwarp_mask_postproc": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "attwarp_mask_upsample_lanczos": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                               c_void_p]),
+    "attwarp_adaptive_avg_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_axis_sums_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "attwarp_gt_marginals": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "attwarp_safe_softmax": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "attwarp_upsample_pdf_right_inverse": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "attwarp_cdf_from_density": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_make_strictly_increasing": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "attwarp_resample_cdf": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_axis_map_from_cdf": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_axis_maps_from_pdf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p]),
+    "attwarp_axis_maps_from_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                                  c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "attwarp_remap_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class AttWarpError(RuntimeError):
+    """A libattwarp_hip.so entry point returned a negative status."""
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Fails loudly if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"attwarp_amd: HIP library not built ({LIB_PATH} missing). Run `python __graft_entry__.py` or "
+            f"`make -C attwarp_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; raise AttWarpError on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.attwarp_last_error().decode("utf-8", "replace")
+        raise AttWarpError(f"{name} failed ({rc}): {msg}")
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def dtype_id(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_IDS[t.dtype]
+    except KeyError:
+        raise TypeError(f"attwarp_amd: unsupported dtype {t.dtype}") from None
+
+
+def require_gpu(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on the same GPU; returns it.  No CPU path exists."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "attwarp_amd: tensor is on %s; the HIP kernels need a GPU tensor (there is no CPU fallback)" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"attwarp_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is None:
+        raise RuntimeError("attwarp_amd: no tensor given")
+    return dev
+
+
+def stream_ptr(dev: torch.device):
+    """The caller's current HIP stream on `dev` (kernels are stream ordered, never synchronise)."""
+    return c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def default_device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("attwarp_amd: no GPU visible; the numpy-facing entry points run their kernels on cuda:0 "
+                           "(there is no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())

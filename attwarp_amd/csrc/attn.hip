@@ -1,0 +1,339 @@
+// Attention-side stages on the 24x24 token grid:
+//   A1  BatchMaskHookLogger._process_attention   AGW/attention_extraction/llava.py:385-396
+//   A2  BatchMaskHookLogger.finalize_batch       llava.py:401-411
+//   A3  revise_mask (normalize -> enhance -> box) llava.py:207-238
+//   A4  ToPILImage (x255, truncate) + PIL resize(LANCZOS) llava.py:192-196,243,253
+//
+// A1 is the only bandwidth-relevant one: per generation step it reads heads*ntok elements per
+// sample (T*32*576*elemsize algorithmic bytes per image over a generation) with
+// coalesced row segments; the rest is 576 numbers per image.
+//
+// Rounding follows the reference's dtype transitions: the hook works in the MODEL dtype
+// (float16 in LLaVA), so every reference op boundary rounds to that dtype; reductions are
+// accumulated in double and rounded once (see oracle/warp_oracle.py, module docstring).
+#include "common.hpp"
+
+namespace attwarp {
+
+constexpr int NT = 256;
+constexpr int MAXPL = 16;          // tokens per lane: ntok <= 1024
+constexpr int MAX_NTOK = MAXPL * WAVE;
+
+template <typename T> __device__ __forceinline__ T add_tiny(T s);   // s + 1e-12 evaluated in dtype T
+template <> __device__ __forceinline__ float add_tiny<float>(float s) { return fadd(s, 1e-12f); }
+template <> __device__ __forceinline__ __half add_tiny<__half>(__half s) {
+  return __float2half_rn(fadd(__half2float(s), 1e-12f));
+}
+template <> __device__ __forceinline__ __hip_bfloat16 add_tiny<__hip_bfloat16>(__hip_bfloat16 s) {
+  return __float2bfloat16(fadd(__bfloat162float(s), 1e-12f));
+}
+template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b evaluated in dtype T
+  return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
+}
+
+// One workgroup per (pseudo-)sample.  Each wave takes heads w, w+4, ...; lane l owns tokens
+// l, l+64, ...  (ntok/64 <= 16 values in registers).  grid = nb
+template <typename T>
+__global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restrict__ attn, int heads, int64_t sb,
+                                                              int64_t sh, int64_t row_off, int64_t skv,
+                                                              const int32_t* __restrict__ starts, int starts_mod,
+                                                              int ntok, T* __restrict__ out) {
+  __shared__ double part[NT / WAVE][MAX_NTOK];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int st = starts[b % starts_mod];
+  const T* base = attn + (int64_t)b * sb + row_off + (int64_t)st * skv;
+  double acc[MAXPL];
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) acc[i] = 0.0;
+  for (int h = wid; h < heads; h += NT / WAVE) {
+    const T* rp = base + (int64_t)h * sh;
+    T v[MAXPL];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int t = lane + WAVE * i;
+      if (t < ntok) {
+        v[i] = rp[(int64_t)t * skv];
+        s += (double)to_f32<T>(v[i]);
+      }
+    }
+    s = wave_sum(s);
+    const T den = add_tiny<T>(from_f64<T>(s));      // (row sum + 1e-12) in the model dtype
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int t = lane + WAVE * i;
+      if (t < ntok) acc[i] += (double)to_f32<T>(div_t<T>(v[i], den));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int t = lane + WAVE * i;
+    if (t < ntok) part[wid][t] = acc[i];
+  }
+  __syncthreads();
+  const T nheads = from_f32<T>((float)heads);
+  for (int t = threadIdx.x; t < ntok; t += NT) {
+    double m = 0.0;
+    for (int w = 0; w < NT / WAVE; ++w) m += part[w][t];
+    out[(int64_t)b * ntok + t] = div_t<T>(from_f64<T>(m), nheads);    // mean = sum / N in dtype T
+  }
+}
+
+// mean over steps.  steps [Tn, n] -> out [n]
+template <typename T>
+__global__ __launch_bounds__(NT) void attn_finalize_kernel(const T* __restrict__ steps, int Tn, int64_t n,
+                                                           T* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int t = 0; t < Tn; ++t) acc += (double)to_f32<T>(steps[(int64_t)t * n + i]);
+  out[i] = div_t<T>(from_f64<T>(acc), from_f32<T>((float)Tn));
+}
+
+// ---- A3: one workgroup per mask -----------------------------------------------------------
+__global__ __launch_bounds__(NT) void mask_postproc_kernel(const float* __restrict__ mask, int n, int ks, float coe,
+                                                           float* __restrict__ out) {
+  __shared__ float x[32 * 32];
+  __shared__ double red[NT / WAVE];
+  __shared__ float fred[2][NT / WAVE];
+  const int b = blockIdx.x, cnt = n * n;
+  const float* m = mask + (size_t)b * cnt;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    const float v = m[k];
+    x[k] = v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    fred[0][threadIdx.x / WAVE] = mn;
+    fred[1][threadIdx.x / WAVE] = mx;
+  }
+  __syncthreads();
+  mn = fred[0][0]; mx = fred[1][0];
+  for (int w = 1; w < NT / WAVE; ++w) { mn = fminf(mn, fred[0][w]); mx = fmaxf(mx, fred[1][w]); }
+  // normalize("min"): (mat - min) / (max - min)
+  const float range = fsub(mx, mn);
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    const float v = fsub(x[k], mn) / range;
+    x[k] = v;
+    acc += (double)v;
+  }
+  // enhance: mat - mean ; / std (unbiased) ; * coe ; sigmoid ; clamp(0,1)
+  const float mean = (float)(block_sum(acc, red) / (double)cnt);
+  acc = 0.0;
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    const float v = fsub(x[k], mean);
+    x[k] = v;
+    acc += (double)v;
+  }
+  const double mu2 = block_sum(acc, red) / (double)cnt;
+  acc = 0.0;
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    const double d = (double)x[k] - mu2;
+    acc += d * d;
+  }
+  const float sd = (float)sqrt(block_sum(acc, red) / (double)(cnt - 1));
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    float v = x[k] / sd;
+    v = fmul(v, coe);
+    v = (float)(1.0 / (1.0 + exp(-(double)v)));
+    x[k] = fminf(fmaxf(v, 0.0f), 1.0f);
+  }
+  __syncthreads();
+  // Conv2d(1,1,ks,padding=(ks-1)/2,padding_mode="replicate"), all weights 1/ks^2
+  const int pad = (ks - 1) / 2;
+  const float wgt = 1.0f / (float)(ks * ks);
+  for (int k = threadIdx.x; k < cnt; k += NT) {
+    const int r = k / n, c = k - r * n;
+    double a = 0.0;
+    for (int dy = -pad; dy <= pad; ++dy)
+      for (int dx = -pad; dx <= pad; ++dx) {
+        const int rr = min(max(r + dy, 0), n - 1), cc = min(max(c + dx, 0), n - 1);
+        a += (double)fmul(x[rr * n + cc], wgt);
+      }
+    out[(size_t)b * cnt + k] = (float)a;
+  }
+}
+
+// ---- A4: Pillow's 8-bit separable resampler (ImagingResampleHorizontal/Vertical_8bpc) ----
+constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
+
+__device__ __forceinline__ uint8_t pil_clip8(int v) { return (uint8_t)min(max(v >> PIL_PRECISION_BITS, 0), 255); }
+
+// ToPILImage on a float tensor: pic.mul(255).byte()  (truncating cast)
+__device__ __forceinline__ uint8_t to_pil_u8(float v) {
+  const float s = fmul(v, 255.0f);
+  return (uint8_t)min(max((int)truncf(s), 0), 255);
+}
+
+// horizontal pass: tmp[b][y][xx], one thread per output.  grid = (ceil(out_w/NT), h, B)
+__global__ __launch_bounds__(NT) void lanczos_h_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
+                                                       int h, int w, int out_w, const int32_t* __restrict__ bounds,
+                                                       const int32_t* __restrict__ kk, int ksize,
+                                                       uint8_t* __restrict__ tmp) {
+  const int xx = blockIdx.x * NT + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (xx >= out_w) return;
+  const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
+  const int32_t* k = kk + (size_t)xx * ksize;
+  const size_t row = ((size_t)b * h + y) * w;
+  int ss = 1 << (PIL_PRECISION_BITS - 1);
+  for (int x = 0; x < cnt; ++x) {
+    const int px = mf ? (int)to_pil_u8(mf[row + xmin + x]) : (int)mu[row + xmin + x];
+    ss += px * k[x];
+  }
+  tmp[((size_t)b * h + y) * out_w + xx] = pil_clip8(ss);
+}
+
+// vertical pass.  grid = (ceil(out_w/NT), out_h, B)
+__global__ __launch_bounds__(NT) void lanczos_v_kernel(const uint8_t* __restrict__ tmp, int h, int out_w, int out_h,
+                                                       const int32_t* __restrict__ bounds,
+                                                       const int32_t* __restrict__ kk, int ksize,
+                                                       uint8_t* __restrict__ out) {
+  const int xx = blockIdx.x * NT + threadIdx.x, yy = blockIdx.y, b = blockIdx.z;
+  if (xx >= out_w) return;
+  const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
+  const int32_t* k = kk + (size_t)yy * ksize;
+  int ss = 1 << (PIL_PRECISION_BITS - 1);
+  for (int y = 0; y < cnt; ++y) ss += (int)tmp[((size_t)b * h + ymin + y) * out_w + xx] * k[y];
+  out[((size_t)b * out_h + yy) * out_w + xx] = pil_clip8(ss);
+}
+
+// copy / quantise pass used when an axis keeps its size (Pillow skips that pass)
+__global__ __launch_bounds__(NT) void quantise_copy_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
+                                                           size_t n, uint8_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+  if (i < n) out[i] = mf ? to_pil_u8(mf[i]) : mu[i];
+}
+
+template <typename T>
+static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
+                       const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
+  hipLaunchKernelGGL((attn_reduce_step_kernel<T>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh, row_off,
+                     skv, starts, starts_mod, ntok, (T*)out);
+  return check_launch("attn_reduce_step_kernel");
+}
+template <typename T>
+static int launch_finalize(const void* steps, int Tn, int64_t n, void* out, hipStream_t st) {
+  hipLaunchKernelGGL((attn_finalize_kernel<T>), dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, (const T*)steps,
+                     Tn, n, (T*)out);
+  return check_launch("attn_finalize_kernel");
+}
+
+static int check_attn_dtype(int dtype, const char* who) {
+  if (dtype == ATTWARP_F32 || dtype == ATTWARP_F16 || dtype == ATTWARP_BF16) return 0;
+  return fail(ATTWARP_E_ARG, "%s: dtype must be F32, F16 or BF16 (got %d)", who, dtype);
+}
+
+}  // namespace attwarp
+
+using namespace attwarp;
+
+extern "C" int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int heads, int q_len, int kv_len,
+                                        int64_t stride_b, int64_t stride_h, int64_t stride_q, int64_t stride_kv,
+                                        const int32_t* starts, int ntok, void* out, void* stream) {
+  ATTWARP_REQUIRE(attn && starts && out, "attn_reduce_step: null pointer");
+  ATTWARP_REQUIRE(B > 0 && heads > 0 && q_len > 0 && kv_len > 0 && ntok > 0, "attn_reduce_step: non-positive size");
+  if (check_attn_dtype(dtype, "attn_reduce_step")) return ATTWARP_E_ARG;
+  if (ntok > MAX_NTOK) return fail(ATTWARP_E_UNSUPPORTED, "attn_reduce_step: ntok=%d > %d", ntok, MAX_NTOK);
+  const int64_t row_off = (int64_t)(q_len - 1) * stride_q;
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ATTWARP_F32: return launch_step<float>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
+    case ATTWARP_F16: return launch_step<__half>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
+    default: return launch_step<__hip_bfloat16>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
+  }
+}
+
+extern "C" int attwarp_attn_finalize(const void* steps, int dtype, int T, int B, int ntok, void* out, void* stream) {
+  ATTWARP_REQUIRE(steps && out, "attn_finalize: null pointer");
+  ATTWARP_REQUIRE(T > 0 && B > 0 && ntok > 0, "attn_finalize: non-positive size");
+  if (check_attn_dtype(dtype, "attn_finalize")) return ATTWARP_E_ARG;
+  const int64_t n = (int64_t)B * ntok;
+  hipStream_t st = as_stream(stream);
+  switch (dtype) {
+    case ATTWARP_F32: return launch_finalize<float>(steps, T, n, out, st);
+    case ATTWARP_F16: return launch_finalize<__half>(steps, T, n, out, st);
+    default: return launch_finalize<__hip_bfloat16>(steps, T, n, out, st);
+  }
+}
+
+extern "C" size_t attwarp_attn_reduce_stack_workspace_bytes(int dtype, int T, int B, int ntok) {
+  if (T <= 0 || B <= 0 || ntok <= 0) return 0;
+  return (size_t)T * B * ntok * (dtype == ATTWARP_F32 ? 4 : 2);
+}
+
+extern "C" int attwarp_attn_reduce_stack(const void* rows, int dtype, int T, int B, int heads, int kv_len,
+                                         const int32_t* starts, int ntok, void* out, void* ws, void* stream) {
+  ATTWARP_REQUIRE(rows && starts && out && ws, "attn_reduce_stack: null pointer");
+  ATTWARP_REQUIRE(T > 0 && B > 0 && heads > 0 && kv_len > 0 && ntok > 0, "attn_reduce_stack: non-positive size");
+  if (check_attn_dtype(dtype, "attn_reduce_stack")) return ATTWARP_E_ARG;
+  if (ntok > MAX_NTOK) return fail(ATTWARP_E_UNSUPPORTED, "attn_reduce_stack: ntok=%d > %d", ntok, MAX_NTOK);
+  hipStream_t st = as_stream(stream);
+  const int64_t sb = (int64_t)heads * kv_len, sh = kv_len;
+  int rc;
+  switch (dtype) {
+    case ATTWARP_F32: rc = launch_step<float>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
+    case ATTWARP_F16: rc = launch_step<__half>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
+    default: rc = launch_step<__hip_bfloat16>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
+  }
+  if (rc) return rc;
+  return attwarp_attn_finalize(ws, dtype, T, B, ntok, out, stream);
+}
+
+extern "C" int attwarp_mask_postproc(const float* mask, int B, int n, int kernel_size, float enhance_coe, float* out,
+                                     void* stream) {
+  ATTWARP_REQUIRE(mask && out, "mask_postproc: null pointer");
+  ATTWARP_REQUIRE(B > 0 && n > 0, "mask_postproc: non-positive size");
+  ATTWARP_REQUIRE(kernel_size > 0 && (kernel_size & 1), "mask_postproc: kernel_size must be odd (got %d)", kernel_size);
+  if (n > 32 || kernel_size > 7) return fail(ATTWARP_E_UNSUPPORTED, "mask_postproc: n <= 32 and kernel_size <= 7");
+  hipLaunchKernelGGL(mask_postproc_kernel, dim3(B), dim3(NT), 0, as_stream(stream), mask, n, kernel_size, enhance_coe,
+                     out);
+  return check_launch("mask_postproc_kernel");
+}
+
+extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_t* mask_u8, int B, int h, int w,
+                                             int out_h, int out_w, const int32_t* bounds_x, const int32_t* kk_x,
+                                             int ksize_x, const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
+                                             uint8_t* tmp, uint8_t* out, void* stream) {
+  ATTWARP_REQUIRE((mask_f32 != nullptr) != (mask_u8 != nullptr), "mask_upsample_lanczos: pass exactly one of mask_f32 / mask_u8");
+  ATTWARP_REQUIRE(out, "mask_upsample_lanczos: null output");
+  ATTWARP_REQUIRE(B > 0 && h > 0 && w > 0 && out_h > 0 && out_w > 0, "mask_upsample_lanczos: non-positive size");
+  if (B > 65535 || h > 65535 || out_h > 65535) return fail(ATTWARP_E_UNSUPPORTED, "mask_upsample_lanczos: dims > 65535");
+  const bool need_h = out_w != w, need_v = out_h != h;
+  ATTWARP_REQUIRE(!need_h || (bounds_x && kk_x && ksize_x > 0), "mask_upsample_lanczos: missing x coefficients");
+  ATTWARP_REQUIRE(!need_v || (bounds_y && kk_y && ksize_y > 0), "mask_upsample_lanczos: missing y coefficients");
+  ATTWARP_REQUIRE(!(need_h && need_v) || tmp, "mask_upsample_lanczos: tmp workspace required for a two-pass resize");
+  hipStream_t st = as_stream(stream);
+  if (!need_h && !need_v) {
+    const size_t n = (size_t)B * h * w;
+    hipLaunchKernelGGL(quantise_copy_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, mask_f32, mask_u8, n, out);
+    return check_launch("quantise_copy_kernel");
+  }
+  const uint8_t* vsrc = mask_u8;
+  if (need_h) {
+    uint8_t* hdst = need_v ? tmp : out;
+    hipLaunchKernelGGL(lanczos_h_kernel, dim3((out_w + NT - 1) / NT, h, B), dim3(NT), 0, st, mask_f32, mask_u8, h, w,
+                       out_w, bounds_x, kk_x, ksize_x, hdst);
+    int rc = check_launch("lanczos_h_kernel");
+    if (rc) return rc;
+    vsrc = hdst;
+  } else if (mask_f32) {
+    ATTWARP_REQUIRE(tmp, "mask_upsample_lanczos: tmp workspace required to quantise a float mask");
+    const size_t n = (size_t)B * h * w;
+    hipLaunchKernelGGL(quantise_copy_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, mask_f32, nullptr, n, tmp);
+    int rc = check_launch("quantise_copy_kernel");
+    if (rc) return rc;
+    vsrc = tmp;
+  }
+  if (need_v) {
+    hipLaunchKernelGGL(lanczos_v_kernel, dim3((out_w + NT - 1) / NT, out_h, B), dim3(NT), 0, st, vsrc, h, out_w, out_h,
+                       bounds_y, kk_y, ksize_y, out);
+    return check_launch("lanczos_v_kernel");
+  }
+  return ATTWARP_OK;
+}

@@ -1,0 +1,107 @@
+// Shared host/device helpers for libattwarp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/attwarp.h"
+
+namespace attwarp {
+
+constexpr int WAVE = 64;  // CDNA wavefront width
+
+// ---- thread-local error text -------------------------------------------------
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+#define ATTWARP_REQUIRE(cond, ...)                                   \
+  do {                                                               \
+    if (!(cond)) return ::attwarp::fail(ATTWARP_E_ARG, __VA_ARGS__); \
+  } while (0)
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ATTWARP_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return ATTWARP_OK;
+}
+
+// ---- float arithmetic with one rounding per operation -------------------------
+// The oracle defines every float32 stage as a sequence of individually rounded
+// operations; the library is built with -ffp-contract=off and these wrappers make
+// the intent explicit where bit parity depends on it.
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+// a + t*(b-a), three roundings (no FMA): the oracle's _lerp
+__device__ __forceinline__ float lerp_rn(float a, float b, float t) { return fadd(a, fmul(t, fsub(b, a))); }
+
+// ---- wave / block reductions ---------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+
+// Block-wide sum in double. `scratch` needs blockDim.x/64 doubles. All threads get the result.
+// The order is fixed (lane tree, then waves ascending) so results are run-to-run identical.
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE, nw = (blockDim.x + WAVE - 1) / WAVE;
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < nw; ++i) t += scratch[i];
+  return t;
+}
+
+// ---- element loads as float / double -------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <> __device__ __forceinline__ float to_f32<uint8_t>(uint8_t v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T> __device__ __forceinline__ T from_f64(double v);
+template <> __device__ __forceinline__ float from_f64<float>(double v) { return (float)v; }
+// double -> half/bf16 with a SINGLE rounding: round-to-odd into float first
+// (truncate towards zero, set the sticky LSB), then round-to-nearest-even.
+__device__ __forceinline__ float f64_to_f32_round_odd(double v) {
+  float f = (float)v;
+  if ((double)f != v) {
+    uint32_t u = __float_as_uint(f);
+    if (fabs((double)f) > fabs(v)) u -= 1u;  // magnitude bits: one step towards zero
+    u |= 1u;
+    f = __uint_as_float(u);
+  }
+  return f;
+}
+template <> __device__ __forceinline__ __half from_f64<__half>(double v) {
+  return __float2half_rn(f64_to_f32_round_odd(v));
+}
+template <> __device__ __forceinline__ __hip_bfloat16 from_f64<__hip_bfloat16>(double v) {
+  return __float2bfloat16(f64_to_f32_round_odd(v));
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace attwarp

@@ -1,0 +1,154 @@
+/*
+ * attwarp.h -- C ABI of libattwarp_hip.so, the MI355X (gfx950) implementation of
+ * AttWarp's attention-guided image-warping hot path.
+ *
+ * The reference (dwipddalal/AttWarp) is pure Python: it has no FFI, custom-op or
+ * plugin layer for this path, so there is no existing binding to mirror.  Each
+ * entry point below replaces one reference *function* (cited as file:line,
+ * AGW = "Attention Guided Warping", MN = "model/marginalnet_full_dataset"); the
+ * Python package attwarp_amd re-exposes the reference's names on top of these
+ * through ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
+ *   - all tensors are dense, row-major ("C contiguous") with the shape given in
+ *     the comment, except attwarp_attn_reduce_step which takes element strides;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every
+ *     call only enqueues work on that stream, never synchronises, never
+ *     allocates: outputs and workspaces are owned by the caller;
+ *   - return value: 0 on success, a negative ATTWARP_E_* code on failure (nothing
+ *     is enqueued then); attwarp_last_error() gives a thread-local message;
+ *   - the library keeps no global mutable state: transform selection etc. are
+ *     arguments (the reference keeps them in module globals,
+ *     AGW/new_method.py:159-163,378-403).
+ */
+#ifndef ATTWARP_H
+#define ATTWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATTWARP_VERSION 100 /* 0.1.0 */
+
+#if defined(__GNUC__)
+#define ATTWARP_API __attribute__((visibility("default")))
+#else
+#define ATTWARP_API
+#endif
+
+/* element types */
+enum { ATTWARP_F32 = 0, ATTWARP_F16 = 1, ATTWARP_BF16 = 2, ATTWARP_U8 = 3, ATTWARP_F64 = 4 };
+/* image layouts: HWC = [B,H,W,C] interleaved (OpenCV / numpy), CHW = [B,C,H,W] planar (torch) */
+enum { ATTWARP_HWC = 0, ATTWARP_CHW = 1 };
+/* resample arithmetic: EXACT = bilinear on unquantised coordinates; CV2 = OpenCV's
+ * 1/32-pixel coordinate quantisation + table weights (unpinned) */
+enum { ATTWARP_EXACT = 0, ATTWARP_CV2 = 1 };
+/* attention transforms, AGW/new_method.py:134-179 */
+enum { ATTWARP_T_IDENTITY = 0, ATTWARP_T_SQUARE = 1, ATTWARP_T_SQRT = 2, ATTWARP_T_EXP = 3, ATTWARP_T_LOG = 4 };
+
+/* error codes */
+enum {
+  ATTWARP_OK = 0,
+  ATTWARP_E_ARG = -1,      /* bad argument (null pointer, non-positive size, unknown enum) */
+  ATTWARP_E_UNSUPPORTED = -2, /* valid request this build cannot serve (size limit, dtype) */
+  ATTWARP_E_LAUNCH = -3    /* HIP reported an error while enqueueing */
+};
+
+ATTWARP_API int attwarp_version(void);
+ATTWARP_API const char* attwarp_last_error(void);
+
+/* ---- A1: BatchMaskHookLogger._process_attention, AGW/attention_extraction/llava.py:385-396
+ * attn [B,heads,q,kv] with element strides; for sample b uses row q-1, columns
+ * starts[b] .. starts[b]+ntok-1; per-head renormalisation (x / (sum + 1e-12)), mean over heads.
+ * out [B,ntok] in the same dtype (F32/F16/BF16).  starts: device int32[B]. */
+ATTWARP_API int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int heads, int q_len, int kv_len,
+                             int64_t stride_b, int64_t stride_h, int64_t stride_q, int64_t stride_kv,
+                             const int32_t* starts, int ntok, void* out, void* stream);
+
+/* ---- A2: BatchMaskHookLogger.finalize_batch, llava.py:401-411
+ * steps [T,B,ntok] -> out [B,ntok] = mean over T (same dtype). */
+ATTWARP_API int attwarp_attn_finalize(const void* steps, int dtype, int T, int B, int ntok, void* out, void* stream);
+
+/* ---- A1+A2 fused over a captured stack of last-query rows.
+ * rows [T,B,heads,kv] -> out [B,ntok]; equals finalize(step(rows[t]) for t).
+ * ws: workspace of attwarp_attn_reduce_stack_workspace_bytes(...) bytes ([T,B,ntok] step maps). */
+ATTWARP_API size_t attwarp_attn_reduce_stack_workspace_bytes(int dtype, int T, int B, int ntok);
+ATTWARP_API int attwarp_attn_reduce_stack(const void* rows, int dtype, int T, int B, int heads, int kv_len,
+                              const int32_t* starts, int ntok, void* out, void* ws, void* stream);
+
+/* ---- A3: revise_mask = normalize("min") -> enhance -> k x k box filter, llava.py:207-238
+ * mask [B,n,n] float32 -> out [B,n,n] float32 (n <= 32, odd kernel_size <= 7). */
+ATTWARP_API int attwarp_mask_postproc(const float* mask, int B, int n, int kernel_size, float enhance_coe,
+                          float* out, void* stream);
+
+/* ---- A4: ToPILImage (x*255, truncating cast) + PIL Image.resize(LANCZOS), llava.py:192-196,243,253
+ * mask_f32 [B,h,w] float32 in [0,1]  (or mask_u8 [B,h,w] if mask_f32 is NULL)
+ * -> out [B,out_h,out_w] uint8.  Coefficients: host-computed Pillow tables uploaded by the
+ * caller: bounds_* int32[out,2] = (first tap, tap count), kk_* int32[out,ksize] (22-bit fixed point).
+ * tmp: uint8 [B,h,out_w] workspace (horizontal pass output). */
+ATTWARP_API int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_t* mask_u8, int B, int h, int w,
+                                  int out_h, int out_w,
+                                  const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
+                                  const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
+                                  uint8_t* tmp, uint8_t* out, void* stream);
+
+/* ---- A5: F.adaptive_avg_pool2d(A,(oh,ow)), call sites MN/trainer.py:197,433,465
+ * A [B,H,W] float32 -> out [B,oh,ow] float32 (oh,ow <= 64). */
+ATTWARP_API int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, float* out, void* stream);
+
+/* ---- A6: gt_marginals, MN/checkpoint_utils.py:43-51
+ * A [B,H,W] float32 -> px [B,W], py [B,H] float32.  ws: workspace of
+ * attwarp_axis_sums_workspace_bytes(B,H,W) bytes. */
+ATTWARP_API size_t attwarp_axis_sums_workspace_bytes(int B, int H, int W);
+ATTWARP_API int attwarp_gt_marginals(const float* A, int B, int H, int W, float* px, float* py, void* ws, void* stream);
+
+/* ---- A7: safe_softmax(dim=1), MN/model.py:8-14.  logits [B,N] -> out [B,N], N <= 4096. */
+ATTWARP_API int attwarp_safe_softmax(const float* logits, int B, int N, float eps, float* out, void* stream);
+
+/* ---- A8: upsample_pdf_right_inverse, MN/checkpoint_utils.py:64-131
+ * y [N,Lo] float32 -> out [N,L] float32.  inv: device float64 [Lo,Lo] = (A A^T + eps I)^-1 of the
+ * adaptive-avg-pool1d matrix A[Lo,L] (24x24: computed once per (Lo,L,eps) on the host). Lo <= 64. */
+ATTWARP_API int attwarp_upsample_pdf_right_inverse(const float* y, int N, int Lo, int L, const double* inv,
+                                       float* out, void* stream);
+
+/* ---- A9: cdf_from_density, MN/checkpoint_utils.py:30-41.  p [B,L] -> F [B,L] float32. */
+ATTWARP_API int attwarp_cdf_from_density(const float* p, int B, int L, float* F, void* stream);
+
+/* ---- A10: _make_strictly_increasing (:17-28) and resample_cdf (:53-62). */
+ATTWARP_API int attwarp_make_strictly_increasing(const float* F, int B, int N, double eps, float* out, void* stream);
+ATTWARP_API int attwarp_resample_cdf(const float* F, int B, int N, int L, float* out, void* stream);
+
+/* ---- A11: grid construction of warp_from_cdf_torch, MN/checkpoint_utils.py:167-193
+ * F [B,L] float32 CDF -> map [B,n_out] float32 source coordinate per output index
+ * (the reference meshgrids two such vectors into dense maps for cv2.remap). L <= 16384. */
+ATTWARP_API int attwarp_axis_map_from_cdf(const float* F, int B, int L, int n_out, float* map, void* stream);
+
+/* ---- A8+A9+A11 fused: 24-bin PDFs -> maps, the MarginalNet inference chain MN/trainer.py:285-289
+ * px [B,Lo], py [B,Lo] -> map_x [B,W_out], map_y [B,H_out]; inv_x / inv_y as in A8 for L=W / L=H. */
+ATTWARP_API int attwarp_axis_maps_from_pdf(const float* px, const float* py, int B, int Lo, int W, int H,
+                               int W_out, int H_out, const double* inv_x, const double* inv_y,
+                               float* map_x, float* map_y, void* stream);
+
+/* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
+ * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.
+ * ws: workspace of attwarp_axis_sums_workspace_bytes(B,h,w) bytes. */
+ATTWARP_API int attwarp_axis_maps_from_attention(const void* att, int dtype, int B, int h, int w, int new_w, int new_h,
+                                     int transform, double exp_scale, double exp_divisor, int apply_inverse,
+                                     float* map_x, float* map_y, void* ws, void* stream);
+
+/* ---- A12 / A13 tail: cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps,
+ * AGW/new_method.py:268-271, MN/checkpoint_utils.py:195-198.
+ * src [B,H,W,C] (HWC) or [B,C,H,W] (CHW), dtype F32 or U8 -> dst same layout with (H_out,W_out).
+ * map_x [B,W_out], map_y [B,H_out] float32 source coordinates.  C <= 4. */
+ATTWARP_API int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int layout, int B, int C, int H, int W,
+                           int H_out, int W_out, const float* map_x, const float* map_y, int mode,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATTWARP_H */

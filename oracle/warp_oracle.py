@@ -342,9 +342,11 @@ def right_inverse_core(L_out: int, L_in: int, eps: float = 1e-8) -> np.ndarray:
     pooling matrix -- the tiny system the reference solves by LU per call
     (MN/checkpoint_utils.py:116-120)."""
     A = pooling_matrix(L_out, L_in, F32).astype(F64)
-    AAT = (A @ A.T).astype(F32).astype(F64)      # reference forms A@A.T in float32
+    # BLAS-free (hence reproducible) Gram matrix, then rounded to the float32 the reference forms it in
+    AAT = (A[:, None, :] * A[None, :, :]).sum(axis=2).astype(F32)
     if eps > 0:
-        AAT = (AAT.astype(F32) + (F32(eps) * np.eye(L_out, dtype=F32))).astype(F64)
+        AAT = (AAT + (F32(eps) * np.eye(L_out, dtype=F32))).astype(F32)
+    AAT = AAT.astype(F64)
     return np.linalg.inv(AAT)
 
 
@@ -367,7 +369,10 @@ def upsample_pdf_right_inverse(y: np.ndarray, target_len: int, eps: float = 1e-8
     L_out = yN.shape[1]
     L_in = int(target_len)
     inv = right_inverse_core(L_out, L_in, eps)
-    tmp = (yN.astype(F64) @ inv.T).astype(F32)                   # [N, L_out]
+    acc = np.zeros((yN.shape[0], L_out), dtype=F64)              # tmp[n,k] = sum_j y[n,j]*inv[k,j], j ascending
+    for j in range(L_out):
+        acc = acc + yN[:, j:j + 1].astype(F64) * inv[:, j][None, :]
+    tmp = acc.astype(F32)                                        # [N, L_out]
     A = pooling_matrix(L_out, L_in, F32)
     x = np.zeros((yN.shape[0], L_in), dtype=F32)
     for k in range(L_out):
