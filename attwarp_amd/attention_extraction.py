@@ -1,0 +1,258 @@
+"""Drop-in for the hot-path half of ``Attention Guided Warping/attention_extraction/llava.py``:
+``BatchMaskHookLogger`` (reference :338-448), ``MaskHookLogger`` (:37-153), ``revise_mask``
+(:223-238), ``blend_mask``'s mask branch (:240-253).
+
+The per-sample Python loops of tiny torch ops in the reference (:388-395) become one HIP launch per
+generation step; the mask post-processing and the PIL LANCZOS up-sample run on the GPU and return
+device tensors, so nothing has to cross PCIe before the warp.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib, _tables
+from ._lib import call, ptr, require_gpu, stream_ptr
+
+NUM_IMAGE_TOKENS = 576  # 24 x 24 patches for LLaVA-1.5 (reference :350)
+
+
+def attn_reduce_step(attn_weights: torch.Tensor, starts: torch.Tensor, ntok: int) -> torch.Tensor:
+    """One step of attention aggregation: [B,heads,q,kv] -> [B,ntok] (same dtype).
+    ``starts``: int32 device tensor [B] of per-sample image-token offsets."""
+    dev = require_gpu(attn_weights, starts)
+    B, heads, q, kv = attn_weights.shape
+    out = torch.empty(B, ntok, device=dev, dtype=attn_weights.dtype)
+    sb, sh, sq, skv = attn_weights.stride()
+    with torch.cuda.device(dev):
+        call("attwarp_attn_reduce_step", ptr(attn_weights), _lib.dtype_id(attn_weights), B, heads, q, kv, sb, sh, sq,
+             skv, ptr(starts), int(ntok), ptr(out), stream_ptr(dev))
+    return out
+
+
+def attn_finalize(steps: torch.Tensor) -> torch.Tensor:
+    """Mean over generation steps: [T,B,ntok] -> [B,ntok]."""
+    dev = require_gpu(steps)
+    s = steps.contiguous()
+    T, B, ntok = s.shape
+    out = torch.empty(B, ntok, device=dev, dtype=s.dtype)
+    with torch.cuda.device(dev):
+        call("attwarp_attn_finalize", ptr(s), _lib.dtype_id(s), T, B, ntok, ptr(out), stream_ptr(dev))
+    return out
+
+
+def attn_reduce_stack(rows: torch.Tensor, starts: torch.Tensor, ntok: int = NUM_IMAGE_TOKENS) -> torch.Tensor:
+    """Fused aggregation of a captured stack of last-query rows [T,B,heads,kv] -> [B,ntok]."""
+    dev = require_gpu(rows, starts)
+    r = rows.contiguous()
+    T, B, heads, kv = r.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.attwarp_attn_reduce_stack_workspace_bytes(_lib.dtype_id(r), T, B, ntok), device=dev,
+                     dtype=torch.uint8)
+    out = torch.empty(B, ntok, device=dev, dtype=r.dtype)
+    with torch.cuda.device(dev):
+        call("attwarp_attn_reduce_stack", ptr(r), _lib.dtype_id(r), T, B, heads, kv, ptr(starts), int(ntok), ptr(out),
+             ptr(ws), stream_ptr(dev))
+    return out
+
+
+class BatchMaskHookLogger(object):
+    """Same interface as the reference class (:338-448): per-sample image-token ranges, a forward
+    hook on one decoder layer's attention, ``finalize_batch() -> List[Tensor[24,24]]``."""
+
+    def __init__(self, model, device, layer_index: int = 20):
+        self.device = device
+        self.model = model
+        self.layer_index = layer_index
+        self.hook_handle = None
+        self.num_image_tokens = NUM_IMAGE_TOKENS
+        self.image_token_starts = None
+        self.image_token_ends = None
+        self.batch_size = 0
+        self.step_attentions: List[torch.Tensor] = []
+        self._original_forward = None
+        self._starts_dev: Optional[torch.Tensor] = None
+
+    def set_batch_image_token_ranges(self, starts: Sequence[int], ends: Sequence[int]):
+        assert len(starts) == len(ends)
+        self.image_token_starts = list(starts)
+        self.image_token_ends = list(ends)
+        self.batch_size = len(starts)
+        self._starts_dev = None
+
+    @torch.no_grad()
+    def _attention_hook(self, module, input, output):
+        if not isinstance(output, tuple) or len(output) < 2:
+            return
+        attn_weights = output[1]
+        if attn_weights is None or not isinstance(attn_weights, torch.Tensor):
+            return
+        if len(attn_weights.shape) != 4:
+            return
+        self._process_attention(attn_weights)
+
+    @torch.no_grad()
+    def _process_attention(self, attn_weights: torch.Tensor):
+        bsz, kv = attn_weights.shape[0], attn_weights.shape[-1]
+        lens = {min(self.image_token_ends[b], kv) - self.image_token_starts[b] for b in range(bsz)}
+        if len(lens) != 1:
+            # the reference's torch.stack raises the same way when the slices differ in length
+            raise RuntimeError(f"stack expects each tensor to be equal size, got image-token slice lengths {sorted(lens)}")
+        ntok = lens.pop()
+        if self._starts_dev is None or self._starts_dev.device != attn_weights.device:
+            self._starts_dev = torch.tensor(self.image_token_starts, dtype=torch.int32, device=attn_weights.device)
+        self.step_attentions.append(attn_reduce_step(attn_weights, self._starts_dev[:bsz], ntok))
+
+    @torch.no_grad()
+    def finalize_batch(self) -> List[torch.Tensor]:
+        if len(self.step_attentions) == 0:
+            return [torch.ones(self.num_image_tokens, device=self.device) / self.num_image_tokens
+                    for _ in range(self.batch_size)]
+        avg = attn_finalize(torch.stack(self.step_attentions, dim=0))
+        return [avg[i].view(24, 24) for i in range(self.batch_size)]
+
+    def reinit(self):
+        self.step_attentions = []
+        self.image_token_starts = None
+        self.image_token_ends = None
+        self.batch_size = 0
+        self._starts_dev = None
+
+    def register_hook_and_patch(self):
+        """Hook the target layer's attention module and force ``output_attentions=True`` for it only."""
+        self.remove_hook_and_unpatch()
+        layer_attn = self.model.model.layers[self.layer_index].self_attn
+        self.hook_handle = layer_attn.register_forward_hook(self._attention_hook)
+        original = layer_attn.forward
+        self._original_forward = original
+
+        def forced(*args, **kwargs):
+            kwargs["output_attentions"] = True
+            return original(*args, **kwargs)
+
+        layer_attn.forward = forced
+
+    def remove_hook_and_unpatch(self):
+        if self.hook_handle is not None:
+            self.hook_handle.remove()
+            self.hook_handle = None
+        if self._original_forward is not None:
+            self.model.model.layers[self.layer_index].self_attn.forward = self._original_forward
+            self._original_forward = None
+
+
+def batch_hook_logger(model, device, layer_index: int = 20) -> BatchMaskHookLogger:
+    """Reference :451-462."""
+    prs = BatchMaskHookLogger(model, device, layer_index)
+    model.config.output_attentions = False
+    prs.register_hook_and_patch()
+    model.batch_hooklogger = prs
+    return prs
+
+
+class MaskHookLogger(object):
+    """Single-sample twin (reference :37-153): one image-token range for the whole batch,
+    ``finalize()`` returns the flat [ntok] mean over steps and batch rows."""
+
+    def __init__(self, model, device, layer_index: int = 20):
+        self.device = device
+        self.attns: List[torch.Tensor] = []
+        self.model = model
+        self.layer_index = layer_index
+        self.hook_handle = None
+        self.image_token_start = None
+        self.image_token_end = None
+        self.num_image_tokens = NUM_IMAGE_TOKENS
+
+    def set_image_token_range(self, start, end):
+        self.image_token_start = start
+        self.image_token_end = end
+
+    @torch.no_grad()
+    def _process_attention(self, attn_weights: torch.Tensor):
+        kv = attn_weights.shape[-1]
+        if self.image_token_start is None or self.image_token_end is None:
+            st, ed = 1, min(1 + self.num_image_tokens, kv)
+        else:
+            st, ed = self.image_token_start, min(self.image_token_end, kv)
+        starts = torch.full((attn_weights.shape[0],), st, dtype=torch.int32, device=attn_weights.device)
+        self.attns.append(attn_reduce_step(attn_weights, starts, ed - st))
+
+    @torch.no_grad()
+    def finalize(self) -> torch.Tensor:
+        if len(self.attns) == 0:
+            return torch.ones(self.num_image_tokens, device=self.device) / self.num_image_tokens
+        rows = torch.cat(self.attns, dim=0)          # [steps*batch, ntok]
+        return attn_finalize(rows.unsqueeze(1))[0]
+
+    def reinit(self):
+        self.attns = []
+        self.image_token_start = None
+        self.image_token_end = None
+
+
+def revise_mask(patch_mask: torch.Tensor, kernel_size: int = 3, enhance_coe: float = 10) -> torch.Tensor:
+    """Reference :223-238: min-max normalise -> z-score * coe -> sigmoid -> k x k mean filter with
+    replicate padding.  Accepts [n,n] (returns [n,n]) or a batch [B,n,n]."""
+    assert kernel_size % 2 == 1
+    dev = require_gpu(patch_mask)
+    m = patch_mask.detach().to(torch.float32).contiguous()
+    single = m.dim() == 2
+    if single:
+        m = m.unsqueeze(0)
+    B, n, n2 = m.shape
+    if n != n2:
+        raise ValueError(f"revise_mask expects square masks, got {tuple(m.shape)}")
+    out = torch.empty_like(m)
+    with torch.cuda.device(dev):
+        call("attwarp_mask_postproc", ptr(m), B, n, int(kernel_size), float(enhance_coe), ptr(out), stream_ptr(dev))
+    return out[0] if single else out
+
+
+def upsample_mask_lanczos(mask: torch.Tensor, size_wh) -> torch.Tensor:
+    """``toImg`` (x255, truncating uint8 cast) + ``PIL.Image.resize((W,H), LANCZOS)`` on the GPU
+    (reference :192-196, :243, :253).  mask [B,h,w] float32 in [0,1] or uint8 -> uint8 [B,H,W]."""
+    dev = require_gpu(mask)
+    m = mask.detach().contiguous()
+    if m.dim() == 2:
+        m = m.unsqueeze(0)
+    B, h, w = m.shape
+    W, H = int(size_wh[0]), int(size_wh[1])
+    is_f = m.dtype != torch.uint8
+    if is_f:
+        m = m.to(torch.float32)
+    bx = kx = by = ky = None
+    ksx = ksy = 0
+    if W != w:
+        bx, kx, ksx = _tables.lanczos_tables(w, W, dev)
+    if H != h:
+        by, ky, ksy = _tables.lanczos_tables(h, H, dev)
+    tmp = torch.empty(B, h, W, device=dev, dtype=torch.uint8)
+    out = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        call("attwarp_mask_upsample_lanczos", ptr(m) if is_f else None, None if is_f else ptr(m), B, h, w, H, W,
+             ptr(bx), ptr(kx), ksx, ptr(by), ptr(ky), ksy, ptr(tmp), ptr(out), stream_ptr(dev))
+    return out
+
+
+def blend_mask(image_path_or_pil_image, mask: torch.Tensor, enhance_coe, kernel_size, interpolate_method, grayscale):
+    """Reference :240-270.  Returns ``(image, mask_pil)``: the mask branch (revise -> uint8 ->
+    LANCZOS to the image size, mode "L") is computed on the GPU; the first element is the input
+    image itself -- the Jet heat-map overlay of the reference is visualisation only and is out of
+    scope (component 3)."""
+    from PIL import Image
+    if isinstance(image_path_or_pil_image, str):
+        image = Image.open(image_path_or_pil_image)
+    elif isinstance(image_path_or_pil_image, Image.Image):
+        image = image_path_or_pil_image
+    else:
+        raise NotImplementedError
+    lanczos = getattr(Image, "LANCZOS", 1)
+    if interpolate_method not in (lanczos, "LANCZOS", getattr(getattr(Image, "Resampling", Image), "LANCZOS", 1)):
+        raise NotImplementedError("only LANCZOS mask interpolation is implemented on the GPU path")
+    if not mask.is_cuda:
+        mask = mask.to(_lib.default_device())
+    rev = revise_mask(mask.float().reshape(24, 24), kernel_size=kernel_size, enhance_coe=enhance_coe)
+    up = upsample_mask_lanczos(rev.unsqueeze(0), image.size)[0]
+    return image, Image.fromarray(up.cpu().numpy(), mode="L")

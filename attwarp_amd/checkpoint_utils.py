@@ -107,7 +107,7 @@ def axis_maps_from_cdf(Fx_img: torch.Tensor, Fy_img: torch.Tensor, out_size: Tup
 
 
 def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "exact",
-                    channels_last: bool = False) -> torch.Tensor:
+                    channels_last: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps on a batch.
     img (B,C,H,W) [or (B,H,W,C) if channels_last] uint8/float32; maps (B,W_out), (B,H_out)."""
     dev = require_gpu(img, map_x, map_y)
@@ -120,7 +120,11 @@ def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor,
         B, C, H, W = x.shape
     W_out, H_out = map_x.shape[1], map_y.shape[1]
     mx, my = _f32c(map_x), _f32c(map_y)
-    out = torch.empty((B, H_out, W_out, C) if channels_last else (B, C, H_out, W_out), device=dev, dtype=x.dtype)
+    shape = (B, H_out, W_out, C) if channels_last else (B, C, H_out, W_out)
+    if out is None:
+        out = torch.empty(shape, device=dev, dtype=x.dtype)
+    elif tuple(out.shape) != shape or out.dtype != x.dtype or out.device != dev or not out.is_contiguous():
+        raise ValueError(f"remap_separable: out must be a contiguous {x.dtype} tensor of shape {shape} on {dev}")
     with torch.cuda.device(dev):
         call("attwarp_remap_bilinear", ptr(x), ptr(out), _lib.dtype_id(x), _lib.HWC if channels_last else _lib.CHW,
              B, C, H, W, H_out, W_out, ptr(mx), ptr(my), _lib.MODE_IDS[mode], stream_ptr(dev))

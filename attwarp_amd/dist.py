@@ -1,0 +1,85 @@
+"""Multi-GPU harness: one process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).
+
+The path shards embarrassingly: every image (with its attention stack) is warped independently, so
+ranks take contiguous blocks of the batch and never exchange image data.  The single collective is
+one broadcast of the flattened MarginalNet weights (11 MB at hidden=256) from rank 0 at start-up
+(SURVEY 8e); an optional all_gather moves a few counters for reporting.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend: str | None = None) -> Tuple[int, int, int]:
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world_size, local_rank).  Single-process runs need no environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of ``n_items`` owned by ``rank`` (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_module_weights(module: torch.nn.Module, src: int = 0) -> int:
+    """Broadcast every parameter and buffer of ``module`` from ``src`` as ONE flat message.
+    Returns the number of bytes moved (0 without a process group)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    if not tensors:
+        return 0
+    dev = tensors[0].device
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors]).to(dev)
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+        off += n
+    return flat.numel() * 4
+
+
+def all_gather_counters(values: Dict[str, float]) -> Dict[str, list]:
+    """Gather a few per-rank scalars (image counts, timings) on every rank."""
+    keys = sorted(values)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {k: [float(values[k])] for k in keys}
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return {k: [float(o[i]) for o in out] for i, k in enumerate(keys)}
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float) -> float:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,99 @@
+"""Batched, device-resident launcher of the hot path.
+
+The reference runs the path one image at a time on the host (``main_batched.py:243-303`` inner loop,
+``checkpoint_utils.py:157`` per-sample loop, PNG files in between).  Here a whole batch stays in HBM:
+
+``warp_from_attention_stack``  (BASELINE configs 2-4)
+    captured last-query attention rows [T,B,heads,kv]
+      -> A1+A2 aggregation                    (attwarp_attn_reduce_stack)
+      -> A6 marginals of the 24x24 map        (attwarp_gt_marginals)
+      -> A8+A9+A11 PDF -> CDF -> inverse maps (attwarp_axis_maps_from_pdf, one launch, both axes)
+      -> A12 bilinear resample                (attwarp_remap_bilinear)
+
+``warp_from_pdf``  (MarginalNet inference chain, MN/trainer.py:285-289)
+``warp_from_masks``  (main_batched chain: revise_mask -> uint8 -> LANCZOS -> float64 marginals -> warp)
+
+All launches go to the caller's current stream; no host synchronisation, so the whole step can be
+captured in a HIP graph (``capture_step``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, _tables
+from ._lib import call, ptr, require_gpu, stream_ptr
+from . import attention_extraction as ae
+from . import checkpoint_utils as cu
+from . import new_method as nm
+
+GRID = 24
+
+
+def axis_maps_from_pdf(px: torch.Tensor, py: torch.Tensor, size_hw: Tuple[int, int],
+                       out_size: Optional[Tuple[int, int]] = None, eps: float = 1e-8
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """px [B,n], py [B,n] low-resolution PDFs -> (map_x [B,W_out], map_y [B,H_out]).
+    Equals upsample_pdf_right_inverse(.).clamp_min(0) -> cdf_from_density -> grid construction."""
+    dev = require_gpu(px, py)
+    H, W = int(size_hw[0]), int(size_hw[1])
+    H_out, W_out = (H, W) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    x, y = px.detach().float().contiguous(), py.detach().float().contiguous()
+    B, n = x.shape
+    inv_x = _tables.right_inverse_inv(n, W, eps, dev)
+    inv_y = _tables.right_inverse_inv(n, H, eps, dev)
+    mx = torch.empty(B, W_out, device=dev, dtype=torch.float32)
+    my = torch.empty(B, H_out, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        call("attwarp_axis_maps_from_pdf", ptr(x), ptr(y), B, n, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y), ptr(mx),
+             ptr(my), stream_ptr(dev))
+    return mx, my
+
+
+def warp_from_pdf(images: torch.Tensor, px: torch.Tensor, py: torch.Tensor, out_size=None, channels_last=False,
+                  mode: str = "exact") -> torch.Tensor:
+    """images [B,C,H,W] (or [B,H,W,C]) float32/uint8; px [B,24] over x, py [B,24] over y."""
+    if channels_last:
+        H, W = images.shape[1], images.shape[2]
+    else:
+        H, W = images.shape[2], images.shape[3]
+    mx, my = axis_maps_from_pdf(px, py, (H, W), out_size)
+    return cu.remap_separable(images, mx, my, mode=mode, channels_last=channels_last)
+
+
+def warp_from_attention_stack(images: torch.Tensor, rows: torch.Tensor, starts: torch.Tensor, out_size=None,
+                              channels_last=False, mode: str = "exact") -> torch.Tensor:
+    """images: batch on the GPU; rows [T,B,heads,kv] last-query attention rows; starts int32 [B]."""
+    B = images.shape[0]
+    att = ae.attn_reduce_stack(rows, starts, ae.NUM_IMAGE_TOKENS).float().view(B, 1, GRID, GRID)
+    px, py = cu.gt_marginals(att)
+    return warp_from_pdf(images, px, py, out_size, channels_last, mode)
+
+
+def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500, 500), enhance_coe=10,
+                    kernel_size=3, transform="identity", exp_scale=1.0, exp_divisor=1.0, apply_inverse=False,
+                    mode: str = "exact") -> torch.Tensor:
+    """The ``main_batched.py:243-287`` chain for a batch of equally sized images.
+    images_u8 [B,H,W,3] uint8 (channel order is irrelevant to the warp); attn24 [B,24,24].
+    -> [B,H_out,W_out,3] uint8."""
+    B, H, W, _ = images_u8.shape
+    rev = ae.revise_mask(attn24.float(), kernel_size=kernel_size, enhance_coe=enhance_coe)
+    mota = ae.upsample_mask_lanczos(rev, (W, H))                       # uint8 [B,H,W]
+    mx, my = nm.attention_axis_maps(mota, out_size[1], out_size[0], transform, exp_scale, exp_divisor, apply_inverse)
+    return nm.remap_hwc(images_u8, mx, my, mode)
+
+
+def capture_step(fn, *args, warmup: int = 2):
+    """Capture ``fn(*args)`` (a function made only of this package's launches on static tensors) into a
+    HIP graph; returns (graph, output).  ``graph.replay()`` re-runs the step with one host call."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warmup):
+            out = fn(*args)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn(*args)
+    return g, out

@@ -655,20 +655,12 @@ def _remap_cv2_compat(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> 
     FY, FX = fy[:, None], fx[None, :]
     if src.dtype == np.uint8:
         scale = 1 << 15
-        tabs = np.stack([w00, w01, w10, w11], axis=-1).astype(F64) * scale
-        it = np.rint(tabs).astype(np.int64)           # saturate_cast<short>(v*32768)
-        it = np.clip(it, -32768, 32767)
-        # OpenCV fixes the table so every 2x2 kernel sums to exactly 32768 by
-        # adjusting the largest / smallest tap.
-        for a in range(32):
-            for b in range(32):
-                k = it[a, b]
-                diff = int(k.sum()) - scale
-                if diff != 0:
-                    if diff < 0:
-                        k[int(np.argmax(k))] -= diff
-                    else:
-                        k[int(np.argmin(k))] -= diff
+        tabs = np.stack([w00, w01, w10, w11], axis=-1).astype(F64) * scale     # exact integers a*b*32
+        # saturate_cast<short>: only the (0,0) entry (w00 = 1.0 -> 32768) saturates to 32767.
+        # OpenCV then patches that kernel to sum to 2**15 by adding 1 to a zero tap; with integer
+        # coordinates the result (p*32767 + q + 2**14) >> 15 equals p either way, so the patch is
+        # not observable and is not modelled.
+        it = np.clip(np.rint(tabs).astype(np.int64), -32768, 32767)
         acc = (p00.astype(np.int64) * it[FY, FX, 0][..., None] + p01.astype(np.int64) * it[FY, FX, 1][..., None]
                + p10.astype(np.int64) * it[FY, FX, 2][..., None] + p11.astype(np.int64) * it[FY, FX, 3][..., None])
         return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)

@@ -1,0 +1,228 @@
+/*
+ * warp_ref.c -- plain-C CPU restatement of the AttWarp warp hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  It restates, scalar and single threaded, the same arithmetic as
+ * oracle/warp_oracle.py (which is pinned to golden vectors captured from the reference) so the
+ * reference's CPU path can be timed on the GPU box, where neither the reference's Python nor
+ * OpenCV exist.  tests/test_oracle_c.py checks it bit-for-bit against the numpy oracle.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile): every float operation is
+ * individually rounded, like the oracle and the HIP kernels.
+ *
+ * Reference lines followed (AGW = "Attention Guided Warping", MN = "model/marginalnet_full_dataset"):
+ *   attn_reduce_stack   AGW/attention_extraction/llava.py:385-411
+ *   marginals24         MN/checkpoint_utils.py:43-51
+ *   right_inverse       MN/checkpoint_utils.py:64-131
+ *   cdf_from_density    MN/checkpoint_utils.py:30-41
+ *   axis_map_from_cdf   MN/checkpoint_utils.py:167-193 (np.interp restated from numpy's compiled_base.c)
+ *   remap_bilinear      AGW/new_method.py:268-271, MN/checkpoint_utils.py:195-198 (cv2.remap stand-in,
+ *                       exact bilinear, replicate border -- parity unpinned, see warp_oracle.py)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define API __attribute__((visibility("default")))
+
+/* ---- A1 + A2 (float32) ------------------------------------------------------------------ */
+API void oracle_attn_reduce_stack_f32(const float* rows, int T, int B, int heads, int kv, const int32_t* starts,
+                                      int ntok, float* out /* [B,ntok] */) {
+  double* acc_steps = (double*)calloc((size_t)ntok, sizeof(double));
+  double* acc_heads = (double*)calloc((size_t)ntok, sizeof(double));
+  for (int b = 0; b < B; ++b) {
+    memset(acc_steps, 0, sizeof(double) * ntok);
+    for (int t = 0; t < T; ++t) {
+      memset(acc_heads, 0, sizeof(double) * ntok);
+      for (int h = 0; h < heads; ++h) {
+        const float* r = rows + (((size_t)t * B + b) * heads + h) * kv + starts[b];
+        double s = 0.0;
+        for (int i = 0; i < ntok; ++i) s += (double)r[i];
+        const float den = (float)s + 1e-12f;
+        for (int i = 0; i < ntok; ++i) acc_heads[i] += (double)(r[i] / den);
+      }
+      for (int i = 0; i < ntok; ++i) acc_steps[i] += (double)((float)acc_heads[i] / (float)heads);
+    }
+    for (int i = 0; i < ntok; ++i) out[(size_t)b * ntok + i] = (float)acc_steps[i] / (float)T;
+  }
+  free(acc_steps);
+  free(acc_heads);
+}
+
+/* ---- A6 on an [n,n] map: px over columns, py over rows ----------------------------------- */
+API void oracle_marginals(const float* A, int H, int W, float* px, float* py) {
+  double tx = 0.0, ty = 0.0;
+  for (int x = 0; x < W; ++x) {
+    double s = 0.0;
+    for (int y = 0; y < H; ++y) { float v = A[(size_t)y * W + x]; s += (double)(v != v ? v : (v > 0.f ? v : 0.f)); }
+    px[x] = (float)s; tx += (double)px[x];
+  }
+  for (int y = 0; y < H; ++y) {
+    double s = 0.0;
+    for (int x = 0; x < W; ++x) { float v = A[(size_t)y * W + x]; s += (double)(v != v ? v : (v > 0.f ? v : 0.f)); }
+    py[y] = (float)s; ty += (double)py[y];
+  }
+  float dx = (float)tx; if (!(dx > 1e-6f)) dx = (dx != dx) ? dx : 1e-6f;
+  float dy = (float)ty; if (!(dy > 1e-6f)) dy = (dy != dy) ? dy : 1e-6f;
+  for (int x = 0; x < W; ++x) px[x] = px[x] / dx;
+  for (int y = 0; y < H; ++y) py[y] = py[y] / dy;
+}
+
+/* ---- A8: x_hat = A^T (inv y); inv = (A A^T + eps I)^-1 given as doubles [Lo,Lo] ------------ */
+API void oracle_right_inverse(const float* y, int Lo, int L, const double* inv, int clamp0, float* out) {
+  float tmp[64];
+  for (int k = 0; k < Lo; ++k) {
+    double acc = 0.0;
+    for (int j = 0; j < Lo; ++j) acc = acc + (double)y[j] * inv[(size_t)k * Lo + j];
+    tmp[k] = (float)acc;
+  }
+  for (int l = 0; l < L; ++l) out[l] = 0.0f;
+  for (int k = 0; k < Lo; ++k) {
+    const int s = (int)(((long long)k * L) / Lo);
+    const int e = (int)((((long long)(k + 1)) * L + Lo - 1) / Lo);
+    const float a = 1.0f / (float)((e - s) > 1 ? (e - s) : 1);
+    for (int l = s; l < e; ++l) out[l] = out[l] + tmp[k] * a;
+  }
+  if (clamp0) for (int l = 0; l < L; ++l) out[l] = out[l] > 0.0f ? out[l] : (out[l] != out[l] ? out[l] : 0.0f);
+}
+
+/* ---- A9 ------------------------------------------------------------------------------------ */
+API void oracle_cdf_from_density(const float* p, int L, float* F) {
+  double s = 0.0;
+  for (int k = 0; k < L; ++k) {
+    float v = p[k];
+    v = (v != v || isinf(v)) ? 0.0f : (v > 0.0f ? v : 0.0f);
+    F[k] = v; s += (double)v;
+  }
+  float den = (float)s; if (den < 1e-6f) den = 1e-6f;
+  double c = 0.0;
+  for (int k = 0; k < L; ++k) { c += (double)(F[k] / den); F[k] = (float)c; }
+  F[L - 1] = 1.0f;
+}
+
+/* ---- np.interp(x = 0..n_out-1, xp, fp = 0..len-1) ------------------------------------------- */
+static int search_with_guess(double key, const double* arr, int len, int guess) {
+  int imin = 0, imax = len;
+  if (key > arr[len - 1]) return len;
+  if (key < arr[0]) return -1;
+  if (len <= 4) { int i; for (i = 1; i < len && key >= arr[i]; ++i) {} return i - 1; }
+  if (guess > len - 3) guess = len - 3;
+  if (guess < 1) guess = 1;
+  if (key < arr[guess]) {
+    if (key < arr[guess - 1]) { imax = guess - 1; if (guess > 8 && key >= arr[guess - 8]) imin = guess - 8; }
+    else return guess - 1;
+  } else {
+    if (key < arr[guess + 1]) return guess;
+    if (key < arr[guess + 2]) return guess + 1;
+    imin = guess + 2;
+    if (guess < len - 8 - 1 && key < arr[guess + 8]) imax = guess + 8;
+  }
+  while (imin < imax) { const int imid = imin + ((imax - imin) >> 1); if (key >= arr[imid]) imin = imid + 1; else imax = imid; }
+  return imin - 1;
+}
+
+static void interp_identity_fp(const double* xp, int len, int n_out, float* map) {
+  int j = 0;
+  for (int i = 0; i < n_out; ++i) {
+    const double x = (double)i;
+    double r;
+    j = search_with_guess(x, xp, len, j);
+    if (j == -1) r = 0.0;
+    else if (j == len) r = (double)(len - 1);
+    else if (j == len - 1) r = (double)j;
+    else if (xp[j] == x) r = (double)j;
+    else {
+      const double slope = 1.0 / (xp[j + 1] - xp[j]);
+      r = slope * (x - xp[j]) + (double)j;
+      if (r != r) r = slope * (x - xp[j + 1]) + (double)(j + 1);
+    }
+    map[i] = (float)r;
+  }
+}
+
+/* ---- A11 ----------------------------------------------------------------------------------- */
+API void oracle_axis_map_from_cdf(const float* F, int L, int n_out, float* map) {
+  const int len = L + 1;
+  double* xn = (double*)malloc(sizeof(double) * len);
+  xn[0] = 0.0;
+  for (int k = 0; k < L; ++k) xn[k + 1] = (double)F[k] * (double)n_out;
+  xn[len - 1] = (double)n_out;
+  int tie = 0;
+  for (int k = 0; k + 1 < len; ++k) if (xn[k + 1] - xn[k] <= 0.0) tie = 1;
+  if (tie) {
+    const float c = (float)(1e-4 / (double)(n_out > 1 ? n_out : 1));
+    for (int k = 0; k < len; ++k) xn[k] += (double)(c * (float)k);
+  }
+  interp_identity_fp(xn, len, n_out, map);
+  free(xn);
+}
+
+/* ---- A12: bilinear, replicate border, separable maps.  layout 0 = HWC, 1 = CHW ------------------ */
+static inline float lerp_rn(float a, float b, float t) { float d = b - a; float m = t * d; return a + m; }
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+API void oracle_remap_bilinear_f32(const float* src, float* dst, int layout, int C, int H, int W, int Ho, int Wo,
+                                   const float* mx, const float* my) {
+  int* x0 = (int*)malloc(sizeof(int) * Wo * 2);
+  int* x1 = x0 + Wo;
+  float* fx = (float*)malloc(sizeof(float) * Wo);
+  for (int x = 0; x < Wo; ++x) {
+    const float fl = floorf(mx[x]);
+    fx[x] = mx[x] - fl;
+    float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)W ? (float)W : cl;
+    const int i = (int)cl;
+    x0[x] = clampi(i, 0, W - 1); x1[x] = clampi(i + 1, 0, W - 1);
+  }
+  for (int y = 0; y < Ho; ++y) {
+    const float fl = floorf(my[y]);
+    const float fy = my[y] - fl;
+    float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)H ? (float)H : cl;
+    const int i = (int)cl;
+    const int y0 = clampi(i, 0, H - 1), y1 = clampi(i + 1, 0, H - 1);
+    if (layout == 0) {
+      const float* r0 = src + (size_t)y0 * W * C;
+      const float* r1 = src + (size_t)y1 * W * C;
+      float* o = dst + (size_t)y * Wo * C;
+      for (int x = 0; x < Wo; ++x)
+        for (int c = 0; c < C; ++c) {
+          const float v0 = lerp_rn(r0[x0[x] * C + c], r1[x0[x] * C + c], fy);
+          const float v1 = lerp_rn(r0[x1[x] * C + c], r1[x1[x] * C + c], fy);
+          o[x * C + c] = lerp_rn(v0, v1, fx[x]);
+        }
+    } else {
+      for (int c = 0; c < C; ++c) {
+        const float* r0 = src + ((size_t)c * H + y0) * W;
+        const float* r1 = src + ((size_t)c * H + y1) * W;
+        float* o = dst + ((size_t)c * Ho + y) * Wo;
+        for (int x = 0; x < Wo; ++x) {
+          const float v0 = lerp_rn(r0[x0[x]], r1[x0[x]], fy);
+          const float v1 = lerp_rn(r0[x1[x]], r1[x1[x]], fy);
+          o[x] = lerp_rn(v0, v1, fx[x]);
+        }
+      }
+    }
+  }
+  free(x0);
+  free(fx);
+}
+
+/* ---- whole hot path for one image (float32): attention stack -> warped image ------------------- */
+API void oracle_warp_from_attention_stack_f32(const float* img, float* out, int layout, int C, int H, int W,
+                                              const float* rows /* [T,1,heads,kv] */, int T, int heads, int kv,
+                                              int start, const double* inv_x, const double* inv_y) {
+  float att[576], px[24], py[24];
+  const int32_t st = start;
+  oracle_attn_reduce_stack_f32(rows, T, 1, heads, kv, &st, 576, att);
+  oracle_marginals(att, 24, 24, px, py);
+  float* dx = (float*)malloc(sizeof(float) * (size_t)(2 * W + 2 * H));
+  float* dy = dx + W; float* mx = dy + H; float* my = mx + W;
+  oracle_right_inverse(px, 24, W, inv_x, 1, dx);
+  oracle_right_inverse(py, 24, H, inv_y, 1, dy);
+  oracle_cdf_from_density(dx, W, dx);
+  oracle_cdf_from_density(dy, H, dy);
+  oracle_axis_map_from_cdf(dx, W, W, mx);
+  oracle_axis_map_from_cdf(dy, H, H, my);
+  oracle_remap_bilinear_f32(img, out, layout, C, H, W, H, W, mx, my);
+  free(dx);
+}

@@ -1,0 +1,584 @@
+"""GPU parity tests: every HIP stage, called through the C ABI (ctypes) by the Python surface that
+mirrors the reference, against the CPU oracle on the same seeded inputs, against the golden vectors
+captured from the reference, and -- at BASELINE's full sizes -- through size-independent properties.
+
+Bars: bit-exact wherever the oracle defines the operation order (everything except the places
+listed in DESIGN.md "parity"); <= 1e-4 max-abs per pixel end to end (north_star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import warp_oracle as O
+from conftest import pool_input
+
+pytestmark = pytest.mark.gpu
+
+TOL_PIXEL = 1e-4   # north_star: max-abs per-pixel tolerance, float32 images in [0,1]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from attwarp_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "HIP library missing -- the product has no fallback"
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def T(x, dev):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def softmax_rows(rng, shape, peak=None):
+    lg = rng.standard_normal(shape).astype(np.float32)
+    if peak is not None:
+        lg[..., peak[0]:peak[1]] += 3.0
+    e = np.exp(lg - lg.max(-1, keepdims=True))
+    return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+
+
+# =============================== A1 / A2 =====================================
+def test_attn_steps_vs_oracle_and_golden(dev, golden):
+    from attwarp_amd import attention_extraction as ae
+    g = golden("attn_reduce")
+    starts, ends = [int(v) for v in g["starts"]], [int(v) for v in g["ends"]]
+    hl = ae.BatchMaskHookLogger(model=None, device=dev)
+    hl.set_batch_image_token_ranges(starts, ends)
+    for t in range(4):
+        full = g[f"step_in_{t}"]                                   # [B, heads, 1, kv]
+        hl._process_attention(T(full, dev))
+        got = N(hl.step_attentions[-1])
+        assert np.array_equal(got, O.attn_reduce_step(full, starts, ends))          # bit-exact vs oracle
+        np.testing.assert_allclose(got, g[f"step_out_{t}"], rtol=3e-7, atol=0)       # few ulps vs torch
+    maps = hl.finalize_batch()
+    assert len(maps) == 3 and all(m.shape == (24, 24) for m in maps)
+    fin = np.stack([N(m) for m in maps])
+    assert np.array_equal(fin.reshape(3, 576), O.attn_finalize([N(s) for s in hl.step_attentions]))
+    np.testing.assert_allclose(fin, g["final"], rtol=3e-7, atol=0)
+    hl.reinit()
+    assert hl.step_attentions == [] and hl.batch_size == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_attn_steps_low_precision(dev, golden, dt):
+    from attwarp_amd import attention_extraction as ae
+    g = golden("attn_reduce")
+    starts, ends = [int(v) for v in g["starts"]], [int(v) for v in g["ends"]]
+    hl = ae.BatchMaskHookLogger(model=None, device=dev)
+    hl.set_batch_image_token_ranges(starts, ends)
+    for t in range(4):
+        a = T(g[f"step_in_{t}"], dev).to(dt)
+        hl._process_attention(a)
+        assert hl.step_attentions[-1].dtype == dt
+        if dt == torch.float16:
+            ref = O.attn_reduce_step(N(a), starts, ends)
+            assert np.array_equal(N(hl.step_attentions[-1]), ref)                      # bit-exact in fp16
+            np.testing.assert_allclose(ref.astype(np.float32), g[f"step_out16_{t}"].astype(np.float32), rtol=2e-3)
+    fin = torch.stack(hl.finalize_batch())
+    assert fin.dtype == dt
+    if dt == torch.float16:
+        np.testing.assert_allclose(N(fin).astype(np.float32), g["final16"].astype(np.float32), rtol=2e-3)
+    else:
+        np.testing.assert_allclose(N(fin.float()), g["final"], rtol=2e-2)
+
+
+def test_attn_strided_prefill_and_empty(dev):
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(21)
+    B, heads, q, kv = 3, 8, 5, 700
+    big = softmax_rows(rng, (B, heads, q, kv + 9))
+    a = T(big, dev)[..., 4:4 + kv]                         # non-contiguous view (kv stride 1, row stride kv+9)
+    starts = [3, 40, 100]
+    hl = ae.BatchMaskHookLogger(None, dev)
+    assert [tuple(m.shape) for m in (hl.finalize_batch())] == []           # batch_size 0 -> empty list
+    hl.set_batch_image_token_ranges(starts, [s + 576 for s in starts])
+    empty = hl.finalize_batch()
+    assert len(empty) == 3 and empty[0].shape == (576,)                    # flat uniform map, reference :404-408
+    assert torch.allclose(empty[0], torch.full((576,), 1 / 576, device=dev))
+    hl._process_attention(a)
+    ref = O.attn_reduce_step(big[..., 4:4 + kv], starts, [s + 576 for s in starts])
+    assert np.array_equal(N(hl.step_attentions[0]), ref)
+    # clipped range: end beyond kv shortens every slice equally
+    hl2 = ae.BatchMaskHookLogger(None, dev)
+    hl2.set_batch_image_token_ranges([150, 150, 150], [726, 726, 726])
+    hl2._process_attention(a)
+    assert hl2.step_attentions[0].shape == (3, 550)
+    assert np.array_equal(N(hl2.step_attentions[0]), O.attn_reduce_step(big[..., 4:4 + kv], [150] * 3, [726] * 3))
+    # ragged clipped ranges cannot be stacked (reference raises in torch.stack)
+    hl3 = ae.BatchMaskHookLogger(None, dev)
+    hl3.set_batch_image_token_ranges([100, 150, 150], [676, 726, 726])
+    with pytest.raises(RuntimeError, match="equal size"):
+        hl3._process_attention(a)
+
+
+def test_attn_stack_fused_and_single_logger(dev):
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(22)
+    T_, B, heads, kv = 5, 4, 32, 640
+    rows = softmax_rows(rng, (T_, B, heads, kv), peak=(200, 260))
+    starts = np.array([35, 36, 42, 37], np.int32)
+    got = N(ae.attn_reduce_stack(T(rows, dev), T(starts, dev)))
+    assert np.array_equal(got, O.attn_reduce_stack(rows, starts))
+    # MaskHookLogger: default range [1, 577), mean over steps AND batch rows
+    ml = ae.MaskHookLogger(None, dev)
+    for t in range(T_):
+        ml._process_attention(T(rows[t][:, :, None, :], dev))
+    steps = [O.attn_reduce_step(rows[t][:, :, None, :], [1] * B, [577] * B) for t in range(T_)]
+    cat = np.concatenate(steps, 0)                                   # [T*B, 576] (reference: torch.cat)
+    ref = O.attn_finalize([r[None] for r in cat])[0]                 # mean over all rows
+    assert np.array_equal(N(ml.finalize()), ref)
+
+
+# =============================== A3 / A4 =====================================
+def test_revise_mask(dev, golden):
+    from attwarp_amd import attention_extraction as ae
+    g = golden("mask_postproc")
+    got = N(ae.revise_mask(T(g["masks"], dev), 3, 10))
+    ref = O.revise_mask(g["masks"], 3, 10)
+    assert np.abs(got - ref).max() <= 6e-8                               # <= 1 ulp near 1.0 vs oracle
+    np.testing.assert_allclose(got, g["revised"], rtol=0, atol=5e-7)      # vs reference (torch float32 reductions)
+    one = N(ae.revise_mask(T(g["masks"][0], dev), kernel_size=5, enhance_coe=4))
+    assert one.shape == (24, 24)
+    np.testing.assert_allclose(one, g["mask0_k5_c4"], rtol=0, atol=5e-7)
+    with pytest.raises(AssertionError):
+        ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
+
+
+@pytest.mark.parametrize("wh", [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24), (24, 24)])
+def test_mask_upsample_lanczos_bit_exact(dev, golden, wh):
+    from attwarp_amd import attention_extraction as ae
+    g = golden("mask_postproc")
+    w, h = wh
+    got_f = N(ae.upsample_mask_lanczos(T(g["revised"][:2], dev), (w, h)))      # float mask: x255 truncation inside
+    got_u = N(ae.upsample_mask_lanczos(T(g["u8"][:2], dev), (w, h)))
+    if wh == (24, 24):
+        assert np.array_equal(got_f, g["u8"][:2]) and np.array_equal(got_u, g["u8"][:2])
+    else:
+        ref = g[f"lanczos_{w}x{h}"]                                            # real Pillow output
+        assert got_f.shape == ref.shape
+        assert np.array_equal(got_f, ref) and np.array_equal(got_u, ref)
+
+
+def test_blend_mask_surface(dev, golden):
+    from PIL import Image
+    from attwarp_amd import attention_extraction as ae
+    g = golden("mask_postproc")
+    img = Image.fromarray(np.zeros((375, 500, 3), np.uint8))
+    merged, mask = ae.blend_mask(img, T(g["masks"][1], dev), 10, 3, Image.LANCZOS, 0)
+    assert mask.mode == "L" and mask.size == (500, 375)
+    rev_u8 = O.mask_to_u8(N(ae.revise_mask(T(g["masks"][1], dev), 3, 10)))
+    assert np.array_equal(np.array(mask), O.lanczos_resize_u8(rev_u8, 500, 375))
+    with pytest.raises(NotImplementedError):
+        ae.blend_mask(3.14, T(g["masks"][1], dev), 10, 3, Image.LANCZOS, 0)
+
+
+# =============================== A5 / A6 / A7 ================================
+@pytest.mark.parametrize("S", [336, 512, 1024])
+def test_adaptive_pool_and_marginals(dev, golden, S):
+    from attwarp_amd import checkpoint_utils as cu, _lib
+    from attwarp_amd._lib import call, ptr, stream_ptr
+    g = golden("pool_marginals")
+    A = pool_input(S)
+    a = T(A[:, 0], dev)
+    out = torch.empty(2, 24, 24, device=dev)
+    call("attwarp_adaptive_avg_pool", ptr(a), 2, S, S, 24, 24, ptr(out), stream_ptr(dev))
+    assert np.array_equal(N(out), O.adaptive_avg_pool24(A)[:, 0])
+    np.testing.assert_allclose(N(out), g[f"P_{S}"][:, 0], rtol=3e-6)
+    px, py = cu.gt_marginals(T(g[f"P_{S}"], dev))
+    pxo, pyo = O.gt_marginals(g[f"P_{S}"])
+    assert np.array_equal(N(px), pxo) and np.array_equal(N(py), pyo)
+    np.testing.assert_allclose(N(px), g[f"px_{S}"], rtol=3e-7, atol=1e-9)
+    # full-resolution marginals (trainer.py:357,501,578)
+    pxf, pyf = cu.gt_marginals(T(A, dev))
+    pxfo, pyfo = O.gt_marginals(A)
+    assert np.array_equal(N(pxf), pxfo) and np.array_equal(N(pyf), pyfo)
+
+
+def test_gt_marginals_negative_nonsquare(dev, golden):
+    from attwarp_amd import checkpoint_utils as cu
+    g = golden("pool_marginals")
+    px, py = cu.gt_marginals(T(g["Afull"], dev))
+    pxo, pyo = O.gt_marginals(g["Afull"])
+    assert np.array_equal(N(px), pxo) and np.array_equal(N(py), pyo)
+    np.testing.assert_allclose(N(px), g["pxf"], rtol=5e-7, atol=1e-9)
+    np.testing.assert_allclose(N(py), g["pyf"], rtol=5e-7, atol=1e-9)
+
+
+def test_safe_softmax(dev, golden):
+    from attwarp_amd import model
+    g = golden("pool_marginals")
+    got = N(model.safe_softmax(T(g["logits"], dev), dim=1, eps=1e-6))
+    assert np.abs(got - O.safe_softmax(g["logits"])).max() <= 1.2e-7
+    np.testing.assert_allclose(got, g["safe_softmax"], rtol=5e-7, atol=1e-12)
+    assert np.isfinite(got).all()
+    # dim handling: softmax over dim 0 of the transposed input
+    got0 = N(model.safe_softmax(T(g["logits"].T.copy(), dev), dim=0))
+    assert np.array_equal(got0.T, got)
+
+
+def test_marginalnet_forward_gpu(dev, golden):
+    from attwarp_amd import model
+    g = golden("marginalnet")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd|")}
+    net = model.MarginalNet(32, 48, hidden=16).eval()
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    with torch.no_grad():
+        px, py = net(T(g["fmap"], dev), 24, 24, T(g["ttok"], dev), T(g["tmask"], dev))
+    np.testing.assert_allclose(N(px), g["px"], rtol=1e-4, atol=1e-6)      # convs run on MIOpen/rocBLAS
+    np.testing.assert_allclose(N(py), g["py"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(N(px).sum(1), 1, atol=1e-5)
+
+
+# =============================== A8 / A9 / A10 / A11 ==========================
+@pytest.mark.parametrize("L", [336, 500, 512, 1024])
+def test_pdf_cdf_chain(dev, golden, L):
+    from attwarp_amd import checkpoint_utils as cu
+    g = golden("pdf_cdf")
+    x = N(cu.upsample_pdf_right_inverse(T(g["y"], dev), L))
+    assert np.array_equal(x, O.upsample_pdf_right_inverse(g["y"], L))
+    np.testing.assert_allclose(x, g[f"x_{L}"], rtol=0, atol=4e-7 * np.abs(g[f"x_{L}"]).max())
+    A = O.pooling_matrix(24, L, np.float64)
+    np.testing.assert_allclose(x.astype(np.float64) @ A.T, g["y"], atol=2e-6)          # docstring invariant
+    p = np.maximum(g[f"x_{L}"], 0)
+    F = N(cu.cdf_from_density(T(p, dev)))
+    assert np.array_equal(F, O.cdf_from_density(p))
+    np.testing.assert_allclose(F, g[f"cdf_{L}"], rtol=6e-7, atol=0)
+    assert (np.diff(F, axis=1) >= 0).all() and (F[:, -1] == 1).all()
+
+
+def test_right_inverse_shapes_and_bad_density(dev, golden):
+    from attwarp_amd import checkpoint_utils as cu
+    g = golden("pdf_cdf")
+    assert np.array_equal(N(cu.upsample_pdf_right_inverse(T(g["y"][0], dev), 336)),
+                          O.upsample_pdf_right_inverse(g["y"][0], 336))
+    x3 = cu.upsample_pdf_right_inverse(T(g["y"].reshape(1, 3, 24), dev), 336)
+    assert x3.shape == (1, 3, 336)
+    assert np.array_equal(N(x3), O.upsample_pdf_right_inverse(g["y"].reshape(1, 3, 24), 336))
+    F = N(cu.cdf_from_density(T(g["p_bad"], dev)))
+    assert np.array_equal(F, O.cdf_from_density(g["p_bad"]))
+    assert np.abs(F - g["cdf_bad"]).max() <= 2.4e-7
+
+
+def test_strictly_increasing_and_resample(dev, golden):
+    from attwarp_amd import checkpoint_utils as cu
+    g = golden("pdf_cdf")
+    m = N(cu._make_strictly_increasing(T(g["F24"], dev)))
+    assert np.array_equal(m, O.make_strictly_increasing(g["F24"]))
+    assert np.abs(m - g["msi"]).max() <= 2.4e-7
+    for L in (336, 1024):
+        r = N(cu.resample_cdf(T(g["F24"], dev), L))
+        assert np.array_equal(r, O.resample_cdf(g["F24"], L))
+        np.testing.assert_allclose(r, g[f"resample_{L}"], rtol=0, atol=3e-7)
+        assert (np.diff(r, axis=1) > 0).all()
+
+
+@pytest.mark.parametrize("case", ["sq336", "rect", "to500", "sq1024", "ties"])
+def test_maps_from_cdf_bit_exact_vs_reference(dev, golden, case):
+    from attwarp_amd import checkpoint_utils as cu
+    g = golden("maps_from_cdf")
+    Fx = g["ties_F"] if case == "ties" else g[f"{case}_Fx"]
+    Fy = g["ties_F"] if case == "ties" else g[f"{case}_Fy"]
+    out = tuple(int(v) for v in g[f"{case}_out"])
+    mx, my = cu.axis_maps_from_cdf(T(Fx, dev), T(Fy, dev), out)
+    assert np.array_equal(N(mx), g[f"{case}_mx"])            # the float32 maps the REFERENCE hands to cv2.remap
+    assert np.array_equal(N(my), g[f"{case}_my"])
+
+
+def test_maps_non_monotone_cdf_replays_numpy_search(dev):
+    """A garbage (non-monotone, NaN) 'CDF' makes np.interp's result depend on its search path; the
+    kernel replays that path exactly."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(31)
+    F = rng.random((3, 40)).astype(np.float32)
+    F[1, 7] = np.nan
+    F[2] = np.sort(F[2])[::-1]
+    ref_x, ref_y = O.maps_from_cdf(F, F, (50, 60))
+    mx, my = cu.axis_maps_from_cdf(T(F, dev), T(F, dev), (50, 60))
+    assert np.array_equal(N(mx), ref_x, equal_nan=True) and np.array_equal(N(my), ref_y, equal_nan=True)
+
+
+def test_fused_axis_maps_from_pdf(dev):
+    from attwarp_amd import pipeline
+    rng = np.random.default_rng(32)
+    px = softmax_rows(rng, (5, 24)); py = softmax_rows(rng, (5, 24), peak=(3, 6))
+    for (H, W, out) in [(336, 336, None), (1024, 1024, None), (48, 100, (60, 80)), (512, 336, (500, 500))]:
+        mx, my = pipeline.axis_maps_from_pdf(T(px, dev), T(py, dev), (H, W), out)
+        Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0))
+        Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
+        rx, ry = O.maps_from_cdf(Fx, Fy, out)
+        assert np.array_equal(N(mx), rx) and np.array_equal(N(my), ry)
+
+
+# =============================== A13 =========================================
+def test_maps_from_attention_vs_reference_golden(dev, golden):
+    """All 96 golden combinations (4 attention maps x 6 transforms x inverse x 2 output sizes).
+    Column profiles use numpy's summation order exactly; row profiles and totals use a fixed GPU
+    order, so a float32 map entry may differ from numpy's by one ulp (never seen more)."""
+    from attwarp_amd import new_method as nm
+    g = golden("maps_from_attention")
+    n_elem = n_diff = 0
+    for key in [str(c) for c in g["combos"]]:
+        aname, tr, inv, wh, es, ed = key.split("|")
+        nw, nh = (int(v) for v in wh.split("x"))
+        att = g[aname]
+        a = T(att if att.dtype in (np.uint8, np.float32, np.float64) else att.astype(np.float64), dev)[None]
+        mx, my = nm.attention_axis_maps(a, nw, nh, tr, float(es), float(ed), bool(int(inv)))
+        for got, ref in ((N(mx)[0], g[f"mx|{key}"]), (N(my)[0], g[f"my|{key}"])):
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+            n_elem += fin.sum(); n_diff += (got[fin] != ref[fin]).sum()
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=2.5e-7, atol=1e-30, err_msg=key)
+    assert n_diff <= 1e-3 * n_elem, (n_diff, n_elem)
+
+
+def test_uniform_attention_gives_identity_warp(dev):
+    from attwarp_amd import new_method as nm
+    rng = np.random.default_rng(33)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    out = nm.warp_image_by_attention(img, np.full((48, 64), 7, np.uint8), 64, 48, transform="identity")
+    assert np.abs(out.astype(int) - img.astype(int)).max() <= 0     # identity map up to 1e-13 -> same pixels
+
+
+# =============================== A12 remap ===================================
+SHAPES = [(336, 336, 336, 336, 3), (64, 96, 50, 70, 3), (33, 47, 40, 31, 1), (128, 128, 128, 128, 4),
+          (100, 28, 30, 200, 3), (32, 40, 500, 500, 3), (512, 512, 500, 500, 3), (31, 29, 31, 29, 2)]
+
+
+def make_maps(rng, B, H, W, Ho, Wo, kind="cdf"):
+    if kind == "cdf":
+        px = softmax_rows(rng, (B, 24)); py = softmax_rows(rng, (B, 24), peak=(10, 13))
+        Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0))
+        Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
+        return O.maps_from_cdf(Fx, Fy, (Ho, Wo))
+    if kind == "wild":      # unsorted, out of range, negative: arbitrary caller maps
+        mx = (rng.random((B, Wo)) * (W + 6) - 3).astype(np.float32)
+        my = (rng.random((B, Ho)) * (H + 6) - 3).astype(np.float32)
+        return mx, my
+    if kind == "identity":
+        return (np.tile(np.arange(Wo, dtype=np.float32) * (W / Wo), (B, 1)),
+                np.tile(np.arange(Ho, dtype=np.float32) * (H / Ho), (B, 1)))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["cdf", "wild"])
+def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C = shape
+    rng = np.random.default_rng(hash((shape, kind)) % 2**32)
+    B = 3
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    for dt in (np.float32, np.uint8):
+        img = rng.random((B, H, W, C), dtype=np.float32)
+        if dt == np.uint8:
+            img = (img * 255).astype(np.uint8)
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+        for variant in ("rows", "gather"):
+            os.environ["ATTWARP_REMAP_VARIANT"] = variant[0]
+            try:
+                hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+                chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev)))
+            finally:
+                os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+            assert np.array_equal(hwc, ref), (dt.__name__, variant, "hwc")
+            assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (dt.__name__, variant, "chw")
+
+
+@pytest.mark.parametrize("R", ["1", "5", "64"])
+def test_remap_rows_block_boundaries(dev, R):
+    """Row-block size must not change a single bit (halo / slide logic at block seams)."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(41)
+    H = W = 96
+    img = rng.random((2, H, W, 3), dtype=np.float32)
+    px = softmax_rows(rng, (2, 24)) ** 3; px /= px.sum(1, keepdims=True)      # strongly peaked: slopes >> 2 and << 1
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px.astype(np.float32), W), 0))
+    mx, my = O.maps_from_cdf(Fx, Fx[::-1].copy(), (H, W))
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(2)])
+    os.environ["ATTWARP_REMAP_ROWS"] = R
+    try:
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+    finally:
+        os.environ.pop("ATTWARP_REMAP_ROWS", None)
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dt", [np.float32, np.uint8])
+def test_remap_cv2_compat_mode(dev, dt):
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(42)
+    B, H, W, C = 2, 40, 56, 3
+    img = rng.random((B, H, W, C), dtype=np.float32)
+    if dt == np.uint8:
+        img = (img * 255).astype(np.uint8)
+    mx, my = make_maps(rng, B, H, W, 64, 48, "cdf")
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], "cv2") for b in range(B)])
+    got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode="cv2", channels_last=True))
+    assert np.array_equal(got, ref)
+    got_chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode="cv2"))
+    assert np.array_equal(got_chw.transpose(0, 2, 3, 1), ref)
+
+
+def test_remap_rejects_bad_input(dev):
+    from attwarp_amd import checkpoint_utils as cu, _lib
+    img = torch.zeros(1, 5, 8, 8, device=dev)
+    m = torch.zeros(1, 8, device=dev)
+    with pytest.raises(_lib.AttWarpError, match="C=5"):
+        cu.remap_separable(img, m, m)
+    with pytest.raises(TypeError):
+        cu.remap_separable(img.double(), m, m)
+    with pytest.raises(KeyError):
+        cu.remap_separable(img[:, :3], m, m, mode="nearest")
+
+
+# =============================== composites ==================================
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8, torch.float16])
+def test_warp_from_cdf_torch_surface(dev, dtype):
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(51)
+    B, C, H, W = 3, 3, 72, 88
+    img = rng.random((B, C, H, W), dtype=np.float32)
+    px = softmax_rows(rng, (B, 24)); py = softmax_rows(rng, (B, 24))
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
+    if dtype == torch.uint8:
+        src = (img * 255).astype(np.uint8)
+        t_img = T(src, dev)
+    else:
+        t_img = T(img, dev).to(dtype)
+        src = N(t_img.float())
+    for out_size in (None, (50, 120)):
+        out = cu.warp_from_cdf_torch(t_img, T(Fx, dev), T(Fy, dev), out_size)
+        assert out.dtype == dtype and out.device == t_img.device          # reference contract :203
+        ref = O.warp_from_cdf(src, Fx, Fy, out_size)
+        if dtype == torch.float16:
+            assert np.array_equal(N(out.float()), ref.astype(np.float16).astype(np.float32))
+        else:
+            assert np.array_equal(N(out), ref)
+
+
+def test_warp_image_by_attention_and_save(dev, golden, tmp_path):
+    from PIL import Image
+    from attwarp_amd import new_method as nm
+    g = golden("maps_from_attention")
+    att = g["att_u8"]                                   # 336x336 uint8 LANCZOS-upsampled mask
+    rng = np.random.default_rng(52)
+    img = rng.integers(0, 256, (336, 336, 3), dtype=np.uint8)
+    for tr in ("identity", "sqrt", "square"):
+        got = nm.warp_image_by_attention(img, att, 500, 500, transform=tr)
+        assert got.shape == (500, 500, 3) and got.dtype == np.uint8
+        ref = O.warp_image_by_attention(img, att, 500, 500, tr)
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-4, tr      # a 1-ulp map difference may flip a rounding
+    # module-state form (reference behaviour) == explicit form
+    nm.set_transform_function("sqrt")
+    assert np.array_equal(nm.warp_image_by_attention(img, att, 500, 500),
+                          nm.warp_image_by_attention(img, att, 500, 500, transform="sqrt"))
+    # float32 image, grayscale image
+    imgf = rng.random((336, 336, 3), dtype=np.float32)
+    gotf = nm.warp_image_by_attention(imgf, att, 336, 336, transform="identity")
+    assert np.abs(gotf - O.warp_image_by_attention(imgf, att, 336, 336, "identity")).max() <= TOL_PIXEL
+    gray = nm.warp_image_by_attention(img[:, :, 0], att, 100, 120, transform="identity")
+    assert gray.shape == (120, 100)
+    # save_warped_image: PIL image in (RGB), file out, True; same pixels as the in-memory warp
+    out_path = tmp_path / "w.png"
+    ok = nm.save_warped_image(Image.fromarray(img), att, str(tmp_path / "orig.png"), None, str(out_path),
+                              width=500, height=500, transform="identity")
+    assert ok is True
+    saved = np.array(Image.open(out_path))
+    expect = nm.warp_image_by_attention(img[:, :, ::-1].copy(), att, 500, 500, transform="identity")[:, :, ::-1]
+    assert np.array_equal(saved, expect)
+    assert np.array_equal(np.array(Image.open(tmp_path / "orig.png")), img)
+    # attention map of another size -> image is resized to it first (reference :478)
+    ok = nm.save_warped_image(Image.fromarray(img), np.ones((100, 120), np.float32), None, None, str(out_path))
+    assert ok and np.array(Image.open(out_path)).shape == (500, 500, 3)
+
+
+def test_pipeline_attention_stack_end_to_end(dev):
+    """Config-2 shape of the path at a small size: stack -> 24x24 -> marginals -> CDF -> maps -> warp."""
+    from attwarp_amd import pipeline
+    rng = np.random.default_rng(53)
+    B, T_, heads, kv, S = 4, 6, 32, 640, 112
+    rows = softmax_rows(rng, (T_, B, heads, kv), peak=(250, 300))
+    starts = (35 + np.arange(B) % 8).astype(np.int32)
+    img = rng.random((B, S, S, 3), dtype=np.float32)
+    att = O.attn_reduce_stack(rows, starts).reshape(B, 1, 24, 24)
+    px, py = O.gt_marginals(att)
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, S), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, S), 0))
+    mx, my = O.maps_from_cdf(Fx, Fy)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+    out = pipeline.warp_from_attention_stack(T(img, dev), T(rows, dev), T(starts, dev), channels_last=True)
+    assert np.array_equal(N(out), ref)
+    out_chw = pipeline.warp_from_attention_stack(T(img.transpose(0, 3, 1, 2), dev), T(rows, dev), T(starts, dev))
+    assert np.array_equal(N(out_chw).transpose(0, 2, 3, 1), ref)
+    # HIP-graph replay of the same step gives the same bytes
+    ti, tr, ts = T(img, dev), T(rows, dev), T(starts, dev)
+    graph, gout = pipeline.capture_step(lambda: pipeline.warp_from_attention_stack(ti, tr, ts, channels_last=True))
+    gout.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(N(gout), ref)
+
+
+def test_pipeline_masks_chain_main_batched(dev, golden):
+    """main_batched.py:243-287: revise_mask -> uint8 -> LANCZOS -> float64 marginals -> 500x500 warp."""
+    from attwarp_amd import pipeline
+    g = golden("mask_postproc")
+    rng = np.random.default_rng(54)
+    B, S = 4, 336
+    imgs = rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    out = N(pipeline.warp_from_masks(T(imgs, dev), T(g["masks"], dev), (500, 500)))
+    assert out.shape == (B, 500, 500, 3)
+    bad = 0
+    for b in range(B):
+        mota = O.lanczos_resize_u8(O.mask_to_u8(O.revise_mask(g["masks"][b], 3, 10)), S, S)
+        ref = O.warp_image_by_attention(imgs[b], mota, 500, 500, "identity")
+        d = np.abs(out[b].astype(int) - ref.astype(int))
+        bad += (d > 0).sum()
+        assert d.max() <= 1
+    assert bad <= 1e-4 * out.size
+
+
+# =============================== full-size properties =========================
+@pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
+def test_full_size_properties(dev, cfg):
+    """BASELINE configs 2 and 3 at full size, checked on the GPU through properties:
+    (1) identity maps reproduce the input bit-for-bit; (2) the streaming kernel and the independent
+    gather kernel agree bit-for-bit on attention-driven maps; (3) a constant image stays constant
+    (partition of unity); (4) every output lies within the input's range."""
+    from attwarp_amd import checkpoint_utils as cu, pipeline
+    B, S = cfg
+    gen = torch.Generator(device=dev).manual_seed(0)
+    img = torch.rand((B, S, S, 3), device=dev, generator=gen)
+    ar = torch.arange(S, device=dev, dtype=torch.float32).repeat(B, 1)
+    out = cu.remap_separable(img, ar, ar, channels_last=True)
+    assert torch.equal(out, img)
+    px = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 2, 1)
+    py = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 2, 1)
+    mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
+    assert bool((mx[:, 1:] >= mx[:, :-1]).all()) and float(mx.min()) >= 0 and float(mx.max()) <= S
+    del out
+    a = cu.remap_separable(img, mx, my, channels_last=True)
+    os.environ["ATTWARP_REMAP_VARIANT"] = "g"
+    try:
+        b = cu.remap_separable(img, mx, my, channels_last=True)
+    finally:
+        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+    assert torch.equal(a, b)
+    assert float(a.min()) >= float(img.min()) and float(a.max()) <= float(img.max())
+    del b
+    const = torch.full_like(img, 0.3125)
+    c = cu.remap_separable(const, mx, my, channels_last=True)
+    assert torch.equal(c, const)
+    # spot-check a few images against the CPU oracle
+    for bi in (0, B - 1):
+        ref = O.remap_bilinear(N(img[bi]), N(mx[bi]), N(my[bi]))
+        assert np.array_equal(N(a[bi]), ref)

@@ -1,0 +1,158 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header
+declares, argument validation works without a GPU, host tables match the oracle, the Python
+surface keeps the reference's error behaviour, and there is NO CPU fallback."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import warp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from attwarp_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from attwarp_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "attwarp.h")).read()
+    declared = set(re.findall(r"ATTWARP_API\s+[\w\s\*]+?\b(attwarp_\w+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/attwarp.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.attwarp_version() == 100
+
+
+def test_c_abi_argument_validation_without_gpu(lib):
+    # every entry point validates before it enqueues anything, so these run on a CPU-only box
+    assert lib.attwarp_remap_bilinear(None, None, 0, 0, 1, 3, 8, 8, 8, 8, None, None, 0, None) == -1
+    assert b"null pointer" in lib.attwarp_last_error()
+    buf = (8 * 8 * 3 * 4) * b"\0"
+    import ctypes
+    p = ctypes.cast(ctypes.create_string_buffer(buf), ctypes.c_void_p)
+    assert lib.attwarp_remap_bilinear(p, p, 7, 0, 1, 3, 8, 8, 8, 8, p, p, 0, None) == -1      # bad dtype
+    assert lib.attwarp_remap_bilinear(p, p, 0, 0, 1, 3, 8, 8, 8, 8, p, p, 5, None) == -1      # bad mode
+    assert lib.attwarp_remap_bilinear(p, p, 0, 0, 1, 9, 8, 8, 8, 8, p, p, 0, None) == -2      # C > 4
+    assert lib.attwarp_remap_bilinear(p, p, 0, 0, 0, 3, 8, 8, 8, 8, p, p, 0, None) == -1      # B = 0
+    assert lib.attwarp_axis_map_from_cdf(p, 1, 100000, 8, p, None) == -2
+    assert lib.attwarp_mask_postproc(p, 1, 24, 4, 10.0, p, None) == -1                         # even kernel
+    assert lib.attwarp_attn_reduce_step(p, 3, 1, 1, 1, 8, 0, 0, 0, 1, p, 4, p, None) == -1     # uint8 attention
+    assert lib.attwarp_axis_maps_from_attention(p, 0, 1, 8, 8, 8, 8, 9, 1.0, 1.0, 0, p, p, p, None) == -1
+    assert lib.attwarp_axis_sums_workspace_bytes(2, 3, 5) == 2 * 8 * 8
+
+
+def test_no_cpu_fallback():
+    from attwarp_amd import checkpoint_utils as cu, model, attention_extraction as ae
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cu.cdf_from_density(torch.rand(2, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cu.warp_from_cdf_torch(torch.rand(1, 3, 8, 8), torch.rand(1, 8), torch.rand(1, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.safe_softmax(torch.rand(2, 24))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ae.revise_mask(torch.rand(24, 24))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "attwarp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("see oracle/warp_oracle.py", "").replace(
+                    "oracle/warp_oracle.py::remap_bilinear", "").replace("The oracle", "").replace(
+                    "the oracle", ""), f"{f} refers to the oracle"
+
+
+def test_reference_error_behaviour():
+    from attwarp_amd import checkpoint_utils as cu
+    with pytest.raises(AssertionError):
+        cu.warp_from_cdf_torch(torch.rand(3, 8, 8), torch.rand(1, 8), torch.rand(1, 8))
+    with pytest.raises(ValueError, match="image width"):
+        cu.warp_from_cdf_torch(torch.rand(1, 3, 8, 8), torch.rand(1, 7), torch.rand(1, 8))
+    with pytest.raises(ValueError, match="image height"):
+        cu.warp_from_cdf_torch(torch.rand(1, 3, 8, 8), torch.rand(1, 8), torch.rand(1, 9))
+    with pytest.raises(ValueError, match="1D/2D/3D"):
+        cu.upsample_pdf_right_inverse(torch.rand(1, 1, 1, 24), 336)
+
+
+def test_set_transform_function_semantics(capsys):
+    from attwarp_amd import new_method as nm
+    assert nm.set_transform_function("sqrt", 2.0, 3.0, True) == "sqrt"
+    assert (nm.ATTENTION_TRANSFORM, nm.EXP_SCALE, nm.EXP_DIVISOR, nm.APPLY_INVERSE_TO_MARGINALS) == ("sqrt", 2.0, 3.0, True)
+    assert nm.set_transform_function("bogus") == "identity"
+    assert "Unknown transform" in capsys.readouterr().out
+    assert nm.ATTENTION_TRANSFORM == "identity" and nm.APPLY_INVERSE_TO_MARGINALS is False
+
+
+def test_save_warped_image_swallows_errors(tmp_path, capsys):
+    from attwarp_amd import new_method as nm
+    ok = nm.save_warped_image(str(tmp_path / "missing.png"), np.ones((4, 4)), None, None, str(tmp_path / "o.png"))
+    assert ok is False
+    ok = nm.save_warped_image(np.zeros((4, 4, 3), np.uint8), np.ones((2, 2, 2, 2)), None, None, str(tmp_path / "o.png"))
+    assert ok is False          # 4-D attention map -> ValueError inside, swallowed
+
+
+def test_att_map_coercion():
+    from attwarp_amd import new_method as nm
+    from PIL import Image
+    a = nm._coerce_att_map([], 7, 5)
+    assert a.shape == (5, 7) and np.all(a == 128)
+    a = nm._coerce_att_map([np.ones((3, 4))], 7, 5)
+    assert a.shape == (3, 4)
+    a = nm._coerce_att_map(Image.fromarray(np.zeros((6, 8), np.uint8), mode="L"), 1, 1)
+    assert a.shape == (6, 8)
+    a = nm._coerce_att_map(np.ones((3, 4, 3)) * np.array([1, 2, 3]), 1, 1)
+    assert a.shape == (3, 4) and np.allclose(a, 2)
+
+
+@pytest.mark.parametrize("L", [336, 500, 512, 1024, 37])
+def test_right_inverse_table_matches_oracle(L):
+    from attwarp_amd import _tables
+    assert np.array_equal(_tables._right_inverse_inv_host(24, L, 1e-8), O.right_inverse_core(24, L, 1e-8))
+
+
+@pytest.mark.parametrize("io", [(24, 336), (24, 1024), (24, 500), (24, 17), (24, 48)])
+def test_lanczos_tables_match_oracle(io):
+    from attwarp_amd import _tables
+    b, k, ks = _tables._lanczos_tables_host(*io)
+    bo, ko, kso = O.pil_lanczos_coeffs(*io)
+    assert ks == kso and np.array_equal(b, bo) and np.array_equal(k, ko)
+
+
+def test_marginalnet_logits_match_reference_golden(golden):
+    """MarginalNet on stock torch ops with the reference's parameter names: load the seeded
+    reference state_dict, compare softmax(logits) with the captured (px, py)."""
+    from attwarp_amd import model
+    g = golden("marginalnet")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd|")}
+    net = model.MarginalNet(32, 48, hidden=16).eval()
+    model.load_reference_checkpoint(net, {"epoch": 1, "model": sd})
+    with torch.no_grad():
+        lx, ly = net.forward_logits(torch.from_numpy(g["fmap"]), 24, 24, torch.from_numpy(g["ttok"]),
+                                    torch.from_numpy(g["tmask"]))
+    np.testing.assert_allclose(O.safe_softmax(lx.numpy()), g["px"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(O.safe_softmax(ly.numpy()), g["py"], rtol=2e-5, atol=1e-7)
+    full = model.MarginalNet(1024, 4096, 256)
+    assert sum(p.numel() for p in full.parameters()) == 2755074     # the 11.0 MB payload
+
+
+def test_shard_range_partitions():
+    from attwarp_amd.dist import shard_range
+    for n in (0, 1, 7, 64, 2048, 2051):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
