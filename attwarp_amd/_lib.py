@@ -50,6 +50,8 @@ SIGNATURES = {
     "attwarp_axis_map_from_cdf": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "attwarp_axis_maps_from_pdf": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                             c_void_p, c_void_p, c_void_p, c_void_p]),
+    "attwarp_axis_maps_from_steps": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_axis_maps_from_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                   c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_remap_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -32,50 +32,58 @@ template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b 
 }
 
 // One workgroup per (pseudo-)sample.  Each wave takes heads w, w+4, ...; lane l owns tokens
-// l, l+64, ...  (ntok/64 <= 16 values in registers).  grid = nb
-template <typename T>
+// l, l+64, ... (NPL = ceil(ntok/64) values per head in registers).  Heads are processed HU at a
+// time so that HU*NPL independent coalesced loads (256 B per wave instruction) are in flight per
+// lane before the first reduction: the kernel is a pure stream over heads*ntok elements per sample.
+// grid = nb
+template <typename T, int NPL, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restrict__ attn, int heads, int64_t sb,
                                                               int64_t sh, int64_t row_off, int64_t skv,
                                                               const int32_t* __restrict__ starts, int starts_mod,
                                                               int ntok, T* __restrict__ out) {
-  __shared__ double part[NT / WAVE][MAX_NTOK];
+  __shared__ double part[NT / WAVE][NPL * WAVE];
+  constexpr int NW = NT / WAVE;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
   const int st = starts[b % starts_mod];
   const T* base = attn + (int64_t)b * sb + row_off + (int64_t)st * skv;
-  double acc[MAXPL];
+  double acc[NPL];
 #pragma unroll
-  for (int i = 0; i < MAXPL; ++i) acc[i] = 0.0;
-  for (int h = wid; h < heads; h += NT / WAVE) {
-    const T* rp = base + (int64_t)h * sh;
-    T v[MAXPL];
-    double s = 0.0;
+  for (int i = 0; i < NPL; ++i) acc[i] = 0.0;
+  for (int h0 = wid; h0 < heads; h0 += NW * HU) {
+    T v[HU][NPL];
 #pragma unroll
-    for (int i = 0; i < MAXPL; ++i) {
-      const int t = lane + WAVE * i;
-      if (t < ntok) {
-        v[i] = rp[(int64_t)t * skv];
-        s += (double)to_f32<T>(v[i]);
+    for (int u = 0; u < HU; ++u) {
+      const int h = h0 + u * NW;
+      const T* rp = base + (int64_t)min(h, heads - 1) * sh;      // clamped: tail heads re-read, not used
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int t = lane + WAVE * i;
+        v[u][i] = rp[(int64_t)min(t, ntok - 1) * skv];
       }
     }
-    s = wave_sum(s);
-    const T den = add_tiny<T>(from_f64<T>(s));      // (row sum + 1e-12) in the model dtype
 #pragma unroll
-    for (int i = 0; i < MAXPL; ++i) {
-      const int t = lane + WAVE * i;
-      if (t < ntok) acc[i] += (double)to_f32<T>(div_t<T>(v[i], den));
+    for (int u = 0; u < HU; ++u) {
+      const int h = h0 + u * NW;
+      if (h < heads) {                                            // wave uniform
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i)
+          if (lane + WAVE * i < ntok) s += (double)to_f32<T>(v[u][i]);
+        s = wave_sum(s);
+        const T den = add_tiny<T>(from_f64<T>(s));      // (row sum + 1e-12) in the model dtype
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) acc[i] += (double)to_f32<T>(div_t<T>(v[u][i], den));
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < MAXPL; ++i) {
-    const int t = lane + WAVE * i;
-    if (t < ntok) part[wid][t] = acc[i];
-  }
+  for (int i = 0; i < NPL; ++i) part[wid][lane + WAVE * i] = acc[i];
   __syncthreads();
   const T nheads = from_f32<T>((float)heads);
   for (int t = threadIdx.x; t < ntok; t += NT) {
     double m = 0.0;
-    for (int w = 0; w < NT / WAVE; ++w) m += part[w][t];
+    for (int w = 0; w < NW; ++w) m += part[w][t];
     out[(int64_t)b * ntok + t] = div_t<T>(from_f64<T>(m), nheads);    // mean = sum / N in dtype T
   }
 }
@@ -213,8 +221,12 @@ __global__ __launch_bounds__(NT) void quantise_copy_kernel(const float* __restri
 template <typename T>
 static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
                        const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
-  hipLaunchKernelGGL((attn_reduce_step_kernel<T>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh, row_off,
-                     skv, starts, starts_mod, ntok, (T*)out);
+  if (ntok <= 9 * WAVE)      // 576 image tokens (LLaVA-1.5): 9 per lane, 4 heads in flight
+    hipLaunchKernelGGL((attn_reduce_step_kernel<T, 9, 4>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh,
+                       row_off, skv, starts, starts_mod, ntok, (T*)out);
+  else
+    hipLaunchKernelGGL((attn_reduce_step_kernel<T, MAXPL, 2>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb,
+                       sh, row_off, skv, starts, starts_mod, ntok, (T*)out);
   return check_launch("attn_reduce_step_kernel");
 }
 template <typename T>

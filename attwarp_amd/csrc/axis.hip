@@ -63,8 +63,26 @@ __device__ void cdf_from_density_block(float* p, int L, double* red) {
   for (int k = threadIdx.x; k < L; k += blockDim.x) p[k] = p[k] / denom;
   __syncthreads();
   if (threadIdx.x == 0) {
+    // sequential double-precision running sum (what torch's CPU cumsum does), 8 values per LDS round trip
     double c = 0.0;
-    for (int k = 0; k < L; ++k) {
+    int k = 0;
+    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+      float4* p4 = reinterpret_cast<float4*>(p);
+      for (; k + 8 <= L; k += 8) {
+        float4 a = p4[k >> 2], b4 = p4[(k >> 2) + 1];
+        c += (double)a.x; a.x = (float)c;
+        c += (double)a.y; a.y = (float)c;
+        c += (double)a.z; a.z = (float)c;
+        c += (double)a.w; a.w = (float)c;
+        c += (double)b4.x; b4.x = (float)c;
+        c += (double)b4.y; b4.y = (float)c;
+        c += (double)b4.z; b4.z = (float)c;
+        c += (double)b4.w; b4.w = (float)c;
+        p4[k >> 2] = a;
+        p4[(k >> 2) + 1] = b4;
+      }
+    }
+    for (; k < L; ++k) {
       c += (double)p[k];
       p[k] = (float)c;
     }
@@ -143,6 +161,71 @@ __global__ __launch_bounds__(NT) void axis_maps_from_pdf_kernel(const float* __r
   double* xn = smem_d + 8;                      // L+1
   float* p = reinterpret_cast<float*>(xn + L + 1 + ((L + 1) & 1));   // L floats
   right_inverse_block(y, Lo, L, inv, tmp, p, true);
+  cdf_from_density_block(p, L, red);
+  map_from_cdf_block(p, L, n_out, xn, map);
+}
+
+// ---- A2 + A6 + A8 + A9 + A11 fused: per-step attention maps -> inverse maps, one launch -------------
+// steps [T,B,g*g] float32 (A1 output) -> mean over steps (A2, llava.py:409-411) -> marginals of the
+// g x g map (A6) -> right-inverse up-sample, clamp, CDF, inverse map (as axis_maps_from_pdf_kernel).
+// Bit-identical to running the stages one by one.  grid = (B, 2).
+__global__ __launch_bounds__(NT) void axis_maps_from_steps_kernel(const float* __restrict__ steps, int T, int B, int g,
+                                                                  int W, int H, int W_out, int H_out,
+                                                                  const double* __restrict__ inv_x,
+                                                                  const double* __restrict__ inv_y,
+                                                                  float* __restrict__ map_x, float* __restrict__ map_y,
+                                                                  float* __restrict__ att_out) {
+  extern __shared__ __attribute__((aligned(16))) double smem_d[];
+  __shared__ float tmp[64];
+  __shared__ float pm[64];
+  const int b = blockIdx.x, axis = blockIdx.y;
+  const int L = axis ? H : W, n_out = axis ? H_out : W_out, ntok = g * g;
+  const double* inv = axis ? inv_y : inv_x;
+  float* map = (axis ? map_y : map_x) + (size_t)b * n_out;
+  double* red = smem_d;                         // 8
+  double* xn = smem_d + 8;                      // L+1
+  float* p = reinterpret_cast<float*>(xn + L + 1 + ((L + 1) & 1));   // L floats
+  float* att = p + L;                           // g*g floats
+  // A2: mean over generation steps (float64 accumulate, one rounding, float32 divide)
+  for (int i = threadIdx.x; i < ntok; i += blockDim.x) {
+    double acc = 0.0;
+    const float* sp = steps + (size_t)b * ntok + i;
+    const size_t tstride = (size_t)B * ntok;
+    int t = 0;
+    for (; t + 8 <= T; t += 8) {          // 8 independent loads in flight, then the ordered accumulation
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(t + u) * tstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += (double)v[u];
+    }
+    for (; t < T; ++t) acc += (double)sp[(size_t)t * tstride];
+    const float m = (float)acc / (float)T;
+    att[i] = m;
+    if (att_out && axis == 0) att_out[(size_t)b * ntok + i] = m;
+  }
+  __syncthreads();
+  // A6: marginal along this axis (x: sum over rows; y: sum over columns), clamp >= 0, normalise
+  for (int k = threadIdx.x; k < g; k += blockDim.x) {
+    double acc = 0.0;
+    for (int j = 0; j < g; ++j) {
+      const float v = axis ? att[k * g + j] : att[j * g + k];
+      acc += (double)((v != v) ? v : (v > 0.0f ? v : 0.0f));
+    }
+    pm[k] = (float)acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < g; ++k) tot += (double)pm[k];
+    tmp[0] = fmaxf((float)tot, 1e-6f);
+  }
+  __syncthreads();
+  const float tot = tmp[0];
+  __syncthreads();
+  if (threadIdx.x < g) pm[threadIdx.x] = pm[threadIdx.x] / tot;
+  __syncthreads();
+  right_inverse_block(pm, g, L, inv, tmp, p, true);
   cdf_from_density_block(p, L, red);
   map_from_cdf_block(p, L, n_out, xn, map);
 }
@@ -294,6 +377,22 @@ extern "C" int attwarp_axis_maps_from_pdf(const float* px, const float* py, int 
   hipLaunchKernelGGL(axis_maps_from_pdf_kernel, dim3(B, 2), dim3(NT), lds, as_stream(stream), px, py, Lo, W, H, W_out,
                      H_out, inv_x, inv_y, map_x, map_y);
   return check_launch("axis_maps_from_pdf_kernel");
+}
+
+extern "C" int attwarp_axis_maps_from_steps(const float* steps, int T, int B, int g, int W, int H, int W_out, int H_out,
+                                            const double* inv_x, const double* inv_y, float* map_x, float* map_y,
+                                            float* att_out, void* stream) {
+  ATTWARP_REQUIRE(steps && inv_x && inv_y && map_x && map_y, "axis_maps_from_steps: null pointer");
+  ATTWARP_REQUIRE(T > 0 && B > 0 && g > 0 && W > 0 && H > 0 && W_out > 0 && H_out > 0,
+                  "axis_maps_from_steps: non-positive size");
+  if (g > 64) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: grid side %d > 64", g);
+  const int L = W > H ? W : H;
+  if (L > 8192) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: max(W,H)=%d > 8192", L);
+  if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: B > 65535");
+  const size_t lds = (size_t)(8 + L + 2) * sizeof(double) + (size_t)(L + g * g) * sizeof(float);
+  hipLaunchKernelGGL(axis_maps_from_steps_kernel, dim3(B, 2), dim3(NT), lds, as_stream(stream), steps, T, B, g, W, H,
+                     W_out, H_out, inv_x, inv_y, map_x, map_y, att_out);
+  return check_launch("axis_maps_from_steps_kernel");
 }
 
 extern "C" int attwarp_safe_softmax(const float* logits, int B, int N, float eps, float* out, void* stream) {

@@ -62,13 +62,62 @@ def warp_from_pdf(images: torch.Tensor, px: torch.Tensor, py: torch.Tensor, out_
     return cu.remap_separable(images, mx, my, mode=mode, channels_last=channels_last)
 
 
+def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int],
+                                   out_size: Optional[Tuple[int, int]] = None, eps: float = 1e-8,
+                                   return_attention: bool = False):
+    """Per-step aggregated maps [T,B,g*g] float32 (output of the A1 kernel) -> (map_x, map_y) in ONE
+    launch: mean over steps, marginals of the g x g map, PDF up-sample, CDF, inverse maps.
+    Bit-identical to attn_finalize -> gt_marginals -> axis_maps_from_pdf."""
+    dev = require_gpu(steps)
+    s = steps.detach().contiguous()
+    if s.dtype != torch.float32:
+        raise TypeError("axis_maps_from_attention_steps: float32 step maps expected (use the staged path otherwise)")
+    T, B, ntok = s.shape
+    g = int(round(ntok ** 0.5))
+    if g * g != ntok:
+        raise ValueError(f"step maps of {ntok} tokens are not a square grid")
+    H, W = int(size_hw[0]), int(size_hw[1])
+    H_out, W_out = (H, W) if out_size is None else (int(out_size[0]), int(out_size[1]))
+    inv_x = _tables.right_inverse_inv(g, W, eps, dev)
+    inv_y = _tables.right_inverse_inv(g, H, eps, dev)
+    mx = torch.empty(B, W_out, device=dev, dtype=torch.float32)
+    my = torch.empty(B, H_out, device=dev, dtype=torch.float32)
+    att = torch.empty(B, ntok, device=dev, dtype=torch.float32) if return_attention else None
+    with torch.cuda.device(dev):
+        call("attwarp_axis_maps_from_steps", ptr(s), T, B, g, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y), ptr(mx),
+             ptr(my), ptr(att), stream_ptr(dev))
+    return (mx, my, att) if return_attention else (mx, my)
+
+
+def attention_step_maps(rows: torch.Tensor, starts: torch.Tensor, ntok: int = ae.NUM_IMAGE_TOKENS,
+                        starts_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A1 over a captured stack: rows [T,B,heads,kv] -> per-step maps [T,B,ntok] (one launch)."""
+    r = rows.contiguous()
+    T, B, heads, kv = r.shape
+    if starts_tiled is None:
+        starts_tiled = starts.repeat(T)
+    steps = ae.attn_reduce_step(r.view(T * B, heads, 1, kv), starts_tiled, ntok)
+    return steps.view(T, B, ntok)
+
+
 def warp_from_attention_stack(images: torch.Tensor, rows: torch.Tensor, starts: torch.Tensor, out_size=None,
-                              channels_last=False, mode: str = "exact") -> torch.Tensor:
-    """images: batch on the GPU; rows [T,B,heads,kv] last-query attention rows; starts int32 [B]."""
-    B = images.shape[0]
-    att = ae.attn_reduce_stack(rows, starts, ae.NUM_IMAGE_TOKENS).float().view(B, 1, GRID, GRID)
-    px, py = cu.gt_marginals(att)
-    return warp_from_pdf(images, px, py, out_size, channels_last, mode)
+                              channels_last=False, mode: str = "exact", out: Optional[torch.Tensor] = None,
+                              starts_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """images: batch on the GPU; rows [T,B,heads,kv] last-query attention rows; starts int32 [B].
+    Three launches for float32 attention: A1 (step maps) -> fused A2+A6+A8+A9+A11 (maps) -> A12 (warp)."""
+    if channels_last:
+        H, W = images.shape[1], images.shape[2]
+    else:
+        H, W = images.shape[2], images.shape[3]
+    if rows.dtype == torch.float32:
+        steps = attention_step_maps(rows, starts, ae.NUM_IMAGE_TOKENS, starts_tiled)
+        mx, my = axis_maps_from_attention_steps(steps, (H, W), out_size)
+    else:   # model-dtype (fp16 / bf16) attention: finalize rounds in that dtype, then the float32 chain
+        B = images.shape[0]
+        att = ae.attn_reduce_stack(rows, starts, ae.NUM_IMAGE_TOKENS).float().view(B, 1, GRID, GRID)
+        px, py = cu.gt_marginals(att)
+        mx, my = axis_maps_from_pdf(px, py, (H, W), out_size)
+    return cu.remap_separable(images, mx, my, mode=mode, channels_last=channels_last, out=out)
 
 
 def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500, 500), enhance_coe=10,

@@ -61,12 +61,13 @@ class Step:
         self.B, self.S = B, S
         self.img, self.rows, self.starts = make_inputs(B, S, dev, seed)
         self.out = torch.empty_like(self.img)
+        self.starts_tiled = self.starts.repeat(T_STEPS)
         self.events = []
 
     def __call__(self, record: bool = False):
-        att = self.ae.attn_reduce_stack(self.rows, self.starts, NTOK).view(self.B, 1, 24, 24)
-        px, py = self.cu.gt_marginals(att)
-        mx, my = self.pipeline.axis_maps_from_pdf(px, py, (self.S, self.S))
+        # same three launches as attwarp_amd.pipeline.warp_from_attention_stack, with events around the third
+        steps = self.pipeline.attention_step_maps(self.rows, self.starts, NTOK, self.starts_tiled)
+        mx, my = self.pipeline.axis_maps_from_attention_steps(steps, (self.S, self.S))
         if record:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)

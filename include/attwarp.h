@@ -133,6 +133,14 @@ ATTWARP_API int attwarp_axis_maps_from_pdf(const float* px, const float* py, int
                                int W_out, int H_out, const double* inv_x, const double* inv_y,
                                float* map_x, float* map_y, void* stream);
 
+/* ---- A2+A6+A8+A9+A11 fused: per-step attention maps (A1 output) -> inverse maps in ONE launch.
+ * steps [T,B,g*g] float32 -> mean over steps -> marginals of the g x g map -> PDF up-sample -> CDF ->
+ * map_x [B,W_out], map_y [B,H_out]; att_out (optional, may be NULL): the aggregated [B,g*g] map (A2 output).
+ * Bit-identical to the separate stages. */
+ATTWARP_API int attwarp_axis_maps_from_steps(const float* steps, int T, int B, int g, int W, int H, int W_out, int H_out,
+                                 const double* inv_x, const double* inv_y, float* map_x, float* map_y,
+                                 float* att_out, void* stream);
+
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.
  * ws: workspace of attwarp_axis_sums_workspace_bytes(B,h,w) bytes. */

@@ -517,6 +517,22 @@ def test_pipeline_attention_stack_end_to_end(dev):
     ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
     out = pipeline.warp_from_attention_stack(T(img, dev), T(rows, dev), T(starts, dev), channels_last=True)
     assert np.array_equal(N(out), ref)
+    # the fused maps launch is bit-identical to the staged one, and returns the aggregated map
+    steps = pipeline.attention_step_maps(T(rows, dev), T(starts, dev))
+    fmx, fmy, fatt = pipeline.axis_maps_from_attention_steps(steps, (S, S), return_attention=True)
+    assert np.array_equal(N(fmx), mx) and np.array_equal(N(fmy), my)
+    assert np.array_equal(N(fatt), att.reshape(B, 576))
+    fmx2, fmy2 = pipeline.axis_maps_from_attention_steps(steps, (S, S), out_size=(150, 90))
+    rx2, ry2 = O.maps_from_cdf(Fx, Fy, (150, 90))
+    assert np.array_equal(N(fmx2), rx2) and np.array_equal(N(fmy2), ry2)
+    # fp16 attention goes through the staged path (rounding in the model dtype)
+    out16 = pipeline.warp_from_attention_stack(T(img, dev), T(rows, dev).half(), T(starts, dev), channels_last=True)
+    att16 = O.attn_reduce_stack(rows.astype(np.float16), starts).astype(np.float32).reshape(B, 1, 24, 24)
+    p16x, p16y = O.gt_marginals(att16)
+    F16x = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(p16x, S), 0))
+    F16y = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(p16y, S), 0))
+    m16x, m16y = O.maps_from_cdf(F16x, F16y)
+    assert np.array_equal(N(out16), np.stack([O.remap_bilinear(img[b], m16x[b], m16y[b]) for b in range(B)]))
     out_chw = pipeline.warp_from_attention_stack(T(img.transpose(0, 3, 1, 2), dev), T(rows, dev), T(starts, dev))
     assert np.array_equal(N(out_chw).transpose(0, 2, 3, 1), ref)
     # HIP-graph replay of the same step gives the same bytes
