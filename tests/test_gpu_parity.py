@@ -598,3 +598,27 @@ def test_full_size_properties(dev, cfg):
     for bi in (0, B - 1):
         ref = O.remap_bilinear(N(img[bi]), N(mx[bi]), N(my[bi]))
         assert np.array_equal(N(a[bi]), ref)
+
+
+def test_integration_md_stub_runs(dev):
+    """The ctypes stub shown in INTEGRATION.md (what a reference maintainer would paste) must work as written."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(import ctypes, torch.*?)```", text, re.S).group(1)
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        ns = {}
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    rng = np.random.default_rng(61)
+    img = rng.random((2, 3, 40, 56), dtype=np.float32)
+    Fx = O.cdf_from_density(rng.random((2, 56), dtype=np.float32))
+    Fy = O.cdf_from_density(rng.random((2, 40), dtype=np.float32))
+    out = ns["warp_from_cdf_torch"](T(img, dev), T(Fx, dev), T(Fy, dev), (48, 64))
+    torch.cuda.synchronize()
+    assert np.array_equal(N(out), O.warp_from_cdf(img, Fx, Fy, (48, 64)))
+    with pytest.raises(ValueError):
+        ns["warp_from_cdf_torch"](T(img, dev), T(Fx[:, :50], dev), T(Fy, dev))
