@@ -34,58 +34,188 @@ struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION
   }
 };
 
-template <typename T> __device__ __forceinline__ double ld_f64(const T* p) { return (double)*p; }
-template <> __device__ __forceinline__ double ld_f64<uint8_t>(const uint8_t* p) { return (double)(int)*p; }
+// ---- numpy's pairwise summation, restated -------------------------------------------------------
+// np.sum over a contiguous axis (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum):
+//   n < 8         : res = 0.; for i: res += a[i]
+//   n <= 128      : r[0..7] = a[0..7]; r[k] += a[i+k] for i = 8, 16, ... < n - n%8;
+//                   res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)); then res += a[i] for the n%8 tail
+//   otherwise     : n2 = n/2; n2 -= n2 % 8; pairwise(a, n2) + pairwise(a+n2, n-n2)
+// The recursion only depends on n, so it is flattened once on the host into a list of leaves
+// (offset, length <= 128) and a postfix program over the leaf sums (0 = push next leaf, 1 = add).
+// tests/test_oracle_golden.py::test_numpy_pairwise_restatement pins this against np.sum itself.
+constexpr int PW_MAX_LEAVES = 128;   // rows up to 16384 elements
+struct PairwisePlan {
+  int nleaves;
+  int nprog;
+  int off[PW_MAX_LEAVES];
+  int len[PW_MAX_LEAVES];
+  unsigned char prog[2 * PW_MAX_LEAVES];
+};
 
-// Column sums: one thread per column, rows in ascending order.  grid = (ceil(W/NT), B)
-template <typename T, typename XF>
-__global__ __launch_bounds__(NT) void col_sums_kernel(const T* __restrict__ A, int H, int W, XF xf,
-                                                      double* __restrict__ col) {
-  const int b = blockIdx.y;
-  const int x = blockIdx.x * NT + threadIdx.x;
-  if (x >= W) return;
-  const T* base = A + (size_t)b * H * W + x;
-  double acc = 0.0;
-  int r = 0;
-  for (; r + 8 <= H; r += 8) {
-    double v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = xf(ld_f64(base + (size_t)(r + i) * W));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc = acc + v[i];
+static void pw_build_rec(int off, int n, PairwisePlan& P) {
+  if (n <= 128) {
+    P.off[P.nleaves] = off;
+    P.len[P.nleaves] = n;
+    P.nleaves++;
+    P.prog[P.nprog++] = 0;
+  } else {
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pw_build_rec(off, n2, P);
+    pw_build_rec(off + n2, n - n2, P);
+    P.prog[P.nprog++] = 1;
   }
-  for (; r < H; ++r) acc = acc + xf(ld_f64(base + (size_t)r * W));
-  col[(size_t)b * W + x] = acc;
+}
+static bool pw_build(int n, PairwisePlan& P) {
+  P.nleaves = 0;
+  P.nprog = 0;
+  if (n <= 0 || n > 128 * PW_MAX_LEAVES) return false;
+  pw_build_rec(0, n, P);
+  return true;
 }
 
-// Row sums: one wave per row.  grid = (ceil(H/4), B)
+// Evaluate the postfix program for one row given its leaf sums (`leaf(j)` returns leaf j).
+// `stack` is per-thread storage with stride `sstride` doubles (LDS), depth <= 10.
+template <typename LeafFn>
+__device__ __forceinline__ double pw_combine(const PairwisePlan& P, LeafFn leaf, double* stack, int sstride) {
+  int sp = 0, next = 0;
+  for (int i = 0; i < P.nprog; ++i) {
+    if (P.prog[i] == 0) {
+      stack[sp * sstride] = leaf(next++);
+      ++sp;
+    } else {
+      const double r = stack[(sp - 1) * sstride], l = stack[(sp - 2) * sstride];
+      stack[(sp - 2) * sstride] = l + r;
+      --sp;
+    }
+  }
+  return stack[0];
+}
+
+// Sequential (one thread) numpy-order sum of n doubles (LDS or global).
+__device__ inline double pw_sum_serial(const double* a, int n, const PairwisePlan& P) {
+  double stack[12];
+  int sp = 0, next = 0;
+  for (int i = 0; i < P.nprog; ++i) {
+    if (P.prog[i] == 0) {
+      const double* x = a + P.off[next];
+      const int len = P.len[next];
+      ++next;
+      double res;
+      if (len < 8) {
+        res = 0.0;
+        for (int j = 0; j < len; ++j) res += x[j];
+      } else {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = x[k];
+        int j = 8;
+        for (; j < len - (len % 8); j += 8) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) r[k] += x[j + k];
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; j < len; ++j) res += x[j];
+      }
+      if (sp < 12) stack[sp] = res;
+      ++sp;
+    } else {
+      stack[sp - 2] = stack[sp - 2] + stack[sp - 1];
+      --sp;
+    }
+  }
+  return stack[0];
+}
+
+template <typename T> struct TileT { using type = float; };        // uint8 / float32 are exact in float
+template <> struct TileT<double> { using type = double; };
+
+constexpr int RBAND = 64;    // rows per LDS tile
+constexpr int TSTR = RBAND + 1;
+
+// ---- single pass over [B,H,W]: column sums AND per-leaf row sums ---------------------------------
+// grid = (nleaves, B); block = 256.  The block owns one leaf (a strip of <= 128 columns) and walks all
+// H rows in bands of 64 through an LDS tile (raw values, transposed, padded):
+//   threads   0..127 : column c of the strip, running sum over rows in ascending order = the order
+//                      np.sum(axis=0) uses, so the x profile is bit-identical to numpy's;
+//   threads 128..191 : row r of the band, numpy's 8-accumulator leaf sum over the strip's columns;
+//   all 256 threads load (coalesced along the row).
+// leaf sums go to ls[b][row][leaf]; the per-row tree over leaves runs in the finalize kernels.
 template <typename T, typename XF>
-__global__ __launch_bounds__(NT) void row_sums_kernel(const T* __restrict__ A, int H, int W, XF xf,
-                                                      double* __restrict__ row) {
-  const int b = blockIdx.y;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int y = blockIdx.x * (NT / WAVE) + threadIdx.x / WAVE;
-  if (y >= H) return;
-  const T* base = A + ((size_t)b * H + y) * W;
-  double acc = 0.0;
-  for (int x = lane; x < W; x += WAVE) acc = acc + xf(ld_f64(base + x));
-  acc = wave_sum(acc);
-  if (lane == 0) row[(size_t)b * H + y] = acc;
+__global__ __launch_bounds__(NT) void profiles_kernel(const T* __restrict__ A, int H, int W, XF xf,
+                                                      const PairwisePlan P, double* __restrict__ col,
+                                                      double* __restrict__ ls) {
+  using TT = typename TileT<T>::type;
+  __shared__ TT tile[128 * TSTR];
+  const int leaf = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int off = P.off[leaf], len = P.len[leaf], nleaves = P.nleaves;
+  const T* base = A + (size_t)b * H * W + off;
+  const int c = tid & 127, rr = tid >> 7;
+  double cacc = 0.0;
+  for (int row0 = 0; row0 < H; row0 += RBAND) {
+    const int nb = min(RBAND, H - row0);
+    if (c < len) {
+      for (int r = rr; r < nb; r += 2) tile[c * TSTR + r] = (TT)base[(size_t)(row0 + r) * W + c];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      if (tid < len) {
+        const TT* tc = tile + tid * TSTR;
+        for (int r = 0; r < nb; ++r) cacc = cacc + xf((double)tc[r]);
+      }
+    } else if (tid < 128 + RBAND) {
+      const int r = tid - 128;
+      if (r < nb) {
+        const TT* tr = tile + r;
+        double res;
+        if (len < 8) {
+          res = 0.0;
+          for (int j = 0; j < len; ++j) res += xf((double)tr[j * TSTR]);
+        } else {
+          double acc8[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc8[k] = xf((double)tr[k * TSTR]);
+          int j = 8;
+          for (; j < len - (len % 8); j += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc8[k] += xf((double)tr[(j + k) * TSTR]);
+          }
+          res = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+          for (; j < len; ++j) res += xf((double)tr[j * TSTR]);
+        }
+        ls[((size_t)b * H + row0 + r) * nleaves + leaf] = res;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < len) col[(size_t)b * W + off + tid] = cacc;
 }
 
 // ---- A6 finalize: normalise a marginal.  grid = (B, 2) ----------------------------------
 __global__ __launch_bounds__(NT) void marginals_finalize_kernel(const double* __restrict__ col,
-                                                                const double* __restrict__ row, int H, int W,
-                                                                float* __restrict__ px, float* __restrict__ py) {
+                                                                const double* __restrict__ ls, int nleaves, int H,
+                                                                int W, float* __restrict__ px,
+                                                                float* __restrict__ py) {
+  extern __shared__ __attribute__((aligned(16))) double smem_d[];   // n doubles
   __shared__ double red[NT / WAVE];
   const int b = blockIdx.x, axis = blockIdx.y;
   const int n = axis ? H : W;
-  const double* src = (axis ? row : col) + (size_t)b * n;
   float* dst = (axis ? py : px) + (size_t)b * n;
   double acc = 0.0;
-  for (int k = threadIdx.x; k < n; k += blockDim.x) acc += (double)(float)src[k];
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    double v;
+    if (axis) {
+      v = 0.0;
+      const double* l = ls + ((size_t)b * H + k) * nleaves;
+      for (int j = 0; j < nleaves; ++j) v += l[j];
+    } else {
+      v = col[(size_t)b * W + k];
+    }
+    smem_d[k] = v;
+    acc += (double)(float)v;
+  }
   const float tot = fmaxf((float)block_sum(acc, red), 1e-6f);
-  for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (float)src[k] / tot;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (float)smem_d[k] / tot;
 }
 
 // ---- A5: adaptive average pool.  grid = (oh, B), one band of rows per block ---------------
@@ -136,62 +266,59 @@ __device__ __forceinline__ double inverse_transform(double x, int transform, dou
 }
 
 __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const double* __restrict__ col,
-                                                                     const double* __restrict__ row, int h, int w,
+                                                                     const double* __restrict__ ls, int h, int w,
+                                                                     const PairwisePlan Pw, const PairwisePlan Ph,
                                                                      int new_w, int new_h, int transform,
                                                                      double exp_scale, double exp_divisor,
                                                                      int apply_inverse, float* __restrict__ map_x,
                                                                      float* __restrict__ map_y) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   __shared__ double red[NT / WAVE];
+  __shared__ double pstack[10 * NT];     // per-thread stack of the leaf-combine program
+  __shared__ double s_total;
   const int b = blockIdx.x, axis = blockIdx.y;
   const int n = axis ? h : w;            // profile length
   const int other = axis ? w : h;        // number of terms summed into each profile entry
   const int n_out = axis ? new_h : new_w;
-  const double* prof_in = (axis ? row : col) + (size_t)b * n;
+  const int nl = Pw.nleaves;
   float* map = (axis ? map_y : map_x) + (size_t)b * n_out;
   double* xn = smem_d;                   // n+1 knots; xn[1..n] first holds the profile
 
-  // sum of all biased values (for the fallback's np.mean): use the row profile before any inverse
-  double all = 0.0;
-  {
-    const double* r = row + (size_t)b * h;
-    for (int k = threadIdx.x; k < h; k += blockDim.x) all += r[k];
-    all = block_sum(all, red);
+  // row r of the y profile = numpy's pairwise tree over that row's leaf sums
+  auto row_sum = [&](int r) -> double {
+    const double* l = ls + ((size_t)b * h + r) * nl;
+    return pw_combine(Pw, [&](int j) { return l[j]; }, pstack + threadIdx.x, NT);
+  };
+  auto inv_bias = [&](double v, int terms) -> double {
+    if (!apply_inverse) return v;
+    return inverse_transform(v - 1e-9 * (double)terms, transform, exp_scale, exp_divisor) + 1e-9 * (double)terms;
+  };
+  // this axis' profile (exact numpy order), the other axis' total and the grand total (any order:
+  // they only feed the `< 1e-9` fallback test and the fallback's np.mean)
+  double acc_other = 0.0, all = 0.0;
+  for (int k = threadIdx.x; k < w; k += blockDim.x) {
+    const double v = col[(size_t)b * w + k];
+    if (axis == 0) xn[k + 1] = inv_bias(v, h); else acc_other += inv_bias(v, h);
   }
-  double acc = 0.0, acc_other = 0.0;
-  for (int k = threadIdx.x; k < n; k += blockDim.x) {
-    double v = prof_in[k];
-    if (apply_inverse) {
-      v = inverse_transform(v - 1e-9 * (double)other, transform, exp_scale, exp_divisor);
-      v = v + 1e-9 * (double)other;
-    }
-    xn[k + 1] = v;
-    acc += v;
+  for (int k = threadIdx.x; k < h; k += blockDim.x) {
+    const double v = row_sum(k);
+    all += v;
+    if (axis == 1) xn[k + 1] = inv_bias(v, w); else acc_other += inv_bias(v, w);
   }
-  const double total_self = block_sum(acc, red);
-  {
-    // the fallback test looks at BOTH totals (total_att_x < EPS or total_att_y < EPS)
-    const int m = axis ? w : h;
-    const double* o = (axis ? col : row) + (size_t)b * m;
-    for (int k = threadIdx.x; k < m; k += blockDim.x) {
-      double v = o[k];
-      if (apply_inverse) {
-        v = inverse_transform(v - 1e-9 * (double)n, transform, exp_scale, exp_divisor);
-        v = v + 1e-9 * (double)n;
-      }
-      acc_other += v;
-    }
-    acc_other = block_sum(acc_other, red);
-  }
+  acc_other = block_sum(acc_other, red);
+  all = block_sum(all, red);
+  __syncthreads();
+  if (threadIdx.x == 0) s_total = pw_sum_serial(xn + 1, n, axis ? Ph : Pw);   // np.sum(profile), numpy's order
+  __syncthreads();
+  const double total_self = s_total;
   double total = total_self;
   const bool fallback = (total_self < 1e-9) || (acc_other < 1e-9);
-  __syncthreads();
   if (fallback) {
     for (int k = threadIdx.x; k < n; k += blockDim.x) xn[k + 1] = 1.0;
     // total_att_x = w * (np.mean(att_map_biased) * h); total_att_y = h * (mean * w); then max(., EPS)
     const double mean = all / ((double)h * (double)w);
     total = (double)n * (mean * (double)other);
-    total = (total != total) ? total : (total > 1e-9 ? total : 1e-9);   // python max(nan-first?) see note
+    total = (total != total) ? total : (total > 1e-9 ? total : 1e-9);   // python max(total, EPS): NaN stays
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -210,12 +337,10 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
 }
 
 template <typename T, typename XF>
-static int launch_axis_sums(const void* A, int B, int H, int W, XF xf, double* col, double* row, hipStream_t st) {
-  hipLaunchKernelGGL((col_sums_kernel<T, XF>), dim3((W + NT - 1) / NT, B), dim3(NT), 0, st, (const T*)A, H, W, xf, col);
-  int rc = check_launch("col_sums_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL((row_sums_kernel<T, XF>), dim3((H + 3) / 4, B), dim3(NT), 0, st, (const T*)A, H, W, xf, row);
-  return check_launch("row_sums_kernel");
+static int launch_profiles(const void* A, int B, int H, int W, XF xf, const PairwisePlan& P, double* col, double* ls,
+                           hipStream_t st) {
+  hipLaunchKernelGGL((profiles_kernel<T, XF>), dim3(P.nleaves, B), dim3(NT), 0, st, (const T*)A, H, W, xf, P, col, ls);
+  return check_launch("profiles_kernel");
 }
 
 }  // namespace attwarp
@@ -223,8 +348,9 @@ static int launch_axis_sums(const void* A, int B, int H, int W, XF xf, double* c
 using namespace attwarp;
 
 extern "C" size_t attwarp_axis_sums_workspace_bytes(int B, int H, int W) {
-  if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return (size_t)B * ((size_t)H + (size_t)W) * sizeof(double);
+  PairwisePlan P;
+  if (B <= 0 || H <= 0 || !pw_build(W, P)) return 0;
+  return (size_t)B * ((size_t)W + (size_t)H * P.nleaves) * sizeof(double);
 }
 
 extern "C" int attwarp_gt_marginals(const float* A, int B, int H, int W, float* px, float* py, void* ws,
@@ -232,12 +358,16 @@ extern "C" int attwarp_gt_marginals(const float* A, int B, int H, int W, float* 
   ATTWARP_REQUIRE(A && px && py && ws, "gt_marginals: null pointer");
   ATTWARP_REQUIRE(B > 0 && H > 0 && W > 0, "gt_marginals: non-positive size");
   if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "gt_marginals: B > 65535");
+  PairwisePlan P;
+  if (!pw_build(W, P) || H > 16384) return fail(ATTWARP_E_UNSUPPORTED, "gt_marginals: H, W must be <= 16384");
   double* col = (double*)ws;
-  double* row = col + (size_t)B * W;
+  double* ls = col + (size_t)B * W;
   hipStream_t st = as_stream(stream);
-  int rc = launch_axis_sums<float, XfClampPos>(A, B, H, W, XfClampPos{}, col, row, st);
+  int rc = launch_profiles<float, XfClampPos>(A, B, H, W, XfClampPos{}, P, col, ls, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(marginals_finalize_kernel, dim3(B, 2), dim3(NT), 0, st, col, row, H, W, px, py);
+  const int n = H > W ? H : W;
+  hipLaunchKernelGGL(marginals_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)n * sizeof(double), st, col, ls,
+                     P.nleaves, H, W, px, py);
   return check_launch("marginals_finalize_kernel");
 }
 
@@ -262,20 +392,22 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
                   "axis_maps_from_attention: unknown transform %d", transform);
   if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_attention: B > 65535");
   const int n = h > w ? h : w;
-  if (n > 16384) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_attention: max(h,w)=%d > 16384", n);
+  PairwisePlan Pw, Ph;
+  if (!pw_build(w, Pw) || !pw_build(h, Ph))
+    return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_attention: max(h,w)=%d > 16384", n);
   double* col = (double*)ws;
-  double* row = col + (size_t)B * w;
+  double* ls = col + (size_t)B * w;
   hipStream_t st = as_stream(stream);
   XfAttention xf{transform, exp_scale, exp_divisor};
   int rc;
   switch (dtype) {
-    case ATTWARP_U8: rc = launch_axis_sums<uint8_t, XfAttention>(att, B, h, w, xf, col, row, st); break;
-    case ATTWARP_F32: rc = launch_axis_sums<float, XfAttention>(att, B, h, w, xf, col, row, st); break;
-    case ATTWARP_F64: rc = launch_axis_sums<double, XfAttention>(att, B, h, w, xf, col, row, st); break;
+    case ATTWARP_U8: rc = launch_profiles<uint8_t, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
+    case ATTWARP_F32: rc = launch_profiles<float, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
+    case ATTWARP_F64: rc = launch_profiles<double, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
     default: return fail(ATTWARP_E_ARG, "axis_maps_from_attention: dtype must be U8, F32 or F64 (got %d)", dtype);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(attention_maps_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)(n + 2) * sizeof(double), st, col,
-                     row, h, w, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
+                     ls, h, w, Pw, Ph, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
   return check_launch("attention_maps_finalize_kernel");
 }

@@ -14,22 +14,21 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend: str | None = None) -> Tuple[int, int, int]:
+def init(backend: str | None = None, device_index: int | None = None) -> Tuple[int, int, int]:
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
-    Returns (rank, world_size, local_rank).  Single-process runs need no environment."""
+    Returns (rank, world_size, local_rank).  Single-process runs need no environment.
+    ``device_index`` overrides the GPU (default: LOCAL_RANK) -- only used to smoke-test the N>1 code
+    path on a one-GPU box with the gloo backend."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_idx = local if device_index is None else device_index
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev_idx)
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        dist.init_process_group(backend)      # "nccl" is RCCL on ROCm; rendezvous from MASTER_ADDR/PORT
     return rank, world, local
 
 
@@ -49,8 +48,14 @@ def broadcast_module_weights(module: torch.nn.Module, src: int = 0) -> int:
     if not tensors:
         return 0
     dev = tensors[0].device
-    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors]).to(dev)
-    dist.broadcast(flat, src=src)
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    if dist.get_backend() == "gloo":          # CPU smoke tests: stage through host memory
+        host = flat.cpu()
+        dist.broadcast(host, src=src)
+        flat = host.to(dev)
+    else:
+        flat = flat.to(dev)
+        dist.broadcast(flat, src=src)
     off = 0
     for t in tensors:
         n = t.numel()
@@ -73,7 +78,10 @@ def all_gather_counters(values: Dict[str, float]) -> Dict[str, list]:
 
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float) -> float:

@@ -150,10 +150,15 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1024")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary 336x336 measurement")
+    ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="force the GPU index (smoke-testing the N>1 path on a one-GPU box with --dist-backend gloo)")
     args = ap.parse_args()
 
     from attwarp_amd import dist as D, _lib
-    rank, world, local = D.init()
+    rank, world, local = D.init(args.dist_backend, args.device)
+    if args.device is not None:
+        local = args.device
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():

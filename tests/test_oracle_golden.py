@@ -258,3 +258,41 @@ def test_warp_from_cdf_validation():
         O.warp_from_cdf(img[0], F, F)
     out = O.warp_from_cdf(img + 0.25, F, F)
     assert out.shape == (1, 3, 8, 8) and np.allclose(out, 0.25)
+
+
+def test_numpy_pairwise_restatement():
+    """The device code restates np.sum's pairwise order (leaves <= 128, 8 accumulators, halves aligned
+    down to 8); this is the same algorithm in Python, checked against np.sum itself."""
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for v in a:
+                r += v
+            return r
+        if n <= 128:
+            r = [a[k] for k in range(8)]
+            i = 8
+            while i < n - (n % 8):
+                for k in range(8):
+                    r[k] += a[i + k]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res += a[i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(a[:n2]) + pw(a[n2:])
+    rng = np.random.default_rng(7)
+    for n in (1, 5, 8, 9, 127, 128, 129, 336, 500, 1000, 1024, 1025, 4099):
+        x = rng.random(n) * 255 + 1e-9
+        assert pw(list(x)) == np.sum(x)
+    x2 = rng.random((9, 336)) * 255 + 1e-9
+    s1 = np.sum(x2, axis=1)
+    assert all(pw(list(x2[i])) == s1[i] for i in range(9))
+    seq = np.zeros(336)
+    for i in range(9):
+        seq = seq + x2[i]
+    assert np.array_equal(seq, np.sum(x2, axis=0))          # axis=0: plain ascending-row accumulation
