@@ -18,18 +18,15 @@ constexpr int NT = 256;
 struct XfClampPos {  // gt_marginals: A.clamp_min(0)
   __device__ __forceinline__ double operator()(double v) const { return (v != v) ? v : (v > 0.0 ? v : 0.0); }  // NaN propagates
 };
-struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION
-  int transform;
+template <int TR>
+struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION   (TR = ATTWARP_T_*, compile time)
   double exp_scale, exp_divisor;
   __device__ __forceinline__ double operator()(double v) const {
     double a = (v != v) ? v : (v > 0.0 ? v : 0.0);       // np.maximum(x, 0) propagates NaN
-    switch (transform) {
-      case ATTWARP_T_SQUARE: a = a * a; break;
-      case ATTWARP_T_SQRT: a = sqrt((a != a) ? a : (a > 0.0 ? a : 0.0)); break;
-      case ATTWARP_T_EXP: a = exp(exp_scale * a) / exp_divisor; break;
-      case ATTWARP_T_LOG: a = log(a + 1e-5); break;
-      default: break;
-    }
+    if (TR == ATTWARP_T_SQUARE) a = a * a;
+    else if (TR == ATTWARP_T_SQRT) a = sqrt(a);            // a >= 0 or NaN here
+    else if (TR == ATTWARP_T_EXP) a = exp(exp_scale * a) / exp_divisor;
+    else if (TR == ATTWARP_T_LOG) a = log(a + 1e-5);
     return a + 1e-9;
   }
 };
@@ -92,39 +89,49 @@ __device__ __forceinline__ double pw_combine(const PairwisePlan& P, LeafFn leaf,
   return stack[0];
 }
 
-// Sequential (one thread) numpy-order sum of n doubles (LDS or global).
-__device__ inline double pw_sum_serial(const double* a, int n, const PairwisePlan& P) {
-  double stack[12];
-  int sp = 0, next = 0;
-  for (int i = 0; i < P.nprog; ++i) {
-    if (P.prog[i] == 0) {
-      const double* x = a + P.off[next];
-      const int len = P.len[next];
-      ++next;
-      double res;
+// np.sum(a[0..n)) in numpy's order by a whole 256-thread block (a in LDS).  Eight consecutive lanes own the
+// eight strided accumulators of one leaf (32 leaves per pass), an xor-butterfly over those lanes is exactly
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), lane 0 of the group adds the leaf's tail, thread 0 runs the tree.
+// leafbuf: LDS, PW_MAX_LEAVES doubles.  Result valid in ALL threads.  Ends with a barrier.
+__device__ inline double pw_sum_block(const double* a, const PairwisePlan& P, double* leafbuf) {
+  const int tid = threadIdx.x, k = tid & 7;
+  for (int l0 = 0; l0 < P.nleaves; l0 += NT / 8) {
+    const int j = l0 + (tid >> 3);
+    const bool live = j < P.nleaves;
+    const double* x = a + (live ? P.off[j] : 0);
+    const int len = live ? P.len[j] : 0;
+    double r = 0.0;
+    if (len >= 8) {
+      r = x[k];
+      for (int i = 8; i < len - (len % 8); i += 8) r += x[i + k];
+    }
+    r += __shfl_xor(r, 1, WAVE);
+    r += __shfl_xor(r, 2, WAVE);
+    r += __shfl_xor(r, 4, WAVE);
+    if (live && k == 0) {
       if (len < 8) {
-        res = 0.0;
-        for (int j = 0; j < len; ++j) res += x[j];
+        r = 0.0;
+        for (int i = 0; i < len; ++i) r += x[i];
       } else {
-        double r[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) r[k] = x[k];
-        int j = 8;
-        for (; j < len - (len % 8); j += 8) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) r[k] += x[j + k];
-        }
-        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; j < len; ++j) res += x[j];
+        for (int i = len - (len % 8); i < len; ++i) r += x[i];
       }
-      if (sp < 12) stack[sp] = res;
-      ++sp;
-    } else {
-      stack[sp - 2] = stack[sp - 2] + stack[sp - 1];
-      --sp;
+      leafbuf[j] = r;
     }
   }
-  return stack[0];
+  __syncthreads();
+  if (tid == 0) {
+    double stack[12];
+    int sp = 0, next = 0;
+    for (int i = 0; i < P.nprog; ++i) {
+      if (P.prog[i] == 0) { if (sp < 12) stack[sp] = leafbuf[next]; ++next; ++sp; }
+      else { stack[sp - 2] = stack[sp - 2] + stack[sp - 1]; --sp; }
+    }
+    leafbuf[0] = stack[0];
+  }
+  __syncthreads();
+  const double tot = leafbuf[0];
+  __syncthreads();
+  return tot;
 }
 
 template <typename T> struct TileT { using type = float; };        // uint8 / float32 are exact in float
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   __shared__ double red[NT / WAVE];
   __shared__ double pstack[10 * NT];     // per-thread stack of the leaf-combine program
-  __shared__ double s_total;
+  __shared__ double leafbuf[PW_MAX_LEAVES];
   const int b = blockIdx.x, axis = blockIdx.y;
   const int n = axis ? h : w;            // profile length
   const int other = axis ? w : h;        // number of terms summed into each profile entry
@@ -308,9 +315,7 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
   acc_other = block_sum(acc_other, red);
   all = block_sum(all, red);
   __syncthreads();
-  if (threadIdx.x == 0) s_total = pw_sum_serial(xn + 1, n, axis ? Ph : Pw);   // np.sum(profile), numpy's order
-  __syncthreads();
-  const double total_self = s_total;
+  const double total_self = pw_sum_block(xn + 1, axis ? Ph : Pw, leafbuf);   // np.sum(profile), numpy's order
   double total = total_self;
   const bool fallback = (total_self < 1e-9) || (acc_other < 1e-9);
   if (fallback) {
@@ -322,12 +327,24 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    // np.cumsum (sequential), / total, * new ; knot 0 = 0 * new ; last knot = new
+    // np.cumsum: sequential running sum (adds only; the division below is elementwise and parallel)
     double c = 0.0;
-    for (int k = 1; k <= n; ++k) {
-      c = c + xn[k];
-      xn[k] = (c / total) * (double)n_out;
+    int k = 1;
+    for (; k + 4 <= n + 1; k += 4) {
+      double v0 = xn[k], v1 = xn[k + 1], v2 = xn[k + 2], v3 = xn[k + 3];
+      c = c + v0; v0 = c;
+      c = c + v1; v1 = c;
+      c = c + v2; v2 = c;
+      c = c + v3; v3 = c;
+      xn[k] = v0; xn[k + 1] = v1; xn[k + 2] = v2; xn[k + 3] = v3;
     }
+    for (; k <= n; ++k) { c = c + xn[k]; xn[k] = c; }
+  }
+  __syncthreads();
+  // (cum / total) * new ; knot 0 = 0 * new ; last knot = new
+  for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) xn[k] = (xn[k] / total) * (double)n_out;
+  __syncthreads();
+  if (threadIdx.x == 0) {
     xn[0] = 0.0;
     xn[n] = (double)n_out;
   }
@@ -398,14 +415,25 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
   double* col = (double*)ws;
   double* ls = col + (size_t)B * w;
   hipStream_t st = as_stream(stream);
-  XfAttention xf{transform, exp_scale, exp_divisor};
-  int rc;
-  switch (dtype) {
-    case ATTWARP_U8: rc = launch_profiles<uint8_t, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
-    case ATTWARP_F32: rc = launch_profiles<float, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
-    case ATTWARP_F64: rc = launch_profiles<double, XfAttention>(att, B, h, w, xf, Pw, col, ls, st); break;
-    default: return fail(ATTWARP_E_ARG, "axis_maps_from_attention: dtype must be U8, F32 or F64 (got %d)", dtype);
+  int rc = ATTWARP_E_ARG;
+#define ATTWARP_PROFILES(TR)                                                                                      \
+  case TR: {                                                                                                      \
+    XfAttention<TR> xf{exp_scale, exp_divisor};                                                                   \
+    if (dtype == ATTWARP_U8) rc = launch_profiles<uint8_t, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);   \
+    else if (dtype == ATTWARP_F32) rc = launch_profiles<float, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st); \
+    else rc = launch_profiles<double, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);                        \
+  } break;
+  if (dtype != ATTWARP_U8 && dtype != ATTWARP_F32 && dtype != ATTWARP_F64)
+    return fail(ATTWARP_E_ARG, "axis_maps_from_attention: dtype must be U8, F32 or F64 (got %d)", dtype);
+  switch (transform) {
+    ATTWARP_PROFILES(ATTWARP_T_IDENTITY)
+    ATTWARP_PROFILES(ATTWARP_T_SQUARE)
+    ATTWARP_PROFILES(ATTWARP_T_SQRT)
+    ATTWARP_PROFILES(ATTWARP_T_EXP)
+    ATTWARP_PROFILES(ATTWARP_T_LOG)
+    default: break;
   }
+#undef ATTWARP_PROFILES
   if (rc) return rc;
   hipLaunchKernelGGL(attention_maps_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)(n + 2) * sizeof(double), st, col,
                      ls, h, w, Pw, Ph, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
