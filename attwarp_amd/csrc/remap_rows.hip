@@ -196,18 +196,29 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     __syncthreads();                                                                                \
     const char* rowb = reinterpret_cast<const char*>(rowbuf);                                       \
     char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + yi_) * p.orow_len);               \
-    float v0[KO], v1[KO];                                                                           \
-    _Pragma("unroll") for (int k = 0; k < KO; ++k) {                                                \
-      unsigned w = pk[k];                                                                           \
-      asm volatile("" : "+v"(w)); /* keep the packed form live: no 2*KO hoisted unpacked offsets */ \
-      v0[k] = *reinterpret_cast<const float*>(rowb + (w & 0xffffu));                                \
-      v1[k] = *reinterpret_cast<const float*>(rowb + (w >> 16));                                    \
-    }                                                                                               \
-    _Pragma("unroll") for (int k = 0; k < KO; ++k) {                                                \
-      const unsigned off = AFF ? (unsigned)(tid * 4 + NT * 4 * k) : ooff[k];                        \
-      const float o_ = lerp_rn(v0[k], v1[k], fxr[k]);                                               \
-      if (p.nt_store) __builtin_nontemporal_store(o_, reinterpret_cast<float*>(orow + off));        \
-      else *reinterpret_cast<float*>(orow + off) = o_;                                              \
+    /* gather in two halves: 2*KO/2 LDS reads in flight, then their lerps+stores (caps live registers) */ \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                        \
+      constexpr int KH = (KO + 1) / 2;                                                              \
+      float v0[KH], v1[KH];                                                                         \
+      _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
+        const int k = half * KH + kk;                                                               \
+        if (k < KO) {                                                                               \
+          unsigned w = pk[k];                                                                       \
+          asm volatile("" : "+v"(w)); /* keep the packed form live: no hoisted unpacked offsets */  \
+          v0[kk] = *reinterpret_cast<const float*>(rowb + (w & 0xffffu));                           \
+          v1[kk] = *reinterpret_cast<const float*>(rowb + (w >> 16));                               \
+        }                                                                                           \
+      }                                                                                             \
+      _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
+        const int k = half * KH + kk;                                                               \
+        if (k < KO) {                                                                               \
+          const unsigned off = AFF ? (unsigned)(tid * 4 + NT * 4 * k) : ooff[k];                    \
+          const float o_ = lerp_rn(v0[kk], v1[kk], fxr[k]);                                         \
+          if (p.nt_store) __builtin_nontemporal_store(o_, reinterpret_cast<float*>(orow + off));    \
+          else *reinterpret_cast<float*>(orow + off) = o_;                                          \
+        }                                                                                           \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                               \
   } while (0)
 
@@ -255,6 +266,9 @@ static int launch_rows_ki(const RowsParams& p, int ko, hipStream_t st) {
   if (ko <= 12) return launch_rows_t<KI, 12>(p, st);
   return launch_rows_t<KI, 16>(p, st);
 }
+
+int launch_remap_ring(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
+                      const float* mx, const float* my, int R, hipStream_t st);
 
 // Returns via *handled whether the fast path took the request.
 int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
@@ -305,6 +319,8 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   if (const char* pe = getenv("ATTWARP_REMAP_LDSPAD")) { int v = atoi(pe); if (v >= 0 && v <= 140000) p.lds_pad = v; }
   const int ki = (p.VLV + NT - 1) / NT, ko = (p.OVL + NT - 1) / NT;
   *handled = true;
+  if (env && env[0] == 'l')   // LDS-ring variant (remap_ring.hip)
+    return launch_remap_ring(src, dst, layout, B, C, H, W, Ho, Wo, mx, my, R, st);
   switch (ki) {
     case 1: return launch_rows_ki<1>(p, ko, st);
     case 2: return launch_rows_ki<2>(p, ko, st);

@@ -400,7 +400,7 @@ def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
         if dt == np.uint8:
             img = (img * 255).astype(np.uint8)
         ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
-        for variant in ("rows", "gather"):
+        for variant in ("rows", "gather", "lds-ring"):
             os.environ["ATTWARP_REMAP_VARIANT"] = variant[0]
             try:
                 hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
@@ -424,10 +424,13 @@ def test_remap_rows_block_boundaries(dev, R):
     ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(2)])
     os.environ["ATTWARP_REMAP_ROWS"] = R
     try:
-        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+        for variant in ("r", "l"):
+            os.environ["ATTWARP_REMAP_VARIANT"] = variant
+            got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+            assert np.array_equal(got, ref), variant
     finally:
         os.environ.pop("ATTWARP_REMAP_ROWS", None)
-    assert np.array_equal(got, ref)
+        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.uint8])
@@ -602,12 +605,15 @@ def test_full_size_properties(dev, cfg):
     assert bool((mx[:, 1:] >= mx[:, :-1]).all()) and float(mx.min()) >= 0 and float(mx.max()) <= S
     del out
     a = cu.remap_separable(img, mx, my, channels_last=True)
-    os.environ["ATTWARP_REMAP_VARIANT"] = "g"
-    try:
-        b = cu.remap_separable(img, mx, my, channels_last=True)
-    finally:
-        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
-    assert torch.equal(a, b)
+    for variant in ("g", "r", "l"):       # gather / register-cache rows / LDS-ring rows kernels
+        os.environ["ATTWARP_REMAP_VARIANT"] = variant
+        try:
+            b = cu.remap_separable(img, mx, my, channels_last=True)
+        finally:
+            os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+        assert torch.equal(a, b), variant
+        del b
+    b = None
     assert float(a.min()) >= float(img.min()) and float(a.max()) <= float(img.max())
     del b
     const = torch.full_like(img, 0.3125)

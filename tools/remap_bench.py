@@ -42,11 +42,8 @@ def run(env, *args):
         else: os.environ[k] = v
 
 if __name__ == "__main__":
-    for alt in ("0", "1"):
-        for R in ("2", "4", "8", "16", "32"):
-            run({"ATTWARP_REMAP_ALT": alt, "ATTWARP_REMAP_ROWS": R}, 256, 1024, "hwc", "uniform")
-    for R in ("4", "8", "16"):
-        run({"ATTWARP_REMAP_ROWS": R}, 256, 1024, "chw", "uniform")
-        run({"ATTWARP_REMAP_ROWS": R}, 256, 1024, "hwc", "peaked")
-        run({"ATTWARP_REMAP_ROWS": R}, 64, 336, "hwc", "uniform", 50)
-        run({"ATTWARP_REMAP_ROWS": R}, 256, 336, "hwc", "uniform", 50)
+    for rep in range(3):
+        for v4 in ("0", "1"):
+            run({"ATTWARP_REMAP_V4": v4}, 256, 1024, "hwc", "uniform")
+    run({"ATTWARP_REMAP_V4": "1"}, 256, 1024, "hwc", "peaked")
+    run({"ATTWARP_REMAP_V4": "1", "ATTWARP_REMAP_ROWS": "8"}, 256, 1024, "hwc", "uniform")
