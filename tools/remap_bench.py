@@ -42,8 +42,13 @@ def run(env, *args):
         else: os.environ[k] = v
 
 if __name__ == "__main__":
-    for rep in range(3):
-        for v4 in ("0", "1"):
-            run({"ATTWARP_REMAP_V4": v4}, 256, 1024, "hwc", "uniform")
-    run({"ATTWARP_REMAP_V4": "1"}, 256, 1024, "hwc", "peaked")
-    run({"ATTWARP_REMAP_V4": "1", "ATTWARP_REMAP_ROWS": "8"}, 256, 1024, "hwc", "uniform")
+    for rep in range(2):
+        for wg in ("64", "256"):
+            for R in ("4", "8", "12", "16"):
+                run({"ATTWARP_REMAP_WG": wg, "ATTWARP_REMAP_ROWS": R}, 256, 336, "hwc", "uniform", 50)
+    for wg in ("64", "256"):
+        run({"ATTWARP_REMAP_WG": wg}, 64, 336, "hwc", "uniform", 50)
+        run({"ATTWARP_REMAP_WG": wg}, 256, 336, "chw", "uniform", 50)
+        run({"ATTWARP_REMAP_WG": wg}, 256, 336, "hwc", "peaked", 50)
+    run({}, 256, 1024, "hwc", "uniform")
+    run({}, 256, 1024, "chw", "uniform")
