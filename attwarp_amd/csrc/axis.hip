@@ -62,27 +62,47 @@ __device__ void cdf_from_density_block(float* p, int L, double* red) {
   __syncthreads();
   for (int k = threadIdx.x; k < L; k += blockDim.x) p[k] = p[k] / denom;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    // sequential double-precision running sum (what torch's CPU cumsum does), 8 values per LDS round trip
-    double c = 0.0;
-    int k = 0;
-    if ((reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
-      float4* p4 = reinterpret_cast<float4*>(p);
-      for (; k + 8 <= L; k += 8) {
-        float4 a = p4[k >> 2], b4 = p4[(k >> 2) + 1];
-        c += (double)a.x; a.x = (float)c;
-        c += (double)a.y; a.y = (float)c;
-        c += (double)a.z; a.z = (float)c;
-        c += (double)a.w; a.w = (float)c;
-        c += (double)b4.x; b4.x = (float)c;
-        c += (double)b4.y; b4.y = (float)c;
-        c += (double)b4.z; b4.z = (float)c;
-        c += (double)b4.w; b4.w = (float)c;
-        p4[k >> 2] = a;
-        p4[(k >> 2) + 1] = b4;
-      }
+  // Running sum in double (what torch's CPU cumsum does), rounded to float32 per prefix.
+  // The values are float32 in [0,1] summing to ~1.  If every non-zero value is >= 2^-28, every partial sum
+  // is a multiple of 2^-51 below 2 and therefore EXACT in double: any association gives the same bits, so
+  // a parallel scan equals the sequential one.  Otherwise (denormal-ish densities) one lane runs the
+  // sequential scan.
+  int small = 0;
+  double lsum = 0.0;
+  const int per = (L + (int)blockDim.x - 1) / (int)blockDim.x;      // consecutive elements per thread
+  const int k0 = threadIdx.x * per, k1 = min(k0 + per, L);
+  for (int k = k0; k < k1; ++k) {
+    const float v = p[k];
+    small |= (v != 0.0f) && (v < 3.7252902984619140625e-9f);          // 2^-28
+    lsum += (double)v;
+  }
+  small = __syncthreads_or(small || !(lsum < 2.0));
+  if (!small) {
+    // exclusive scan of the per-thread sums: wave shuffle scan, then the wave totals through LDS
+    double inc = lsum;
+    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const double t = __shfl_up(inc, o, WAVE);
+      if (lane >= o) inc += t;
     }
-    for (; k < L; ++k) {
+    if (lane == WAVE - 1) red[wid] = inc;
+    __syncthreads();
+    double base = inc - lsum;
+    for (int w = 0; w < wid; ++w) base += red[w];
+    double c = base;
+    for (int k = k0; k < k1; ++k) {
+      c += (double)p[k];
+      p[k] = (float)c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) p[L - 1] = 1.0f;
+    __syncthreads();
+    return;
+  }
+  if (threadIdx.x == 0) {
+    double c = 0.0;
+    for (int k = 0; k < L; ++k) {
       c += (double)p[k];
       p[k] = (float)c;
     }
@@ -107,8 +127,9 @@ __global__ __launch_bounds__(NT) void cdf_from_density_kernel(const float* __res
 // MN/checkpoint_utils.py:64-131.  y: Lo floats (global), inv: Lo x Lo doubles (global),
 // tmp: LDS float[Lo], out: float[L] (LDS or global).
 __device__ __forceinline__ void adaptive_window(int k, int L, int Lo, int& s, int& e) {
-  s = (int)(((long long)k * L) / Lo);
-  e = (int)((((long long)(k + 1)) * L + Lo - 1) / Lo);
+  // k < Lo <= 64 and L <= 16384: the products fit 32 bits
+  s = (int)(((unsigned)k * (unsigned)L) / (unsigned)Lo);
+  e = (int)(((unsigned)(k + 1) * (unsigned)L + (unsigned)Lo - 1u) / (unsigned)Lo);
 }
 
 __device__ void right_inverse_block(const float* y, int Lo, int L, const double* inv, float* tmp, float* out,
@@ -120,7 +141,7 @@ __device__ void right_inverse_block(const float* y, int Lo, int L, const double*
   }
   __syncthreads();
   for (int l = threadIdx.x; l < L; l += blockDim.x) {
-    const int k0 = (int)(((long long)l * Lo) / L);
+    const int k0 = (int)(((unsigned)l * (unsigned)Lo) / (unsigned)L);
     float x = 0.0f;
     for (int k = max(k0 - 1, 0); k <= min(k0 + 1, Lo - 1); ++k) {
       int s, e;

@@ -266,6 +266,20 @@ def test_right_inverse_shapes_and_bad_density(dev, golden):
     assert np.abs(F - g["cdf_bad"]).max() <= 2.4e-7
 
 
+def test_cdf_scan_paths_agree_with_sequential_oracle(dev):
+    """cdf_from_density scans in parallel when every partial sum is provably exact in double and falls back
+    to one sequential lane otherwise (tiny densities); both must equal the oracle's sequential cumsum."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(71)
+    for L in (37, 336, 1024, 4099):
+        p = rng.random((4, L)).astype(np.float32)
+        p[1] *= rng.random(L).astype(np.float32) ** 8          # wide dynamic range, still >= 2^-28 after normalising?
+        p[2, ::3] = 1e-13                                       # forces the sequential path
+        p[3] = 0; p[3, L // 2] = 1.0; p[3, 5] = 3e-39           # one spike + a denormal
+        F = N(cu.cdf_from_density(T(p, dev)))
+        assert np.array_equal(F, O.cdf_from_density(p)), L
+
+
 def test_strictly_increasing_and_resample(dev, golden):
     from attwarp_amd import checkpoint_utils as cu
     g = golden("pdf_cdf")
