@@ -225,7 +225,8 @@ def main():
         n2 = max(args.steps, 50)
         rm2 = float(np.mean(remap2))
         ach2 = 2.0 * S2 * S2 * 3 * 4 * B2 / (rm2 * 1e-3) / 1e9
-        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), eager launches",
+        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), eager launches (a HIP-graph replay of the "
+                                      f"same 3 kernels measured identical: the step is GPU-bound)",
                           "value": round(world * B2 * n2 / wall2, 1), "unit": "images/s",
                           "ms_per_step": round(wall2 / n2 * 1e3, 4),
                           "roofline": {"achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
