@@ -17,6 +17,7 @@
 //                         of consecutive output rows; source rows are read once with 16-byte
 //                         coalesced loads, blended vertically in registers, staged in LDS and
 //                         gathered horizontally from LDS.  See DESIGN.md "K7".
+//   remap_rows_u8_kernel (remap_u8.hip) - the uint8 counterpart (main_batched chain).
 //   remap_gather_kernel - generic fallback (any size / dtype / mode): one thread per output
 //                         element, four global taps served by L1/L2.
 #include "common.hpp"
@@ -138,6 +139,8 @@ static int launch_gather(const void* src, void* dst, int B, int C, int H, int W,
 
 int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                       const float* mx, const float* my, int mode, hipStream_t st, bool* handled);
+int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
+                         const float* mx, const float* my, int mode, hipStream_t st, bool* handled);
 
 }  // namespace attwarp
 
@@ -161,6 +164,11 @@ extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int
     bool handled = false;
     int rc = launch_remap_rows((const float*)src, (float*)dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, st,
                                &handled);
+    if (handled) return rc;
+  } else {
+    bool handled = false;
+    int rc = launch_remap_rows_u8((const uint8_t*)src, (uint8_t*)dst, layout, B, C, H, W, H_out, W_out, map_x, map_y,
+                                  mode, st, &handled);
     if (handled) return rc;
   }
 
