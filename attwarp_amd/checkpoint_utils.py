@@ -143,6 +143,8 @@ def warp_from_cdf_torch(img: torch.Tensor, Fx_img: torch.Tensor, Fy_img: torch.T
     assert img.ndim == 4, f"img must be (B,C,H,W); got {img.shape}"
     B, C, H, W = img.shape
     H_out, W_out = (H, W) if out_size is None else out_size
+    if B == 0:
+        raise ValueError("need at least one array to stack")      # the reference's np.stack([]) (:201)
     if Fx_img.shape[-1] != W:
         raise ValueError(f"Fx_img[0] length {Fx_img.shape[-1]} != image width W={W}")
     if Fy_img.shape[-1] != H:

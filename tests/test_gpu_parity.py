@@ -661,3 +661,69 @@ def test_integration_md_stub_runs(dev):
     assert np.array_equal(N(out), O.warp_from_cdf(img, Fx, Fy, (48, 64)))
     with pytest.raises(ValueError):
         ns["warp_from_cdf_torch"](T(img, dev), T(Fx[:, :50], dev), T(Fy, dev))
+
+
+def test_hook_plumbing_with_dummy_decoder(dev):
+    """batch_hook_logger on a stand-in model: the hook is registered on layers[i].self_attn, the patched
+    forward forces output_attentions=True for that layer only, and generation steps accumulate."""
+    import types
+    from attwarp_amd import attention_extraction as ae
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.calls = []
+
+        def forward(self, hidden, output_attentions=False):
+            self.calls.append(output_attentions)
+            B, q = hidden.shape[0], hidden.shape[1]
+            w = torch.softmax(hidden.new_ones(B, 4, q, 640).cumsum(-1) * 0.01, dim=-1) if output_attentions else None
+            return hidden, w, None
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn = Attn()
+
+    model = types.SimpleNamespace(model=types.SimpleNamespace(layers=torch.nn.ModuleList([Layer() for _ in range(3)])),
+                                  config=types.SimpleNamespace(output_attentions=True))
+    hl = ae.batch_hook_logger(model, dev, layer_index=1)
+    assert model.config.output_attentions is False and model.batch_hooklogger is hl
+    hl.set_batch_image_token_ranges([10, 12], [586, 588])
+    h = torch.zeros(2, 5, 8, device=dev)
+    for i, layer in enumerate(model.model.layers):            # prefill
+        layer.self_attn(h)
+    for i, layer in enumerate(model.model.layers):            # one decode step
+        layer.self_attn(h[:, :1])
+    assert model.model.layers[1].self_attn.calls == [True, True]          # forced on the hooked layer
+    assert model.model.layers[0].self_attn.calls == [False, False]        # untouched elsewhere
+    assert len(hl.step_attentions) == 2 and hl.step_attentions[0].shape == (2, 576)
+    maps = hl.finalize_batch()
+    assert len(maps) == 2 and maps[0].shape == (24, 24)
+    assert abs(float(maps[0].sum()) - 1.0) < 1e-5                         # renormalised over the image tokens
+    hl.remove_hook_and_unpatch()
+    model.model.layers[1].self_attn(h)
+    assert model.model.layers[1].self_attn.calls[-1] is False and len(hl.step_attentions) == 2
+
+
+def test_wide_rows_fall_back_to_gather(dev):
+    """Rows wider than the fast kernels' 4096-element limit take the generic kernel; same bits."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(81)
+    H, W, C = 12, 1500, 3                                  # 4500 floats per row
+    for dt in (np.float32, np.uint8):
+        img = rng.random((1, H, W, C), dtype=np.float32)
+        if dt == np.uint8:
+            img = (img * 255).astype(np.uint8)
+        mx = np.sort(rng.random((1, 1600)).astype(np.float32) * W, axis=1)
+        my = np.sort(rng.random((1, 20)).astype(np.float32) * H, axis=1)
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+        assert np.array_equal(got[0], O.remap_bilinear(img[0], mx[0], my[0]))
+
+
+def test_empty_batch_behaves_like_reference(dev):
+    """warp_from_cdf_torch on B=0: the reference ends in np.stack([]) -> ValueError."""
+    from attwarp_amd import checkpoint_utils as cu
+    with pytest.raises(ValueError, match="at least one"):
+        cu.warp_from_cdf_torch(torch.zeros(0, 3, 8, 8, device=dev), torch.zeros(0, 8, device=dev),
+                               torch.zeros(0, 8, device=dev))
