@@ -65,21 +65,29 @@ class Step:
         self.events = []
 
     def __call__(self, record: bool = False):
-        # same three launches as attwarp_amd.pipeline.warp_from_attention_stack, with events around the third
+        # same three launches as attwarp_amd.pipeline.warp_from_attention_stack, with HIP events between them
+        # (torch's current stream == the stream the kernels are launched on)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
+        if record:
+            ev[0].record()
         steps = self.pipeline.attention_step_maps(self.rows, self.starts, NTOK, self.starts_tiled)
+        if record:
+            ev[1].record()
         mx, my = self.pipeline.axis_maps_from_attention_steps(steps, (self.S, self.S))
         if record:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()                              # torch's current stream == the stream of the launch
+            ev[2].record()
         self.cu.remap_separable(self.img, mx, my, channels_last=True, out=self.out)
         if record:
-            e1.record()
-            self.events.append((e0, e1))
+            ev[3].record()
+            self.events.append(ev)
         return self.out
 
+    def stage_ms(self):
+        """Mean duration of the three kernels of a step: (attention reduce, maps, resample)."""
+        return [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in self.events])) for i in range(3)]
+
     def remap_ms(self):
-        return [a.elapsed_time(b) for a, b in self.events]
+        return [e[2].elapsed_time(e[3]) for e in self.events]
 
 
 def run_workload(name, steps, warmup, dist_mod, dev, rank):
@@ -211,6 +219,9 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_mean": round(remap_ms, 4),
                      "kernel_ms_min": round(float(np.min(remap)), 4), "launches_timed": len(remap)},
     }
+    st_ms = step.stage_ms()
+    result["stages_ms"] = {"attn_reduce_step_kernel": round(st_ms[0], 4), "axis_maps_from_steps_kernel": round(st_ms[1], 4),
+                           "remap_rows_kernel": round(st_ms[2], 4)}
     if bcast:
         result["weights_broadcast"] = bcast
 

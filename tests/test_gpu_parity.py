@@ -727,3 +727,25 @@ def test_empty_batch_behaves_like_reference(dev):
     with pytest.raises(ValueError, match="at least one"):
         cu.warp_from_cdf_torch(torch.zeros(0, 3, 8, 8, device=dev), torch.zeros(0, 8, device=dev),
                                torch.zeros(0, 8, device=dev))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_equivalence(dev, world):
+    """Multi-GPU correctness by construction: the batch is cut into contiguous per-rank blocks
+    (dist.shard_range) and every rank runs the same pipeline on its block; concatenating the per-rank
+    results must give the single-process result byte for byte (images are independent)."""
+    from attwarp_amd import pipeline
+    from attwarp_amd.dist import shard_range
+    rng = np.random.default_rng(91)
+    B, T_, heads, kv, S = 11, 3, 32, 640, 64
+    rows = T(softmax_rows(rng, (T_, B, heads, kv), peak=(100, 140)), dev)
+    starts = T((35 + np.arange(B) % 8).astype(np.int32), dev)
+    img = T(rng.random((B, S, S, 3), dtype=np.float32), dev)
+    full = pipeline.warp_from_attention_stack(img, rows, starts, channels_last=True)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(B, r, world)
+        if hi > lo:
+            parts.append(pipeline.warp_from_attention_stack(img[lo:hi].contiguous(), rows[:, lo:hi].contiguous(),
+                                                            starts[lo:hi].contiguous(), channels_last=True))
+    assert torch.equal(torch.cat(parts), full)
