@@ -88,6 +88,69 @@ __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restric
   }
 }
 
+// float32 rows with unit kv stride: the same reduction with 16-byte loads (4-byte aligned: the image-token
+// slice starts at an arbitrary token).  Lane l owns tokens 4l..4l+3 (+256 per vector); NV = ceil(ntok/256).
+struct __attribute__((packed, aligned(4))) F4u {
+  float x, y, z, w;
+};
+template <int NV, int HU>
+__global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* __restrict__ attn, int heads,
+                                                                   int64_t sb, int64_t sh, int64_t row_off,
+                                                                   const int32_t* __restrict__ starts, int starts_mod,
+                                                                   int ntok, float* __restrict__ out) {
+  __shared__ double part[NT / WAVE][NV * 4 * WAVE];
+  constexpr int NW = NT / WAVE;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  const int st = starts[b % starts_mod];
+  const float* base = attn + (int64_t)b * sb + row_off + st;
+  double acc[NV][4];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
+  for (int h0 = wid; h0 < heads; h0 += NW * HU) {
+    F4u v[HU][NV];
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      const float* rp = base + (int64_t)min(h0 + u * NW, heads - 1) * sh;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int t = min(4 * lane + 4 * WAVE * i, ntok - 4);       // clamped: tail lanes re-read, masked below
+        v[u][i] = *reinterpret_cast<const F4u*>(rp + t);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < HU; ++u) {
+      if (h0 + u * NW < heads) {                                    // wave uniform
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (4 * lane + 4 * WAVE * i < ntok)
+            s += ((double)v[u][i].x + (double)v[u][i].y) + ((double)v[u][i].z + (double)v[u][i].w);
+        s = wave_sum(s);
+        const float den = fadd((float)s, 1e-12f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          acc[i][0] += (double)(v[u][i].x / den);
+          acc[i][1] += (double)(v[u][i].y / den);
+          acc[i][2] += (double)(v[u][i].z / den);
+          acc[i][3] += (double)(v[u][i].w / den);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[wid][4 * lane + 4 * WAVE * i + j] = acc[i][j];
+  __syncthreads();
+  const float nheads = (float)heads;
+  for (int t = threadIdx.x; t < ntok; t += NT) {
+    double m = 0.0;
+    for (int w = 0; w < NW; ++w) m += part[w][t];
+    out[(int64_t)b * ntok + t] = (float)m / nheads;
+  }
+}
+
 // mean over steps.  steps [Tn, n] -> out [n]
 template <typename T>
 __global__ __launch_bounds__(NT) void attn_finalize_kernel(const T* __restrict__ steps, int Tn, int64_t n,
@@ -243,6 +306,14 @@ __global__ __launch_bounds__(NT) void quantise_copy_kernel(const float* __restri
 template <typename T>
 static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
                        const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    // float32, contiguous kv, slice length a multiple of 4 and <= 768: 16-byte loads
+    if (skv == 1 && ntok % 4 == 0 && ntok >= 4 && ntok <= 3 * 4 * WAVE && sb % 1 == 0) {
+      hipLaunchKernelGGL((attn_reduce_step_f32v_kernel<3, 4>), dim3(nb), dim3(NT), 0, st, (const float*)attn, heads,
+                         sb, sh, row_off, starts, starts_mod, ntok, (float*)out);
+      return check_launch("attn_reduce_step_f32v_kernel");
+    }
+  }
   if (ntok <= 9 * WAVE)      // 576 image tokens (LLaVA-1.5): 9 per lane, 4 heads in flight
     hipLaunchKernelGGL((attn_reduce_step_kernel<T, 9, 4>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh,
                        row_off, skv, starts, starts_mod, ntok, (T*)out);
