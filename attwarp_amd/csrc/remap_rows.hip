@@ -285,9 +285,6 @@ static int launch_rows_nt(const RowsParams& p, hipStream_t st) {
   }
 }
 
-int launch_remap_ring(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
-                      const float* mx, const float* my, int R, hipStream_t st);
-
 // Returns via *handled whether the fast path took the request.
 int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                       const float* mx, const float* my, int mode, hipStream_t st, bool* handled) {
@@ -335,8 +332,6 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   if (const char* pe = getenv("ATTWARP_REMAP_NOSWZ")) p.no_swz = atoi(pe) != 0;
   if (const char* pe = getenv("ATTWARP_REMAP_LDSPAD")) { int v = atoi(pe); if (v >= 0 && v <= 140000) p.lds_pad = v; }
   *handled = true;
-  if (env && env[0] == 'l')   // LDS-ring variant (remap_ring.hip)
-    return launch_remap_ring(src, dst, layout, B, C, H, W, Ho, Wo, mx, my, R, st);
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)
   return launch_rows_nt<NT_BIG>(p, st);

@@ -414,7 +414,7 @@ def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
         if dt == np.uint8:
             img = (img * 255).astype(np.uint8)
         ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
-        for variant in ("rows", "gather", "lds-ring"):
+        for variant in ("rows", "gather"):
             os.environ["ATTWARP_REMAP_VARIANT"] = variant[0]
             try:
                 hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
@@ -438,13 +438,10 @@ def test_remap_rows_block_boundaries(dev, R):
     ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(2)])
     os.environ["ATTWARP_REMAP_ROWS"] = R
     try:
-        for variant in ("r", "l"):
-            os.environ["ATTWARP_REMAP_VARIANT"] = variant
-            got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
-            assert np.array_equal(got, ref), variant
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+        assert np.array_equal(got, ref)
     finally:
         os.environ.pop("ATTWARP_REMAP_ROWS", None)
-        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.uint8])
@@ -619,15 +616,12 @@ def test_full_size_properties(dev, cfg):
     assert bool((mx[:, 1:] >= mx[:, :-1]).all()) and float(mx.min()) >= 0 and float(mx.max()) <= S
     del out
     a = cu.remap_separable(img, mx, my, channels_last=True)
-    for variant in ("g", "r", "l"):       # gather / register-cache rows / LDS-ring rows kernels
-        os.environ["ATTWARP_REMAP_VARIANT"] = variant
-        try:
-            b = cu.remap_separable(img, mx, my, channels_last=True)
-        finally:
-            os.environ.pop("ATTWARP_REMAP_VARIANT", None)
-        assert torch.equal(a, b), variant
-        del b
-    b = None
+    os.environ["ATTWARP_REMAP_VARIANT"] = "g"      # the independent gather kernel
+    try:
+        b = cu.remap_separable(img, mx, my, channels_last=True)
+    finally:
+        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+    assert torch.equal(a, b)
     assert float(a.min()) >= float(img.min()) and float(a.max()) <= float(img.max())
     del b
     const = torch.full_like(img, 0.3125)

@@ -43,12 +43,11 @@ def run(env, *args):
 
 if __name__ == "__main__":
     for rep in range(2):
-        for wg in ("64", "256"):
-            for R in ("4", "8", "12", "16"):
-                run({"ATTWARP_REMAP_WG": wg, "ATTWARP_REMAP_ROWS": R}, 256, 336, "hwc", "uniform", 50)
-    for wg in ("64", "256"):
-        run({"ATTWARP_REMAP_WG": wg}, 64, 336, "hwc", "uniform", 50)
-        run({"ATTWARP_REMAP_WG": wg}, 256, 336, "chw", "uniform", 50)
-        run({"ATTWARP_REMAP_WG": wg}, 256, 336, "hwc", "peaked", 50)
-    run({}, 256, 1024, "hwc", "uniform")
-    run({}, 256, 1024, "chw", "uniform")
+        run({"ATTWARP_REMAP_VARIANT": "r"}, 256, 1024, "hwc", "uniform")
+        run({"ATTWARP_REMAP_VARIANT": "o", "ATTWARP_REMAP_NTMEM": "1"}, 256, 1024, "hwc", "uniform")
+        run({"ATTWARP_REMAP_VARIANT": "o", "ATTWARP_REMAP_NTMEM": "0"}, 256, 1024, "hwc", "uniform")
+    for var in ("r", "o"):
+        run({"ATTWARP_REMAP_VARIANT": var}, 256, 1024, "hwc", "peaked")
+        run({"ATTWARP_REMAP_VARIANT": var}, 256, 1024, "chw", "uniform")
+        run({"ATTWARP_REMAP_VARIANT": var}, 256, 336, "hwc", "uniform", 50)
+        run({"ATTWARP_REMAP_VARIANT": var}, 64, 336, "hwc", "uniform", 50)

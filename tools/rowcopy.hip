@@ -1,0 +1,101 @@
+// Dev tool: is remap_rows_kernel limited by its access PATTERN or by its own overheads?
+// Copies [rows x 3072] float32 with the same work decomposition (one 256-thread workgroup per R consecutive
+// 12 KB rows, 3 x 16-byte loads and stores per thread per row) but no LDS, no barrier, no arithmetic.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+template <int MODE>
+__global__ __launch_bounds__(256) void rowcopy(const float4* __restrict__ src, float4* __restrict__ dst, int nrows, int R) {
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * R;
+  for (int r = 0; r < R; ++r) {
+    const long long row = row0 + r;
+    if (row >= nrows) break;
+    const float4* s = src + row * 768;
+    float4* d = dst + row * 768;
+    float4 a, b, c;
+    if (MODE >= 2) {   // nontemporal loads
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f* sv = reinterpret_cast<const v4f*>(s);
+      v4f ta = __builtin_nontemporal_load(sv + tid), tb = __builtin_nontemporal_load(sv + tid + 256), tc = __builtin_nontemporal_load(sv + tid + 512);
+      a = make_float4(ta.x, ta.y, ta.z, ta.w); b = make_float4(tb.x, tb.y, tb.z, tb.w); c = make_float4(tc.x, tc.y, tc.z, tc.w);
+    } else {
+      a = s[tid]; b = s[tid + 256]; c = s[tid + 512];
+    }
+    if (MODE == 1) {  // dword stores, 256 B per wave instruction, like the resample kernel
+      float* df = reinterpret_cast<float*>(d);
+      const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int k = 0; k < 12; ++k) df[tid + 256 * k] = v[k];
+    } else if (MODE == 3) {   // nontemporal loads AND stores
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      v4f* dv = reinterpret_cast<v4f*>(d);
+      v4f ta = {a.x, a.y, a.z, a.w}, tb = {b.x, b.y, b.z, b.w}, tc = {c.x, c.y, c.z, c.w};
+      __builtin_nontemporal_store(ta, dv + tid); __builtin_nontemporal_store(tb, dv + tid + 256); __builtin_nontemporal_store(tc, dv + tid + 512);
+    } else {
+      d[tid] = a; d[tid + 256] = b; d[tid + 512] = c;
+    }
+  }
+}
+template <int VPT, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void flatcopy(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* s = reinterpret_cast<const v4f*>(src);
+  v4f* d = reinterpret_cast<v4f*>(dst);
+  const long long base = (long long)blockIdx.x * (256 * VPT) + threadIdx.x;
+  v4f v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) v[i] = NTL ? __builtin_nontemporal_load(s + base + 256 * i) : s[base + 256 * i];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) { if (NTS) __builtin_nontemporal_store(v[i], d + base + 256 * i); else d[base + 256 * i] = v[i]; }
+}
+template <int VPT, bool NTL, bool NTS>
+static void run_flat(const float4* src, float4* dst, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
+  std::vector<float> ts;
+  const long long n4 = (long long)bytes / 16;
+  for (int it = 0; it < 12; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((flatcopy<VPT, NTL, NTS>), dim3((unsigned)(n4 / (256 * VPT))), dim3(256), 0, 0, src, dst, n4);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("flat copy %2d float4/thread ntload=%d ntstore=%d: %.4f ms  %.2f TB/s\n", VPT, (int)NTL, (int)NTS, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
+}
+int main() {
+  const int B = 256, S = 1024;
+  const long long nrows = (long long)B * S;
+  const size_t bytes = (size_t)nrows * 3072 * 4;
+  float4 *src, *dst;
+  hipMalloc(&src, bytes); hipMalloc(&dst, bytes);
+  hipMemset(src, 1, bytes); hipMemset(dst, 0, bytes);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int mode = 0; mode < 4; ++mode)
+    for (int R : {1, 4, 32}) {
+      std::vector<float> ts;
+      for (int it = 0; it < 12; ++it) {
+        hipEventRecord(e0);
+        const int grid = (int)((nrows + R - 1) / R);
+        if (mode == 0) hipLaunchKernelGGL(rowcopy<0>, dim3(grid), dim3(256), 0, 0, src, dst, (int)nrows, R);
+        else if (mode == 1) hipLaunchKernelGGL(rowcopy<1>, dim3(grid), dim3(256), 0, 0, src, dst, (int)nrows, R);
+        else if (mode == 2) hipLaunchKernelGGL(rowcopy<2>, dim3(grid), dim3(256), 0, 0, src, dst, (int)nrows, R);
+        else hipLaunchKernelGGL(rowcopy<3>, dim3(grid), dim3(256), 0, 0, src, dst, (int)nrows, R);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+      }
+      std::sort(ts.begin(), ts.end());
+      const char* names[4] = {"plain float4", "dword stores", "nt loads    ", "nt ld + st  "};
+      printf("mode=%s R=%3d: %.4f ms  %.2f TB/s\n", names[mode], R, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
+    }
+  run_flat<4, false, false>(src, dst, bytes, e0, e1);
+  run_flat<4, true, false>(src, dst, bytes, e0, e1);
+  run_flat<4, false, true>(src, dst, bytes, e0, e1);
+  run_flat<4, true, true>(src, dst, bytes, e0, e1);
+  run_flat<1, true, true>(src, dst, bytes, e0, e1);
+  run_flat<2, true, true>(src, dst, bytes, e0, e1);
+  run_flat<8, true, true>(src, dst, bytes, e0, e1);
+  run_flat<3, true, true>(src, dst, bytes, e0, e1);
+  return 0;
+}
