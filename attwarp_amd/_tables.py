@@ -60,11 +60,28 @@ def _lanczos3(x: float) -> float:
     return _sinc(x) * _sinc(x / 3.0) if -3.0 <= x < 3.0 else 0.0
 
 
+def _bicubic(x: float) -> float:
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_FILTERS = {"lanczos": (_lanczos3, 3.0), "bicubic": (_bicubic, 2.0)}
+
+
 @functools.lru_cache(maxsize=64)
-def _lanczos_tables_host(n_in: int, n_out: int):
+def _lanczos_tables_host(n_in: int, n_out: int, filt: str = "lanczos"):
+    fn, support0 = _FILTERS[filt]
+    if n_in == n_out:       # Pillow skips the pass; an identity table makes clip8((v << 22 + 2^21) >> 22) == v
+        bounds = np.stack([np.arange(n_out, dtype=np.int32), np.ones(n_out, dtype=np.int32)], axis=1)
+        return bounds, np.full((n_out, 1), 1 << _PRECISION_BITS, dtype=np.int32), 1
     scale = n_in / n_out
     fscale = max(scale, 1.0)
-    support = 3.0 * fscale
+    support = support0 * fscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((n_out, 2), dtype=np.int32)
     kk = np.zeros((n_out, ksize), dtype=np.int32)
@@ -74,7 +91,7 @@ def _lanczos_tables_host(n_in: int, n_out: int):
         lo = max(int(center - support + 0.5), 0)
         hi = min(int(center + support + 0.5), n_in)
         cnt = hi - lo
-        w = [_lanczos3((i + lo - center + 0.5) * inv_fscale) for i in range(cnt)]
+        w = [fn((i + lo - center + 0.5) * inv_fscale) for i in range(cnt)]
         tot = 0.0
         for v in w:
             tot += v
@@ -86,11 +103,12 @@ def _lanczos_tables_host(n_in: int, n_out: int):
     return bounds, kk, ksize
 
 
-def lanczos_tables(n_in: int, n_out: int, device: torch.device):
-    key = ("lanczos", n_in, n_out, str(device))
+def lanczos_tables(n_in: int, n_out: int, device: torch.device, filt: str = "lanczos"):
+    """Pillow 8-bit coefficient tables on the device: (bounds int32 [n_out,2], kk int32 [n_out,ksize], ksize)."""
+    key = (filt, n_in, n_out, str(device))
     t = _DEV_CACHE.get(key)
     if t is None:
-        bounds, kk, ksize = _lanczos_tables_host(n_in, n_out)
+        bounds, kk, ksize = _lanczos_tables_host(n_in, n_out, filt)
         t = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
         _DEV_CACHE[key] = t
     return t

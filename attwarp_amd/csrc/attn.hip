@@ -303,6 +303,49 @@ __global__ __launch_bounds__(NT) void quantise_copy_kernel(const float* __restri
   if (i < n) out[i] = mf ? to_pil_u8(mf[i]) : mu[i];
 }
 
+// ---- "next" row 3: warped uint8 RGB image -> CLIP-ready tensor (HF CLIPImageProcessor, PIL backend) ----
+// horizontal pass of Pillow's 8-bit resampler on interleaved C-channel images, restricted to the output
+// columns [left, left+ow):  tmp[b][y][xx][c].   grid = (ceil(ow*C/NT), h, B)
+__global__ __launch_bounds__(NT) void resample8_h_kernel(const uint8_t* __restrict__ src, int h, int w, int C,
+                                                         int left, int ow, const int32_t* __restrict__ bounds,
+                                                         const int32_t* __restrict__ kk, int ksize,
+                                                         uint8_t* __restrict__ tmp) {
+  const int e = blockIdx.x * NT + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (e >= ow * C) return;
+  const int xx = e / C, c = e - xx * C;
+  const int xo = left + xx;
+  const int xmin = bounds[2 * xo], cnt = bounds[2 * xo + 1];
+  const int32_t* k = kk + (size_t)xo * ksize;
+  const uint8_t* row = src + ((size_t)b * h + y) * w * C + c;
+  int ss = 1 << (PIL_PRECISION_BITS - 1);
+  for (int x = 0; x < cnt; ++x) ss += (int)row[(size_t)(xmin + x) * C] * k[x];
+  tmp[((size_t)b * h + y) * ow * C + e] = pil_clip8(ss);
+}
+
+// vertical pass for the output rows [top, top+oh) fused with the CLIP epilogue:
+//   u8 -> float32(float64(u8) * (1/255)) -> (x - mean[c]) / std[c] in float32 -> planar [B,C,oh,ow] (f32 or f16)
+// grid = (ceil(ow/NT), oh, B)
+template <typename OutT>
+__global__ __launch_bounds__(NT) void clip_v_kernel(const uint8_t* __restrict__ tmp, int h, int C, int top, int oh,
+                                                    int ow, const int32_t* __restrict__ bounds,
+                                                    const int32_t* __restrict__ kk, int ksize, float m0, float m1,
+                                                    float m2, float m3, float s0, float s1, float s2, float s3,
+                                                    OutT* __restrict__ out) {
+  const int xx = blockIdx.x * NT + threadIdx.x, yy = blockIdx.y, b = blockIdx.z;
+  if (xx >= ow) return;
+  const int yo = top + yy;
+  const int ymin = bounds[2 * yo], cnt = bounds[2 * yo + 1];
+  const int32_t* k = kk + (size_t)yo * ksize;
+  const float mean[4] = {m0, m1, m2, m3}, stdv[4] = {s0, s1, s2, s3};
+  for (int c = 0; c < C; ++c) {
+    int ss = 1 << (PIL_PRECISION_BITS - 1);
+    for (int y = 0; y < cnt; ++y) ss += (int)tmp[(((size_t)b * h + ymin + y) * ow + xx) * C + c] * k[y];
+    const float x = (float)((double)pil_clip8(ss) * (1.0 / 255.0));
+    const float v = fsub(x, mean[c]) / stdv[c];
+    out[(((size_t)b * C + c) * oh + yy) * ow + xx] = from_f32<OutT>(v);
+  }
+}
+
 template <typename T>
 static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
                        const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
@@ -446,4 +489,33 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     return check_launch("lanczos_v_kernel");
   }
   return ATTWARP_OK;
+}
+
+extern "C" int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int w, int C, int top, int left, int size,
+                                          const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
+                                          const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
+                                          const float* mean, const float* stdv /* host, C floats each */,
+                                          uint8_t* tmp, void* out, int out_dtype, void* stream) {
+  ATTWARP_REQUIRE(src && bounds_x && kk_x && bounds_y && kk_y && mean && stdv && tmp && out,
+                  "clip_preprocess_u8: null pointer");
+  ATTWARP_REQUIRE(B > 0 && h > 0 && w > 0 && size > 0 && top >= 0 && left >= 0 && ksize_x > 0 && ksize_y > 0,
+                  "clip_preprocess_u8: bad size");
+  ATTWARP_REQUIRE(C >= 1 && C <= 4, "clip_preprocess_u8: C must be 1..4 (got %d)", C);
+  ATTWARP_REQUIRE(out_dtype == ATTWARP_F32 || out_dtype == ATTWARP_F16, "clip_preprocess_u8: out dtype must be F32 or F16");
+  if (B > 65535 || h > 65535 || size > 65535) return fail(ATTWARP_E_UNSUPPORTED, "clip_preprocess_u8: dims > 65535");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(resample8_h_kernel, dim3((size * C + NT - 1) / NT, h, B), dim3(NT), 0, st, src, h, w, C, left, size,
+                     bounds_x, kk_x, ksize_x, tmp);
+  int rc = check_launch("resample8_h_kernel");
+  if (rc) return rc;
+  float m[4] = {0, 0, 0, 0}, s[4] = {1, 1, 1, 1};
+  for (int c = 0; c < C; ++c) { m[c] = mean[c]; s[c] = stdv[c]; }
+  const dim3 grid((size + NT - 1) / NT, size, B);
+  if (out_dtype == ATTWARP_F32)
+    hipLaunchKernelGGL((clip_v_kernel<float>), grid, dim3(NT), 0, st, tmp, h, C, top, size, size, bounds_y, kk_y,
+                       ksize_y, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3], (float*)out);
+  else
+    hipLaunchKernelGGL((clip_v_kernel<__half>), grid, dim3(NT), 0, st, tmp, h, C, top, size, size, bounds_y, kk_y,
+                       ksize_y, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3], (__half*)out);
+  return check_launch("clip_v_kernel");
 }

@@ -133,6 +133,44 @@ def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500
     return nm.remap_hwc(images_u8, mx, my, mode)
 
 
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(images_u8: torch.Tensor, size: int = 336, dtype: torch.dtype = torch.float16,
+                    mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD) -> torch.Tensor:
+    """Warped uint8 RGB batch [B,H,W,3] -> CLIP-ready [B,3,size,size] on the GPU ("next" row 3).
+
+    Replaces the PNG round trip of the reference (``cv2.imwrite`` new_method.py:491 -> ``Image.open`` +
+    ``process_images`` evaluate_accuracy.py:157-158) with two launches.  Arithmetic = HF CLIPImageProcessor
+    (PIL backend) as LLaVA-1.5 configures it: PIL BICUBIC resize of the shorter edge to ``size``, center crop,
+    ``float32(float64(u8) * (1/255))``, ``(x - mean) / std`` in float32; ``dtype`` float32 or float16
+    (LLaVA casts to float16, functions.py:270-271).  Bit-identical to the processor for float32."""
+    import ctypes
+    dev = require_gpu(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
+        raise TypeError("clip_preprocess expects a uint8 [B,H,W,C] tensor")
+    if dtype not in (torch.float32, torch.float16):
+        raise TypeError("clip_preprocess: dtype must be float32 or float16")
+    x = images_u8.contiguous()
+    B, H, W, C = x.shape
+    short, long_ = (H, W) if H <= W else (W, H)
+    new_long = int(size * long_ / short)
+    nh, nw = (size, new_long) if H <= W else (new_long, size)
+    top, left = (nh - size) // 2, (nw - size) // 2
+    bx, kx, ksx = _tables.lanczos_tables(W, nw, dev, "bicubic")
+    by, ky, ksy = _tables.lanczos_tables(H, nh, dev, "bicubic")
+    tmp = torch.empty(B, H, size, C, device=dev, dtype=torch.uint8)
+    out = torch.empty(B, C, size, size, device=dev, dtype=dtype)
+    m = (ctypes.c_float * C)(*[float(v) for v in mean[:C]])
+    s = (ctypes.c_float * C)(*[float(v) for v in std[:C]])
+    with torch.cuda.device(dev):
+        call("attwarp_clip_preprocess_u8", ptr(x), B, H, W, C, top, left, size, ptr(bx), ptr(kx), ksx, ptr(by), ptr(ky),
+             ksy, ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), ptr(tmp), ptr(out),
+             _lib.F32 if dtype == torch.float32 else _lib.F16, stream_ptr(dev))
+    return out
+
+
 def capture_step(fn, *args, warmup: int = 2):
     """Capture ``fn(*args)`` (a function made only of this package's launches on static tensors) into a
     HIP graph; returns (graph, output).  ``graph.replay()`` re-runs the step with one host call."""

@@ -96,6 +96,19 @@ ATTWARP_API int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8
                                   const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
                                   uint8_t* tmp, uint8_t* out, void* stream);
 
+/* ---- "next" row 3: warped uint8 image -> CLIP-ready tensor, replacing the PNG round trip
+ * AGW/new_method.py:491 (cv2.imwrite) -> AGW/evaluate_accuracy.py:157-158 (Image.open, process_images):
+ * HF CLIPImageProcessor as LLaVA-1.5 configures it = PIL BICUBIC resize (shorter edge -> size), center crop,
+ * float32(float64(u8)*(1/255)), (x-mean)/std in float32, channels first.
+ * src [B,h,w,C] uint8 (C<=4) -> out [B,C,size,size] (F32 or F16).  The caller passes Pillow's 8-bit coefficient
+ * tables for the resized width / height (identity tables when an axis keeps its size) and the crop origin
+ * (top,left) in the resized image; mean/stdv are HOST arrays of C floats; tmp: uint8 [B,h,size,C]. */
+ATTWARP_API int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int w, int C, int top, int left, int size,
+                               const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
+                               const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
+                               const float* mean, const float* stdv, uint8_t* tmp, void* out, int out_dtype,
+                               void* stream);
+
 /* ---- A5: F.adaptive_avg_pool2d(A,(oh,ow)), call sites MN/trainer.py:197,433,465
  * A [B,H,W] float32 -> out [B,oh,ow] float32 (oh,ow <= 64). */
 ATTWARP_API int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, float* out, void* stream);

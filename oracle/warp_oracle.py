@@ -183,15 +183,30 @@ def _lanczos(x: float) -> float:
     return 0.0
 
 
-def pil_lanczos_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
-    """Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` for the
-    LANCZOS filter (support 3) over the full box ``[0, in_size)``.
+def _bicubic(x: float) -> float:
+    """Pillow's bicubic_filter (a = -0.5), support 2."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+_PIL_FILTERS = {"lanczos": (_lanczos, 3.0), "bicubic": (_bicubic, 2.0)}
+
+
+def pil_resample_coeffs(in_size: int, out_size: int, filt: str = "lanczos") -> Tuple[np.ndarray, np.ndarray, int]:
+    """Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (src/libImaging/Resample.c) over the full
+    box ``[0, in_size)`` for the LANCZOS (support 3) or BICUBIC (support 2) filter.
 
     Returns (bounds[out, 2] = (xmin, count), kk[out, ksize] int32, ksize).
-    Pillow is the third-party dependency behind ``invtrans`` (llava.py:195-196);
-    version used for the goldens: Pillow 12.2.0.
+    Pillow is the third-party dependency behind ``invtrans`` (llava.py:195-196) and behind the CLIP
+    image processor's resize; version used for the goldens: Pillow 12.2.0.
     """
-    support0 = 3.0
+    fn, support0 = _PIL_FILTERS[filt]
     scale = float(in_size) / float(out_size)
     filterscale = max(scale, 1.0)
     support = support0 * filterscale
@@ -208,7 +223,7 @@ def pil_lanczos_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndar
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        w = [_lanczos((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        w = [fn((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for v in w:
             ww += v
@@ -224,10 +239,14 @@ def pil_lanczos_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndar
     return bounds, kk, ksize
 
 
-def _pil_resample_axis_u8(src: np.ndarray, out_size: int) -> np.ndarray:
+def pil_lanczos_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    return pil_resample_coeffs(in_size, out_size, "lanczos")
+
+
+def _pil_resample_axis_u8(src: np.ndarray, out_size: int, filt: str = "lanczos") -> np.ndarray:
     """One 8-bit pass of Pillow's separable resampler along the LAST axis."""
     in_size = src.shape[-1]
-    bounds, kk, ksize = pil_lanczos_coeffs(in_size, out_size)
+    bounds, kk, ksize = pil_resample_coeffs(in_size, out_size, filt)
     out = np.empty(src.shape[:-1] + (out_size,), dtype=np.uint8)
     s = src.astype(np.int64)
     for xx in range(out_size):
@@ -239,21 +258,58 @@ def _pil_resample_axis_u8(src: np.ndarray, out_size: int) -> np.ndarray:
     return out
 
 
-def lanczos_resize_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
-    """``PIL.Image.resize((out_w, out_h), LANCZOS)`` for a mode-"L" image.
+def pil_resize_u8(img: np.ndarray, out_w: int, out_h: int, filt: str = "lanczos") -> np.ndarray:
+    """``PIL.Image.resize((out_w, out_h), <filter>)`` for an 8-bit image, mode "L" ([H,W]) or
+    multi-band ([H,W,C]; Pillow resamples every band with the same integer arithmetic).
 
-    Two passes, horizontal first then vertical, uint8 intermediate
-    (Pillow ``ImagingResampleInner``).  A pass is skipped when that axis keeps
-    its size; same size both ways returns a copy.  img: [H, W] uint8.
-    """
+    Two passes, horizontal first then vertical, uint8 intermediate (``ImagingResampleInner``).
+    A pass is skipped when that axis keeps its size."""
     img = np.asarray(img, dtype=np.uint8)
-    h, w = img.shape
-    cur = img
+    squeeze = img.ndim == 2
+    cur = img[:, :, None] if squeeze else img
+    h, w, _ = cur.shape
     if out_w != w:
-        cur = _pil_resample_axis_u8(cur, out_w)
+        cur = _pil_resample_axis_u8(cur.transpose(0, 2, 1), out_w, filt).transpose(0, 2, 1)
     if out_h != h:
-        cur = _pil_resample_axis_u8(cur.T, out_h).T
-    return np.ascontiguousarray(cur)
+        cur = _pil_resample_axis_u8(cur.transpose(1, 2, 0), out_h, filt).transpose(2, 0, 1)
+    cur = np.ascontiguousarray(cur)
+    return cur[:, :, 0] if squeeze else cur
+
+
+def lanczos_resize_u8(img: np.ndarray, out_w: int, out_h: int) -> np.ndarray:
+    """``PIL.Image.resize((out_w, out_h), LANCZOS)`` for a mode-"L" image (A4, llava.py:195-196,253)."""
+    return pil_resize_u8(img, out_w, out_h, "lanczos")
+
+
+# ---------------------------------------------------------------------------
+# "next" row 3: warped uint8 image -> CLIP-ready tensor (what LLaVA-1.5 feeds its vision tower)
+# ---------------------------------------------------------------------------
+
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess(img_rgb_u8: np.ndarray, size: int = 336) -> np.ndarray:
+    """HF ``CLIPImageProcessor`` (PIL backend) as LLaVA-1.5 configures it, for an RGB uint8 image [H,W,3]:
+    resize so that the SHORTER edge is ``size`` (PIL BICUBIC, long edge int(size*long/short)), center crop
+    ``size`` x ``size``, rescale ``float32(float64(u8) * (1/255))``, normalize ``(x - mean32) / std32`` in
+    float32, channels first.  Returns float32 [3,size,size] (LLaVA casts to float16 afterwards:
+    AGW/attention_extraction/functions.py:270-271; the evaluation path re-reads the warped PNG,
+    AGW/evaluate_accuracy.py:157-158).  Pinned to transformers 5.15's PIL backend + Pillow 12.2.0 goldens
+    (the reference pins transformers 4.37.2, whose slow processor does the same arithmetic)."""
+    img = np.asarray(img_rgb_u8, dtype=np.uint8)
+    h, w, c = img.shape
+    short, long_ = (h, w) if h <= w else (w, h)
+    new_short, new_long = size, int(size * long_ / short)
+    nh, nw = (new_short, new_long) if h <= w else (new_long, new_short)
+    r = pil_resize_u8(img, nw, nh, "bicubic")
+    top, left = (nh - size) // 2, (nw - size) // 2
+    r = r[top:top + size, left:left + size]
+    x = (r.astype(F64) * (1 / 255)).astype(F32)
+    mean = np.array(OPENAI_CLIP_MEAN, dtype=F32)
+    std = np.array(OPENAI_CLIP_STD, dtype=F32)
+    x = ((x - mean).astype(F32) / std).astype(F32)
+    return np.ascontiguousarray(x.transpose(2, 0, 1))
 
 
 # ---------------------------------------------------------------------------

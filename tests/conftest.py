@@ -29,3 +29,23 @@ def pool_input(S: int) -> np.ndarray:
     A = rng.random((2, 1, S, S), dtype=np.float32)
     A[0, 0, S // 3: S // 3 + S // 8, S // 2: S // 2 + S // 8] += np.float32(5.0)
     return A
+
+
+def clip_input(name: str) -> np.ndarray:
+    """Same recipe as tests/golden/make_golden.py::clip_input."""
+    hh, ww = {"sq500": (500, 500), "sq336": (336, 336), "land": (375, 500), "small": (64, 48)}[name]
+    rng = np.random.default_rng(1800 + hh + ww)
+    im = rng.integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+    if name == "sq500":
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        im[..., 0] = (127 + 120 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.uint8)
+    return im
+
+
+def clip_digest(out: np.ndarray) -> dict:
+    """Same digest as tests/golden/make_golden.py::clip_digest."""
+    out = np.ascontiguousarray(out, dtype=np.float32)
+    bits = out.view(np.uint32).astype(np.uint64)
+    pos = (np.arange(out.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+    return {"sub": out[:, ::7, ::5].copy(), "sum_bits": np.array(bits.sum(dtype=np.uint64)),
+            "wsum_bits": np.array((bits.ravel() * pos).sum(dtype=np.uint64))}

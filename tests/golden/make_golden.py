@@ -112,7 +112,48 @@ def _load(name, path):
     return mod
 
 
+def clip_input(name: str) -> np.ndarray:
+    """Deterministic RGB uint8 inputs for the CLIP-preprocess goldens (recipe duplicated in tests/conftest.py)."""
+    hh, ww = {"sq500": (500, 500), "sq336": (336, 336), "land": (375, 500), "small": (64, 48)}[name]
+    rng = np.random.default_rng(1800 + hh + ww)
+    im = rng.integers(0, 256, (hh, ww, 3), dtype=np.uint8)
+    if name == "sq500":       # smooth content as well as noise
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        im[..., 0] = (127 + 120 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.uint8)
+    return im
+
+
+def clip_digest(out: np.ndarray) -> dict:
+    """Small stand-in for a 1.35 MB float32 output: a strided sub-grid (exact values) + order-free checksums
+    of ALL values (the float32 bit patterns summed as integers, plain and position-weighted)."""
+    bits = out.view(np.uint32).astype(np.uint64)
+    pos = (np.arange(out.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
+    return {"sub": out[:, ::7, ::5].copy(), "sum_bits": np.array(bits.sum(dtype=np.uint64)),
+            "wsum_bits": np.array((bits.ravel() * pos).sum(dtype=np.uint64))}
+
+
+def make_clip_goldens():
+    """"next" row 3: warped image -> CLIP tensor.  Third-party code only (run BEFORE the stubs are installed):
+    Pillow BICUBIC + the HF CLIP image processor (PIL backend) configured like LLaVA-1.5's."""
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    import transformers
+    clip = {}
+    proc = CLIPImageProcessorPil(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336})
+    for name in ("sq500", "sq336", "land", "small"):
+        out = proc.preprocess([clip_input(name)], return_tensors="np")["pixel_values"][0]
+        for k, v in clip_digest(out).items():
+            clip[f"{name}_{k}"] = v
+    rng = np.random.default_rng(18)
+    bic = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    clip["bic_img"] = bic
+    for (w, h) in [(30, 20), (100, 90), (56, 17)]:
+        clip[f"bic_{w}x{h}"] = np.array(Image.fromarray(bic).resize((w, h), Image.BICUBIC))
+    clip["versions"] = np.array([Image.__version__, transformers.__version__])
+    np.savez_compressed(os.path.join(OUT, "clip_preprocess.npz"), **clip)
+
+
 def main():
+    make_clip_goldens()
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(1)

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import warp_oracle as O
-from conftest import pool_input
+from conftest import pool_input, clip_input, clip_digest
 
 pytestmark = pytest.mark.gpu
 
@@ -743,3 +743,35 @@ def test_shard_equivalence(dev, world):
             parts.append(pipeline.warp_from_attention_stack(img[lo:hi].contiguous(), rows[:, lo:hi].contiguous(),
                                                             starts[lo:hi].contiguous(), channels_last=True))
     assert torch.equal(torch.cat(parts), full)
+
+
+@pytest.mark.parametrize("name", ["sq500", "sq336", "land", "small"])
+def test_clip_preprocess_bit_exact(dev, golden, name):
+    """"next" row 3: warped uint8 image -> CLIP tensor on the GPU == HF CLIPImageProcessor (PIL backend)."""
+    from attwarp_amd import pipeline
+    g = golden("clip_preprocess")
+    img = clip_input(name)
+    out = pipeline.clip_preprocess(T(np.stack([img, img[::-1].copy()]), dev), 336, torch.float32)
+    assert out.shape == (2, 3, 336, 336)
+    got = N(out)
+    assert np.array_equal(got[0], O.clip_preprocess(img, 336))
+    assert np.array_equal(got[1], O.clip_preprocess(img[::-1].copy(), 336))
+    d = clip_digest(got[0])
+    assert np.array_equal(d["sub"], g[f"{name}_sub"])
+    assert int(d["sum_bits"]) == int(g[f"{name}_sum_bits"]) and int(d["wsum_bits"]) == int(g[f"{name}_wsum_bits"])
+    half = pipeline.clip_preprocess(T(img[None], dev), 336)                # LLaVA feeds float16
+    assert half.dtype == torch.float16
+    assert np.array_equal(N(half[0]), got[0].astype(np.float16))
+
+
+def test_warp_to_clip_pipeline(dev, golden):
+    """main_batched chain + CLIP epilogue with nothing leaving the GPU: masks -> 500x500 uint8 warp -> [B,3,336,336]."""
+    from attwarp_amd import pipeline
+    g = golden("mask_postproc")
+    rng = np.random.default_rng(93)
+    imgs = rng.integers(0, 256, (4, 336, 336, 3), dtype=np.uint8)
+    warped = pipeline.warp_from_masks(T(imgs, dev), T(g["masks"], dev), (500, 500))
+    clip = pipeline.clip_preprocess(warped, 336, torch.float32)
+    w = N(warped)
+    for b in range(4):
+        assert np.array_equal(N(clip[b]), O.clip_preprocess(w[b], 336))

@@ -133,6 +133,16 @@ def test_lanczos_tables_match_oracle(io):
     assert ks == kso and np.array_equal(b, bo) and np.array_equal(k, ko)
 
 
+@pytest.mark.parametrize("io", [(500, 336), (375, 336), (64, 448), (40, 17)])
+def test_bicubic_tables_match_oracle(io):
+    from attwarp_amd import _tables
+    b, k, ks = _tables._lanczos_tables_host(io[0], io[1], "bicubic")
+    bo, ko, kso = O.pil_resample_coeffs(io[0], io[1], "bicubic")
+    assert ks == kso and np.array_equal(b, bo) and np.array_equal(k, ko)
+    bi, ki, ksi = _tables._lanczos_tables_host(336, 336, "bicubic")          # identity pass
+    assert ksi == 1 and np.all(ki == 1 << 22) and np.array_equal(bi[:, 0], np.arange(336))
+
+
 def test_marginalnet_logits_match_reference_golden(golden):
     """MarginalNet on stock torch ops with the reference's parameter names: load the seeded
     reference state_dict, compare softmax(logits) with the captured (px, py)."""

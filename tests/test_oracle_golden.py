@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import warp_oracle as O
-from conftest import pool_input
+from conftest import pool_input, clip_input, clip_digest
 
 
 def ulps(a, b):
@@ -296,3 +296,22 @@ def test_numpy_pairwise_restatement():
     for i in range(9):
         seq = seq + x2[i]
     assert np.array_equal(seq, np.sum(x2, axis=0))          # axis=0: plain ascending-row accumulation
+
+
+# ---- "next" row 3: warped image -> CLIP tensor --------------------------------
+def test_pil_bicubic_bit_exact_vs_pillow(golden):
+    g = golden("clip_preprocess")
+    for (w, h) in [(30, 20), (100, 90), (56, 17)]:
+        assert np.array_equal(O.pil_resize_u8(g["bic_img"], w, h, "bicubic"), g[f"bic_{w}x{h}"])
+
+
+@pytest.mark.parametrize("name", ["sq500", "sq336", "land", "small"])
+def test_clip_preprocess_vs_hf_processor(golden, name):
+    """Bit-for-bit against the HF CLIPImageProcessor (PIL backend): exact values on a sub-grid + checksums of
+    every float32 bit pattern (the full 1.35 MB outputs are not stored)."""
+    g = golden("clip_preprocess")
+    out = O.clip_preprocess(clip_input(name), 336)
+    assert out.shape == (3, 336, 336) and out.dtype == np.float32
+    d = clip_digest(out)
+    assert np.array_equal(d["sub"], g[f"{name}_sub"])
+    assert int(d["sum_bits"]) == int(g[f"{name}_sum_bits"]) and int(d["wsum_bits"]) == int(g[f"{name}_wsum_bits"])

@@ -40,5 +40,7 @@ for (B, S) in [(256, 1024), (64, 336)]:
     mx, my = pipeline.axis_maps_from_pdf(px, px, (S, S), (500, 500))
     rep(f"remap u8 HWC {S}->500 (gather) B={B}", timeit(lambda: nm.remap_hwc(img8, mx, my)), B*(S*S*3 + 500*500*3))
     if S == 336:
+        w500 = (torch.rand(B, 500, 500, 3, device=dev) * 255).to(torch.uint8)
+        rep(f"clip_preprocess 500->336 u8 -> f16 [B,3,336,336] B={B}", timeit(lambda: pipeline.clip_preprocess(w500)), B*(500*500*3 + 3*336*336*2))
         rep(f"pipeline.warp_from_masks (main_batched chain) B={B}", timeit(lambda: pipeline.warp_from_masks(img8, m24)), B*(S*S*3 + 500*500*3))
     del A, a3, au8, rows, r16, img8
