@@ -133,6 +133,17 @@ def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500
     return nm.remap_hwc(images_u8, mx, my, mode)
 
 
+@torch.no_grad()
+def warp_from_marginalnet(net, fmap_v: torch.Tensor, txt_tok: torch.Tensor, txt_mask: torch.Tensor,
+                          images: torch.Tensor, out_size=None, channels_last=False, mode: str = "exact"):
+    """BASELINE config 5's device-resident chain: MarginalNet(hidden=256) forward (stock PyTorch-ROCm ops +
+    the HIP safe_softmax) -> px, py over the 24 x 24 grid -> A8+A9+A11 (one launch) -> A12 warp.
+    Mirrors the inference block of the reference trainer (MN/trainer.py:210, :285-289).
+    Returns (warped images, px, py)."""
+    px, py = net(fmap_v, GRID, GRID, txt_tok, txt_mask)
+    return warp_from_pdf(images, px, py, out_size, channels_last, mode), px, py
+
+
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 

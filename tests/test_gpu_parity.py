@@ -775,3 +775,21 @@ def test_warp_to_clip_pipeline(dev, golden):
     w = N(warped)
     for b in range(4):
         assert np.array_equal(N(clip[b]), O.clip_preprocess(w[b], 336))
+
+
+def test_marginalnet_to_warp_chain(dev, golden):
+    """Config-5 chain at toy size: seeded reference weights -> MarginalNet on the GPU -> maps -> warp.
+    The network runs on library convolutions (tolerance on px, py); given ITS px, py the rest is bit-exact."""
+    from attwarp_amd import model, pipeline
+    g = golden("marginalnet")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd|")}
+    net = model.MarginalNet(32, 48, hidden=16).eval()
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    rng = np.random.default_rng(95)
+    img = rng.random((2, 3, 96, 128), dtype=np.float32)
+    out, px, py = pipeline.warp_from_marginalnet(net, T(g["fmap"], dev), T(g["ttok"], dev), T(g["tmask"], dev), T(img, dev))
+    np.testing.assert_allclose(N(px), g["px"], rtol=1e-4, atol=1e-6)
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(px), 128), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(py), 96), 0))
+    assert np.array_equal(N(out), O.warp_from_cdf(img, Fx, Fy))
