@@ -12,13 +12,13 @@
 // every operation individually rounded to float32 (no FMA); uint8 sources are
 // converted to float32, interpolated the same way and rounded half-to-even.
 //
-// Kernels in this file
-//   remap_rows_kernel   - the HBM-roofline path (float32): one workgroup streams a block
+// Kernels of the resample stage
+//   remap_rows_kernel (remap_rows.hip) - the HBM-roofline path (float32): one workgroup streams a block
 //                         of consecutive output rows; source rows are read once with 16-byte
 //                         coalesced loads, blended vertically in registers, staged in LDS and
 //                         gathered horizontally from LDS.  See DESIGN.md "K7".
 //   remap_rows_u8_kernel (remap_u8.hip) - the uint8 counterpart (main_batched chain).
-//   remap_gather_kernel - generic fallback (any size / dtype / mode): one thread per output
+//   remap_gather_kernel (this file) - generic fallback (any size / dtype / mode): one thread per output
 //                         element, four global taps served by L1/L2.
 #include "common.hpp"
 
