@@ -90,6 +90,8 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // cache logic is correct for arbitrary (also non-monotone) maps; monotone maps simply never miss.
 // AFF: output offsets are tid*4 + a block-uniform term per k (OVL == KO*256 exactly; for planar images also
 // Wo % 256 == 0 so that a k-slice never straddles two planes): no per-element offset table in VGPRs.
+// (forcing >= 4 waves per SIMD on the planar variants, which allocate 130-138 VGPRs, was measured: the
+//  register-limited code is 4-8 % slower than running them at 3 workgroups per CU)
 template <int NT, int KI, int KO, bool HWC, bool AFF>
 __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];

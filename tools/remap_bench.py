@@ -42,12 +42,10 @@ def run(env, *args):
         else: os.environ[k] = v
 
 if __name__ == "__main__":
-    for rep in range(2):
-        run({"ATTWARP_REMAP_VARIANT": "r"}, 256, 1024, "hwc", "uniform")
-        run({"ATTWARP_REMAP_VARIANT": "o", "ATTWARP_REMAP_NTMEM": "1"}, 256, 1024, "hwc", "uniform")
-        run({"ATTWARP_REMAP_VARIANT": "o", "ATTWARP_REMAP_NTMEM": "0"}, 256, 1024, "hwc", "uniform")
-    for var in ("r", "o"):
-        run({"ATTWARP_REMAP_VARIANT": var}, 256, 1024, "hwc", "peaked")
-        run({"ATTWARP_REMAP_VARIANT": var}, 256, 1024, "chw", "uniform")
-        run({"ATTWARP_REMAP_VARIANT": var}, 256, 336, "hwc", "uniform", 50)
-        run({"ATTWARP_REMAP_VARIANT": var}, 64, 336, "hwc", "uniform", 50)
+    for layout in ("hwc", "chw"):
+        for kind in ("uniform", "peaked"):
+            bench(256, 1024, layout, kind)
+    bench(64, 336, "hwc", "uniform", 50)
+    bench(256, 336, "hwc", "uniform", 50)
+    bench(256, 336, "chw", "uniform", 50)
+    run({"ATTWARP_REMAP_VARIANT": "g"}, 256, 1024, "hwc", "uniform")
