@@ -793,3 +793,29 @@ def test_marginalnet_to_warp_chain(dev, golden):
     Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(px), 128), 0))
     Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(py), 96), 0))
     assert np.array_equal(N(out), O.warp_from_cdf(img, Fx, Fy))
+
+
+def test_remap_fuzz_shapes(dev):
+    """Seeded random shapes / channel counts / layouts / dtypes / map kinds through every dispatch path
+    (float rows kernel, uint8 rows kernel, gather fallback for unaligned shapes): bit-exact vs the oracle."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        H, W = int(rng.integers(24, 160)), int(rng.integers(24, 200))
+        Ho, Wo = int(rng.integers(1, 180)), int(rng.integers(1, 220))
+        C = int(rng.integers(1, 5))
+        if case % 3 == 0:                     # aligned shapes so the fast kernels are exercised, not only the fallback
+            W, Wo = (W // 4) * 4 + 4, (Wo // 4) * 4 + 4
+        B = int(rng.integers(1, 4))
+        kind = ("cdf", "wild", "identity")[case % 3]
+        mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+        dt = (np.float32, np.uint8)[case % 2]
+        img = rng.random((B, H, W, C), dtype=np.float32)
+        if dt == np.uint8:
+            img = (img * 255).astype(np.uint8)
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+        hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
+        chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev)))
+        tag = (case, H, W, Ho, Wo, C, kind, dt.__name__)
+        assert np.array_equal(hwc, ref), tag
+        assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), tag

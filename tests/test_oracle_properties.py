@@ -1,0 +1,92 @@
+"""Property tests of the CPU oracle (hypothesis): the invariants the reference's docstrings promise and the
+ones the HIP kernels rely on (monotone maps, CDF shape, right-inverse consistency).  CPU only."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import warp_oracle as O
+
+SET = dict(max_examples=40, deadline=None)
+
+
+@settings(**SET)
+@given(L=st.integers(24, 700), seed=st.integers(0, 2**31 - 1), peak=st.floats(0.1, 6.0))
+def test_right_inverse_pools_back_to_input(L, seed, peak):
+    """adaptive_avg_pool1d(x_hat, 24) == y (MN/checkpoint_utils.py:70-72)."""
+    rng = np.random.default_rng(seed)
+    z = rng.standard_normal((2, 24)) * peak
+    y = (np.exp(z) / np.exp(z).sum(1, keepdims=True)).astype(np.float32)
+    x = O.upsample_pdf_right_inverse(y, L)
+    A = O.pooling_matrix(24, L, np.float64)
+    np.testing.assert_allclose(x.astype(np.float64) @ A.T, y, rtol=0, atol=5e-6)
+    # mass is preserved up to rounding: sum(x) = sum over windows... (each x is a window average spread)
+    assert x.shape == (2, L) and np.isfinite(x).all()
+
+
+@settings(**SET)
+@given(L=st.integers(2, 600), seed=st.integers(0, 2**31 - 1), zero_frac=st.floats(0.0, 0.9))
+def test_cdf_shape_and_map_monotone(L, seed, zero_frac):
+    rng = np.random.default_rng(seed)
+    p = rng.random((3, L)).astype(np.float32)
+    p[rng.random((3, L)) < zero_frac] = 0.0
+    F = O.cdf_from_density(p)
+    assert F.dtype == np.float32 and (F[:, -1] == 1.0).all()
+    assert (np.diff(F, axis=1) >= 0).all() and (F >= 0).all() and (F <= 1.0 + 1e-6).all()
+    n_out = int(rng.integers(1, 700))
+    m = np.stack([O.axis_map_from_cdf(F[b], n_out) for b in range(3)])
+    assert (np.diff(m, axis=1) >= 0).all()                      # non-decreasing: what remap_rows_kernel exploits
+    assert (m >= 0).all() and (m <= L).all()
+    assert np.all(m[:, 0] >= 0)
+
+
+@settings(**SET)
+@given(h=st.integers(1, 40), w=st.integers(1, 40), nw=st.integers(1, 80), nh=st.integers(1, 80),
+       seed=st.integers(0, 2**31 - 1), tr=st.sampled_from(["identity", "square", "sqrt"]))
+def test_attention_maps_monotone_and_in_range(h, w, nw, nh, seed, tr):
+    rng = np.random.default_rng(seed)
+    att = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    mx, my = O.maps_from_attention(att, nw, nh, tr)
+    assert mx.shape == (nw,) and my.shape == (nh,)
+    assert (np.diff(mx) >= 0).all() and (np.diff(my) >= 0).all()
+    assert mx[0] == 0 and my[0] == 0 and mx.max() <= w and my.max() <= h
+
+
+@settings(**SET)
+@given(h=st.integers(2, 24), w=st.integers(2, 24), c=st.integers(1, 4), seed=st.integers(0, 2**31 - 1))
+def test_remap_convexity_and_constant(h, w, c, seed):
+    """Bilinear resampling is a convex combination: outputs stay within the input range; a constant image
+    stays constant for ANY maps (also out-of-range and unsorted ones)."""
+    rng = np.random.default_rng(seed)
+    img = rng.random((h, w, c), dtype=np.float32)
+    mx = (rng.random(17) * (w + 4) - 2).astype(np.float32)
+    my = (rng.random(13) * (h + 4) - 2).astype(np.float32)
+    for mode in ("exact", "cv2"):
+        out = O.remap_bilinear(img, mx, my, mode)
+        assert out.shape == (13, 17, c)
+        assert out.min() >= img.min() - 1e-6 and out.max() <= img.max() + 1e-6
+        const = np.full_like(img, 0.3125)
+        assert np.array_equal(O.remap_bilinear(const, mx, my, mode), np.full((13, 17, c), 0.3125, np.float32))
+    u8 = (img * 255).astype(np.uint8)
+    o8 = O.remap_bilinear(u8, mx, my)
+    assert o8.dtype == np.uint8 and o8.min() >= u8.min() and o8.max() <= u8.max()
+
+
+@settings(**SET)
+@given(n=st.integers(1, 2000), seed=st.integers(0, 2**31 - 1))
+def test_lanczos_identity_and_range(n, seed):
+    """Pillow resample: same size is a copy; up-sampling a constant image keeps the constant."""
+    rng = np.random.default_rng(seed)
+    v = int(rng.integers(0, 256))
+    img = np.full((24, 24), v, np.uint8)
+    size = int(rng.integers(24, 200))
+    assert (O.lanczos_resize_u8(img, size, size) == v).all()
+    r = rng.integers(0, 256, (24, 24), dtype=np.uint8)
+    assert np.array_equal(O.lanczos_resize_u8(r, 24, 24), r)
+
+
+def test_attn_reduce_rows_sum_to_one():
+    rng = np.random.default_rng(0)
+    lg = rng.standard_normal((3, 2, 8, 640)).astype(np.float32)
+    e = np.exp(lg - lg.max(-1, keepdims=True)); rows = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    m = O.attn_reduce_stack(rows, [30, 50])
+    np.testing.assert_allclose(m.sum(1), 1.0, atol=2e-6)       # every head renormalised over the image tokens
