@@ -35,6 +35,10 @@ SIGNATURES = {
     "attwarp_attn_reduce_stack_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "attwarp_attn_reduce_stack": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                            c_void_p, c_void_p]),
+    "attwarp_attn_probe_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "attwarp_attn_probe_last_query": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
+                                               c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_float,
+                                               c_void_p, c_void_p, c_void_p]),
     "attwarp_mask_postproc": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "attwarp_mask_upsample_lanczos": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

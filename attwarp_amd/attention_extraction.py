@@ -57,6 +57,46 @@ def attn_reduce_stack(rows: torch.Tensor, starts: torch.Tensor, ntok: int = NUM_
     return out
 
 
+def probe_last_query(query: torch.Tensor, key: torch.Tensor, starts: torch.Tensor, ntok: int = NUM_IMAGE_TOKENS,
+                     kv_begin: Optional[torch.Tensor] = None, scaling: Optional[float] = None) -> torch.Tensor:
+    """Hook-side capture: one generation step's [B,ntok] map computed from the post-RoPE
+    query of the LAST token and the key cache, instead of from materialised [B,heads,q,kv] probabilities.
+
+    query [B,heads,q,D] (or [B,heads,D]); key [B,kv_heads,kv,D]; starts int32 [B] on the device;
+    kv_begin int32 [B] = number of left-padding keys per sample (None: none); scaling defaults to D**-0.5.
+    Equals ``attn_reduce_step`` applied to HF's eager attention weights (same dtype transitions)."""
+    dev = require_gpu(query, key, starts)
+    q = query[:, :, -1] if query.dim() == 4 else query
+    B, heads, D = q.shape
+    if key.dim() != 4 or key.shape[0] != B or key.shape[3] != D:
+        raise ValueError(f"key must be [B,kv_heads,kv,D] matching query {tuple(query.shape)}; got {tuple(key.shape)}")
+    if key.dtype != q.dtype:
+        raise ValueError(f"query/key dtype mismatch: {q.dtype} vs {key.dtype}")
+    kv_heads, kv = key.shape[1], key.shape[2]
+    per = 16 // q.element_size()
+
+    def ok(t):   # 16-byte loads: unit stride on D, every other stride and the base a multiple of 16 bytes
+        return t.stride(-1) == 1 and all(st % per == 0 for st in t.stride()[:-1]) and t.data_ptr() % 16 == 0
+
+    if not ok(q):
+        q = q.contiguous()
+    k = key if ok(key) else key.contiguous()
+    lib = _lib.load()
+    dt = _lib.dtype_id(q)
+    ws = torch.empty(lib.attwarp_attn_probe_workspace_bytes(dt, B, heads, int(ntok)), device=dev, dtype=torch.uint8)
+    out = torch.empty(B, int(ntok), device=dev, dtype=q.dtype)
+    kb = None
+    if kv_begin is not None:
+        require_gpu(kv_begin)
+        kb = kv_begin.to(torch.int32).contiguous()
+    st = starts.to(torch.int32).contiguous()
+    with torch.cuda.device(dev):
+        call("attwarp_attn_probe_last_query", ptr(q), ptr(k), dt, B, heads, kv_heads, D, kv, q.stride(0), q.stride(1),
+             k.stride(0), k.stride(1), k.stride(2), ptr(kb) if kb is not None else None, ptr(st), int(ntok),
+             float(D ** -0.5 if scaling is None else scaling), ptr(out), ptr(ws), stream_ptr(dev))
+    return out
+
+
 class BatchMaskHookLogger(object):
     """Same interface as the reference class (:338-448): per-sample image-token ranges, a forward
     hook on one decoder layer's attention, ``finalize_batch() -> List[Tensor[24,24]]``."""
@@ -133,6 +173,57 @@ class BatchMaskHookLogger(object):
 
         layer_attn.forward = forced
 
+    # ---- capture without output_attentions ------------------------------------------
+    @torch.no_grad()
+    def _probe_attention(self, query: torch.Tensor, key: torch.Tensor, attention_mask, scaling=None):
+        """Same bookkeeping as ``_process_attention``, fed with the target layer's post-RoPE query/key."""
+        bsz, kv = key.shape[0], key.shape[2]
+        lens = {min(self.image_token_ends[b], kv) - self.image_token_starts[b] for b in range(bsz)}
+        if len(lens) != 1:
+            raise RuntimeError(f"stack expects each tensor to be equal size, got image-token slice lengths {sorted(lens)}")
+        ntok = lens.pop()
+        if self._starts_dev is None or self._starts_dev.device != key.device:
+            self._starts_dev = torch.tensor(self.image_token_starts, dtype=torch.int32, device=key.device)
+        kv_begin = None
+        if isinstance(attention_mask, torch.Tensor) and attention_mask.dim() == 4:
+            row = attention_mask[:, 0, -1, :kv]                   # what the last query may attend to
+            valid = row if row.dtype == torch.bool else row > torch.finfo(row.dtype).min / 2
+            kv_begin = valid.to(torch.int32).argmax(dim=-1).to(torch.int32)   # first attended key = left padding
+        self.step_attentions.append(probe_last_query(query, key, self._starts_dev[:bsz], ntok, kv_begin, scaling))
+
+    def register_probe(self):
+        """Alternative to ``register_hook_and_patch``: leave the target layer on its fast attention kernel and
+        compute the one attention row the hook needs from (query, key) with ``probe_last_query``.  Uses
+        transformers' ``AttentionInterface`` (>= 4.48): the target layer alone gets a private config whose
+        attention implementation is a wrapper that probes and then delegates to the model's own."""
+        import copy
+        import sys
+        try:
+            from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS, AttentionInterface
+        except ImportError as e:   # fail loudly: there is no silent fallback to the eager path
+            raise RuntimeError("register_probe needs transformers' AttentionInterface (>= 4.48); "
+                               "use register_hook_and_patch with this transformers version") from e
+        self.remove_hook_and_unpatch()
+        layer_attn = self.model.model.layers[self.layer_index].self_attn
+        base = layer_attn.config._attn_implementation
+        eager = getattr(sys.modules[type(layer_attn).__module__], "eager_attention_forward", None)
+        base_fn = ALL_ATTENTION_FUNCTIONS.get_interface(base, eager)
+        if base_fn is None:
+            raise RuntimeError(f"register_probe: cannot resolve the attention implementation '{base}'")
+        logger = self
+
+        def probed(module, query, key, value, attention_mask, **kwargs):
+            if logger.image_token_starts is not None:
+                logger._probe_attention(query, key, attention_mask, kwargs.get("scaling"))
+            return base_fn(module, query, key, value, attention_mask, **kwargs)
+
+        name = f"attwarp_probe_{id(self):x}"
+        AttentionInterface.register(name, probed)
+        self._probe_saved = (layer_attn, layer_attn.config, name)
+        private = copy.copy(layer_attn.config)
+        private._attn_implementation = name
+        layer_attn.config = private
+
     def remove_hook_and_unpatch(self):
         if self.hook_handle is not None:
             self.hook_handle.remove()
@@ -140,6 +231,16 @@ class BatchMaskHookLogger(object):
         if self._original_forward is not None:
             self.model.model.layers[self.layer_index].self_attn.forward = self._original_forward
             self._original_forward = None
+        saved = getattr(self, "_probe_saved", None)
+        if saved is not None:
+            layer_attn, config, name = saved
+            layer_attn.config = config
+            try:
+                from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+                ALL_ATTENTION_FUNCTIONS._global_mapping.pop(name, None)
+            except Exception:
+                pass
+            self._probe_saved = None
 
 
 def batch_hook_logger(model, device, layer_index: int = 20) -> BatchMaskHookLogger:

@@ -372,6 +372,16 @@ static int launch_finalize(const void* steps, int Tn, int64_t n, void* out, hipS
   return check_launch("attn_finalize_kernel");
 }
 
+// dtype-dispatched A1 launch for other translation units (probe.hip chains into it)
+int launch_attn_step_dtype(int dtype, const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off,
+                           int64_t skv, const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
+  switch (dtype) {
+    case ATTWARP_F32: return launch_step<float>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
+    case ATTWARP_F16: return launch_step<__half>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
+    default: return launch_step<__hip_bfloat16>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
+  }
+}
+
 static int check_attn_dtype(int dtype, const char* who) {
   if (dtype == ATTWARP_F32 || dtype == ATTWARP_F16 || dtype == ATTWARP_BF16) return 0;
   return fail(ATTWARP_E_ARG, "%s: dtype must be F32, F16 or BF16 (got %d)", who, dtype);

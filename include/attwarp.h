@@ -80,6 +80,26 @@ ATTWARP_API size_t attwarp_attn_reduce_stack_workspace_bytes(int dtype, int T, i
 ATTWARP_API int attwarp_attn_reduce_stack(const void* rows, int dtype, int T, int B, int heads, int kv_len,
                               const int32_t* starts, int ntok, void* out, void* ws, void* stream);
 
+/* ---- "next" row 4: hook-side capture without materialising [B,heads,q,kv] probabilities.
+ * Replaces  register_hook_and_patch (llava.py:422-438: output_attentions=True on the target layer, i.e. HF's
+ * eager_attention_forward producing softmax(QK^T*scaling + mask) for every query row) followed by
+ * _process_attention (llava.py:385-396), which only consumes the LAST query row.
+ *   q  : post-RoPE query vectors of the last token, [B,heads,head_dim], element strides q_stride_b/_h
+ *   k  : post-RoPE key cache, [B,kv_heads,kv_len,head_dim], element strides k_stride_b/_h/_t
+ *        (head_dim contiguous; heads % kv_heads == 0: grouped-query attention shares a key head)
+ *   kv_begin : device int32[B] or NULL - first attended key position (left padding); earlier keys get p = 0
+ *   starts   : device int32[B], image-token slice starts; starts[b]+ntok <= kv_len
+ *   out      : [B,ntok] in `dtype` = mean over heads of p[st:st+ntok] / (sum + 1e-12), as A1
+ *   ws       : attwarp_attn_probe_workspace_bytes(...) bytes, 16-byte aligned
+ * Rounding mirrors the eager path's dtype transitions (matmul -> dtype, *scaling -> dtype, softmax in
+ * float32 -> dtype).  q, k 16-byte aligned, strides multiples of 16 bytes, kv_len <= 15872, ntok <= 1024. */
+ATTWARP_API size_t attwarp_attn_probe_workspace_bytes(int dtype, int B, int heads, int ntok);
+ATTWARP_API int attwarp_attn_probe_last_query(const void* q, const void* k, int dtype, int B, int heads, int kv_heads,
+                                  int head_dim, int kv_len, int64_t q_stride_b, int64_t q_stride_h,
+                                  int64_t k_stride_b, int64_t k_stride_h, int64_t k_stride_t,
+                                  const int32_t* kv_begin, const int32_t* starts, int ntok, float scaling,
+                                  void* out, void* ws, void* stream);
+
 /* ---- A3: revise_mask = normalize("min") -> enhance -> k x k box filter, llava.py:207-238
  * mask [B,n,n] float32 -> out [B,n,n] float32 (n <= 32, odd kernel_size <= 7). */
 ATTWARP_API int attwarp_mask_postproc(const float* mask, int B, int n, int kernel_size, float enhance_coe,

@@ -108,6 +108,47 @@ def attn_reduce_stack(rows: np.ndarray, starts: Sequence[int], ntok: int = NUM_I
     return attn_finalize(steps)
 
 
+def attn_probe_last_row(q: np.ndarray, k: np.ndarray, scaling: float,
+                        kv_begin: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Last query row of HF's eager attention, the tensor the reference's hook slices
+    (AGW/attention_extraction/llava.py:391 reads ``attn_weights[b, :, -1, st:ed]``; the weights come from
+    ``register_hook_and_patch`` forcing ``output_attentions=True``, llava.py:422-438).
+
+    Third-party arithmetic, not vendored: transformers (pinned 4.37.2 in the reference's attwarp.yaml:26)
+    ``eager_attention_forward``: ``softmax(matmul(q, k^T) * scaling + mask, dtype=float32).to(q.dtype)``
+    (4.37.2 writes ``/ sqrt(head_dim)`` instead of ``* scaling``; equal for power-of-4 head_dim, within one
+    float32 ulp before the rounding to the model dtype otherwise).  Dtype transitions kept; the dot
+    product and the softmax denominator are accumulated in float64 and rounded once.
+
+    q [B,H,D] (last query, post-RoPE), k [B,Hkv,kv,D] -> probabilities [B,H,kv] in q's dtype.
+    kv_begin[b]: first attended key (left padding); earlier keys carry the mask's finfo.min -> 0.
+    """
+    q, k = np.asarray(q), np.asarray(k)
+    dt = q.dtype
+    B, H, D = q.shape
+    Hkv, kv = k.shape[1], k.shape[2]
+    kk = np.repeat(k, H // Hkv, axis=1)                                    # repeat_kv
+    w = np.einsum("bhd,bhjd->bhj", q.astype(F64), kk.astype(F64)).astype(dt)
+    w = (w.astype(F32) * F32(scaling)).astype(dt)
+    x = w.astype(F32)
+    out = np.zeros((B, H, kv), dtype=dt)
+    for b in range(B):
+        kb = 0 if kv_begin is None else int(kv_begin[b])
+        xv = x[b, :, kb:]
+        m = xv.max(axis=-1, keepdims=True)
+        e = np.exp((xv - m).astype(F32).astype(F64)).astype(F32)
+        den = e.astype(F64).sum(axis=-1, keepdims=True).astype(F32)
+        out[b, :, kb:] = (e / den).astype(dt)
+    return out
+
+
+def attn_probe_step(q: np.ndarray, k: np.ndarray, starts: Sequence[int], ntok: int, scaling: float,
+                    kv_begin: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Probed generation step = ``attn_reduce_step`` of ``attn_probe_last_row``: [B, ntok]."""
+    p = attn_probe_last_row(q, k, scaling, kv_begin)
+    return attn_reduce_step(p[:, :, None, :], starts, [int(s) + ntok for s in starts])
+
+
 # ---------------------------------------------------------------------------
 # A3  mask post-processing (24 x 24)
 # ---------------------------------------------------------------------------

@@ -152,8 +152,55 @@ def make_clip_goldens():
     np.savez_compressed(os.path.join(OUT, "clip_preprocess.npz"), **clip)
 
 
+def probe_cases():
+    """Inputs of the "next" row 4 goldens: (name, query [B,H,q,D], key [B,Hkv,kv,D], left pads, slice starts)."""
+    g = torch.Generator().manual_seed(19)
+    B, H, Hkv, D, ntok = 2, 4, 2, 64, 24
+    cases = []
+    for name, q, kv in (("prefill", 48, 48), ("decode", 1, 49)):
+        query = torch.randn(B, H, q, D, generator=g)
+        key = torch.randn(B, Hkv, kv, D, generator=g)
+        cases.append((name, query, key, [0, 3], [5, 8], ntok))
+    return cases
+
+
+def make_probe_golden(eager_attention_forward, llava):
+    """"next" row 4: what the reference's hook sees when the target layer runs HF's eager attention
+    (third-party: transformers' eager_attention_forward, imported before the stubs) and what
+    BatchMaskHookLogger._process_attention (the reference) makes of it."""
+    import transformers
+    out = {"versions": np.array([transformers.__version__, torch.__version__])}
+    for name, query, key, pads, starts, ntok in probe_cases():
+        B, H, q, D = query.shape
+        Hkv, kv = key.shape[1], key.shape[2]
+        module = types.SimpleNamespace(num_key_value_groups=H // Hkv, training=False)
+        scaling = D ** -0.5
+        for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+            i = torch.arange(kv - q, kv)[:, None]
+            j = torch.arange(kv)[None, :]
+            allowed = (j <= i)[None, None] & (j[None, None] >= torch.tensor(pads)[:, None, None, None])
+            mask = torch.zeros(B, 1, q, kv, dtype=dt).masked_fill(~allowed, torch.finfo(dt).min)
+            qd, kd = query.to(dt), key.to(dt)
+            vd = torch.zeros_like(kd)
+            _, probs = eager_attention_forward(module, qd, kd, vd, mask, scaling=scaling)
+            logger = llava.BatchMaskHookLogger(model=None, device="cpu", layer_index=20)
+            logger.set_batch_image_token_ranges(starts, [s + ntok for s in starts])
+            logger._process_attention(probs)
+            out[f"{name}_{tag}_probs_last"] = probs[:, :, -1, :].numpy()
+            out[f"{name}_{tag}_step"] = logger.step_attentions[0].numpy()
+        out[f"{name}_q_last"] = query[:, :, -1, :].numpy()
+        out[f"{name}_key"] = key.numpy()
+        out[f"{name}_pads"] = np.array(pads)
+        out[f"{name}_starts"] = np.array(starts)
+        out[f"{name}_ntok"] = np.array(ntok)
+        out[f"{name}_scaling"] = np.array(scaling)
+    np.savez_compressed(os.path.join(OUT, "attn_probe.npz"), **out)
+
+
 def main():
-    make_clip_goldens()
+    if "--only-probe" not in sys.argv:
+        make_clip_goldens()
+    from transformers.models.llama.modeling_llama import eager_attention_forward
     _install_stubs()
     torch.manual_seed(0)
     torch.set_num_threads(1)
@@ -163,6 +210,10 @@ def main():
     model = _load("ref_model", os.path.join(MN, "model.py"))
     sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
     llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
+
+    make_probe_golden(eager_attention_forward, llava)
+    if "--only-probe" in sys.argv:
+        return
 
     # ---------------- A1 / A2: attention aggregation -----------------------
     g = torch.Generator().manual_seed(11)

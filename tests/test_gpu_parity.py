@@ -88,6 +88,135 @@ def test_attn_steps_low_precision(dev, golden, dt):
         np.testing.assert_allclose(N(fin.float()), g["final"], rtol=2e-2)
 
 
+# ===================== "next" row 4: probe from (query, key) ==================
+@pytest.mark.parametrize("name", ["prefill", "decode"])
+def test_probe_vs_oracle_and_golden(dev, golden, name):
+    from attwarp_amd import attention_extraction as ae
+    g = golden("attn_probe")
+    starts, pads, ntok, sc = g[f"{name}_starts"], g[f"{name}_pads"], int(g[f"{name}_ntok"]), float(g[f"{name}_scaling"])
+    for tag, dt in (("f32", np.float32), ("f16", np.float16)):
+        q, k = g[f"{name}_q_last"].astype(dt), g[f"{name}_key"].astype(dt)
+        got = N(ae.probe_last_query(T(q, dev), T(k, dev), T(starts.astype(np.int32), dev), ntok,
+                                    T(pads.astype(np.int32), dev), sc))
+        assert got.dtype == dt
+        assert np.array_equal(got, O.attn_probe_step(q, k, starts, ntok, sc, pads))          # bit-exact vs oracle
+        # vs transformers' eager attention + the reference's hook: fp16 exact, fp32 within torch's sgemm/expf
+        if dt == np.float16:
+            assert np.array_equal(got, g[f"{name}_{tag}_step"])
+        else:
+            np.testing.assert_allclose(got, g[f"{name}_{tag}_step"], rtol=2e-6)
+
+
+@pytest.mark.parametrize("dt,D,H,Hkv,kv", [
+    (np.float16, 128, 32, 32, 640),      # LLaVA-1.5-7B geometry
+    (np.float16, 128, 8, 2, 701),        # grouped-query attention, ragged kv
+    (np.float32, 128, 4, 4, 333),        # two 16-byte chunks per lane
+    (np.float16, 64, 6, 3, 97),          # 8 lanes per row
+    (np.float16, 96, 4, 4, 130),         # 4 lanes per row, 3 chunks per lane
+    (np.float32, 20, 3, 1, 64),          # 1 lane per row, 5 chunks -> unsupported
+    (np.float16, 256, 2, 1, 1500),       # 2 chunks per lane
+])
+def test_probe_shapes_and_strides(dev, dt, D, H, Hkv, kv):
+    from attwarp_amd import attention_extraction as ae, _lib
+    rng = np.random.default_rng(D * 7 + kv)
+    B, ntok = 3, min(576, kv - 40)
+    q = rng.standard_normal((B, H, D)).astype(dt)
+    k = rng.standard_normal((B, Hkv, kv, D)).astype(dt)
+    starts = np.array([5, 17, 40], np.int32)
+    pads = np.array([0, 3, 39], np.int32)
+    sc = D ** -0.5
+    if D == 20:
+        with pytest.raises(_lib.AttWarpError, match="chunks per lane"):
+            ae.probe_last_query(T(q, dev), T(k, dev), T(starts, dev), ntok, T(pads, dev))
+        return
+    ref = O.attn_probe_step(q, k, starts, ntok, sc, pads)
+    got = N(ae.probe_last_query(T(q, dev), T(k, dev), T(starts, dev), ntok, T(pads, dev)))
+    assert np.array_equal(got, ref)
+    # the layout HF hands over at prefill without a cache: [B,kv,Hkv,D] memory viewed as [B,Hkv,kv,D],
+    # query [B,q,H,D] memory viewed as [B,H,q,D]; the last row is taken by the wrapper
+    k_t = T(np.ascontiguousarray(k.transpose(0, 2, 1, 3)), dev).transpose(1, 2)
+    q_full = rng.standard_normal((B, 3, H, D)).astype(dt)
+    q_full[:, -1] = q
+    q_t = T(q_full, dev).transpose(1, 2)
+    assert Hkv == 1 or not k_t.is_contiguous()
+    got2 = N(ae.probe_last_query(q_t, k_t, T(starts, dev), ntok, T(pads, dev)))
+    assert np.array_equal(got2, ref)
+    # no padding argument == all-zero padding
+    ref0 = O.attn_probe_step(q, k, starts, ntok, sc, None)
+    assert np.array_equal(N(ae.probe_last_query(T(q, dev), T(k, dev), T(starts, dev), ntok)), ref0)
+
+
+def test_probe_bf16_and_misaligned_inputs(dev):
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(5)
+    B, H, kv, D, ntok = 2, 8, 300, 128, 192
+    q = torch.from_numpy(rng.standard_normal((B, H, D)).astype(np.float32)).to(dev).bfloat16()
+    k = torch.from_numpy(rng.standard_normal((B, H, kv, D)).astype(np.float32)).to(dev).bfloat16()
+    starts = torch.tensor([7, 30], dtype=torch.int32, device=dev)
+    got = ae.probe_last_query(q, k, starts, ntok)
+    assert got.dtype == torch.bfloat16
+    # bf16 has no numpy dtype: compare with the float32 oracle on the same (bf16-representable) inputs
+    ref = O.attn_probe_step(N(q.float()), N(k.float()), N(starts), ntok, D ** -0.5, None)
+    np.testing.assert_allclose(N(got.float()), ref, rtol=3e-2)
+    # a key view whose rows start 2 bytes off a 16-byte boundary is copied by the wrapper, not mis-read
+    big = torch.zeros(B, H, kv, D + 8, device=dev, dtype=torch.float16)
+    kh = k.half()
+    big[..., 1:D + 1] = kh
+    view = big[..., 1:D + 1]
+    a = ae.probe_last_query(q.half(), view, starts, ntok)
+    b = ae.probe_last_query(q.half(), kh, starts, ntok)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("layer,rtol", [(0, 4e-3), (1, 5e-2)])
+def test_probe_equals_hooked_eager_on_hf_llama(dev, layer, rtol):
+    """End to end through the installed transformers' LlamaAttention: the reference's way (eager attention,
+    output_attentions forced on the target layer, hook on the probabilities) against register_probe on the
+    model's fast path.  Layer 0 sees identical inputs on both paths (tolerance = fp16 rounding of the
+    GEMM-vs-exact logits); deeper layers add the eager-vs-sdpa drift of the hidden states."""
+    transformers = pytest.importorskip("transformers")
+    from attwarp_amd import attention_extraction as ae
+    cfg = transformers.LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2,
+                                   num_attention_heads=4, num_key_value_heads=4, vocab_size=1000, head_dim=128,
+                                   max_position_embeddings=2048)
+    torch.manual_seed(3)
+    model = transformers.LlamaForCausalLM(cfg).to(dev).half().eval()
+    B, L, ntok = 3, 640, 576
+    pads = [0, 5, 11]
+    ids = torch.randint(0, 1000, (B, L), device=dev)
+    am = torch.ones(B, L, dtype=torch.long, device=dev)
+    for b, p_ in enumerate(pads):
+        am[b, :p_] = 0
+    nxt = torch.randint(0, 1000, (3, B, 1), device=dev)               # fixed continuation: both paths see the same tokens
+    starts = [30 + p_ for p_ in pads]
+
+    def run(impl, probe):
+        model.config._attn_implementation = impl
+        hl = ae.BatchMaskHookLogger(model, dev, layer_index=layer)
+        hl.set_batch_image_token_ranges(starts, [s + ntok for s in starts])
+        hl.register_probe() if probe else hl.register_hook_and_patch()
+        try:
+            with torch.no_grad():
+                out = model(input_ids=ids, attention_mask=am, use_cache=True)
+                cache, mask = out.past_key_values, am
+                for t in range(3):
+                    mask = torch.cat([mask, torch.ones(B, 1, dtype=torch.long, device=dev)], dim=1)
+                    out = model(input_ids=nxt[t], attention_mask=mask, past_key_values=cache, use_cache=True)
+                    cache = out.past_key_values
+        finally:
+            hl.remove_hook_and_unpatch()
+        return hl
+
+    hooked = run("eager", probe=False)
+    probed = run("sdpa", probe=True)
+    assert len(hooked.step_attentions) == len(probed.step_attentions) == 4
+    for a, b in zip(hooked.step_attentions, probed.step_attentions):
+        assert a.shape == b.shape == (B, ntok) and a.dtype == b.dtype == torch.float16
+        np.testing.assert_allclose(N(b.float()), N(a.float()), rtol=rtol, atol=2e-6)
+    fa, fb = torch.stack(hooked.finalize_batch()), torch.stack(probed.finalize_batch())
+    np.testing.assert_allclose(N(fb.float()), N(fa.float()), rtol=rtol, atol=2e-6)
+
+
 def test_attn_strided_prefill_and_empty(dev):
     from attwarp_amd import attention_extraction as ae
     rng = np.random.default_rng(21)

@@ -51,6 +51,61 @@ def test_c_abi_argument_validation_without_gpu(lib):
     assert lib.attwarp_axis_sums_workspace_bytes(2, 3, 5) == 2 * 8 * 8
 
 
+def test_probe_abi_validation_without_gpu(lib):
+    import ctypes
+    p = ctypes.cast(ctypes.create_string_buffer(4096), ctypes.c_void_p)
+    a = ctypes.c_void_p((p.value + 15) & ~15)
+    f = lib.attwarp_attn_probe_last_query
+    assert f(a, a, 1, 2, 4, 2, 64, 48, 256, 64, 6144, 3072, 64, None, a, 24, 0.125, a, None, None) == -1   # ws null
+    assert f(a, a, 1, 2, 4, 3, 64, 48, 256, 64, 6144, 3072, 64, None, a, 24, 0.125, a, a, None) == -1      # heads % kv_heads
+    assert f(a, a, 3, 2, 4, 2, 64, 48, 256, 64, 6144, 3072, 64, None, a, 24, 0.125, a, a, None) == -1      # uint8
+    assert f(a, a, 1, 2, 4, 2, 60, 48, 240, 60, 5760, 2880, 60, None, a, 24, 0.125, a, a, None) == -2      # D % 8
+    assert f(a, a, 1, 2, 4, 2, 64, 48, 256, 64, 6144, 3072, 65, None, a, 24, 0.125, a, a, None) == -2      # stride
+    assert b"16 bytes" in lib.attwarp_last_error()
+    assert f(a, a, 1, 2, 4, 2, 64, 20000, 256, 64, 6144, 3072, 64, None, a, 24, 0.125, a, a, None) == -2   # kv too long
+    assert f(a, a, 1, 2, 4, 2, 64, 16, 256, 64, 6144, 3072, 64, None, a, 24, 0.125, a, a, None) == -1      # ntok > kv
+    assert lib.attwarp_attn_probe_workspace_bytes(1, 2, 4, 24) == 16 + 2 * 4 * 24 * 2
+
+
+def test_register_probe_plumbing_on_hf_llama():
+    """register_probe wires the target layer only, sees post-RoPE (query, key), the model's own mask and
+    scaling, leaves the model's output untouched and restores everything on removal (no GPU needed: the
+    probe itself is replaced by a recorder)."""
+    transformers = pytest.importorskip("transformers")
+    from attwarp_amd import attention_extraction as ae
+    cfg = transformers.LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=3, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=100, head_dim=16)
+    cfg._attn_implementation = "sdpa"
+    torch.manual_seed(0)
+    m = transformers.LlamaModel(cfg).eval()
+    holder = type("Holder", (), {})()
+    holder.model = m
+    hl = ae.BatchMaskHookLogger(holder, "cpu", layer_index=1)
+    calls = []
+    hl._probe_attention = lambda q, k, mask, scaling=None: calls.append((tuple(q.shape), tuple(k.shape), mask, scaling))
+    hl.set_batch_image_token_ranges([2, 3], [10, 11])
+    ids = torch.randint(0, 100, (2, 12))
+    am = torch.ones(2, 12, dtype=torch.long)
+    am[1, :3] = 0
+    with torch.no_grad():
+        ref = m(input_ids=ids, attention_mask=am).last_hidden_state
+        hl.register_probe()
+        out = m(input_ids=ids, attention_mask=am).last_hidden_state
+    assert torch.equal(ref, out)
+    assert len(calls) == 1                                           # one layer, one call
+    qs, ks, mask, scaling = calls[0]
+    assert qs == (2, 4, 12, 16) and ks == (2, 2, 12, 16) and scaling == 0.25
+    assert mask.shape == (2, 1, 12, 12) and not bool(mask[1, 0, -1, :3].any()) and bool(mask[1, 0, -1, 3:].all())
+    hl.remove_hook_and_unpatch()
+    assert m.layers[1].self_attn.config is cfg
+    calls.clear()
+    with torch.no_grad():
+        m(input_ids=ids, attention_mask=am)
+    assert calls == []
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ae.probe_last_query(torch.rand(2, 4, 16), torch.rand(2, 2, 12, 16), torch.zeros(2, dtype=torch.int32), 8)
+
+
 def test_no_cpu_fallback():
     from attwarp_amd import checkpoint_utils as cu, model, attention_extraction as ae
     with pytest.raises(RuntimeError, match="no CPU fallback"):

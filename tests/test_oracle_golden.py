@@ -51,6 +51,29 @@ def test_attn_stack_equals_steps(golden):
     assert np.array_equal(fused, O.attn_finalize(steps))
 
 
+@pytest.mark.parametrize("name", ["prefill", "decode"])
+def test_attn_probe_vs_hf_eager_and_reference_hook(golden, name):
+    """"next" row 4: last-row attention restated from (q, k) against transformers' eager_attention_forward
+    followed by the reference's _process_attention (tests/golden/make_golden.py::make_probe_golden)."""
+    g = golden("attn_probe")
+    starts, pads, ntok, sc = g[f"{name}_starts"], g[f"{name}_pads"], int(g[f"{name}_ntok"]), float(g[f"{name}_scaling"])
+    for tag, dt, rtol in (("f32", np.float32, 2e-6), ("f16", np.float16, 0.0)):
+        q, k = g[f"{name}_q_last"].astype(dt), g[f"{name}_key"].astype(dt)
+        probs = O.attn_probe_last_row(q, k, sc, pads)
+        ref = g[f"{name}_{tag}_probs_last"]
+        assert probs.dtype == ref.dtype and probs.shape == ref.shape
+        if rtol == 0.0:
+            assert np.array_equal(probs, ref)                       # fp16: bit-exact vs torch + transformers
+        else:
+            np.testing.assert_allclose(probs, ref, rtol=rtol, atol=1e-12)
+        assert np.all(probs[1, :, :int(pads[1])] == 0)               # left padding carries no probability
+        step = O.attn_probe_step(q, k, starts, ntok, sc, pads)
+        if rtol == 0.0:
+            assert np.array_equal(step, g[f"{name}_{tag}_step"])
+        else:
+            np.testing.assert_allclose(step, g[f"{name}_{tag}_step"], rtol=rtol)
+
+
 def test_attn_empty_uniform(golden):
     g = golden("attn_reduce")
     out = O.attn_finalize([], batch_size=2)
