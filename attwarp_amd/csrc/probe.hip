@@ -27,7 +27,6 @@ int launch_attn_step_dtype(int dtype, const void* attn, int nb, int heads, int64
 namespace probe {
 
 constexpr int NT = 256;
-constexpr int U = 4;        // rows in flight per lane group
 constexpr int MAXCPL = 4;   // 16-byte chunks of a row per lane
 constexpr int MAX_KV = 15872;
 
@@ -57,7 +56,7 @@ template <> __device__ __forceinline__ void decode<__hip_bfloat16>(const u4& v, 
 }
 
 struct Params {
-  int heads, group, kv, ntok, cpl;
+  int heads, group, kv, ntok;
   int64_t q_sb, q_sh, k_sb, k_sh, k_st;   // element strides
   const int32_t* kv_begin;                // [B] or null
   const int32_t* starts;                  // [B]
@@ -65,8 +64,8 @@ struct Params {
   int32_t* zero;                          // workspace word the chained reduction reads as its slice start
 };
 
-// grid = (heads, B)
-template <typename T, int LPR>
+// grid = (heads, B).  CPL = 16-byte chunks of a row per lane; U rows per lane group in flight (8 loads per lane).
+template <typename T, int LPR, int CPL>
 __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const Params p, T* __restrict__ probs) {
   extern __shared__ float logit[];                 // kv floats
@@ -74,6 +73,7 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
   __shared__ float fred[NT / WAVE];
   constexpr int NE = Chunk<T>::NE;
   constexpr int G = NT / LPR;                      // lane groups = rows per sweep
+  constexpr int U = CPL == 1 ? 8 : (CPL == 2 ? 4 : 2);
   const int h = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, g = tid / LPR, l = tid % LPR;
   const int kv = p.kv;
@@ -81,18 +81,13 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
   if (h == 0 && b == 0 && tid == 0) *p.zero = 0;
 
   // this lane's slices of the query vector, as double
-  double qd[MAXCPL][NE];
+  double qd[CPL][NE];
   {
     const char* qp = reinterpret_cast<const char*>(q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh);
 #pragma unroll
-    for (int c = 0; c < MAXCPL; ++c) {
-      if (c < p.cpl) {
-        const u4 v = *reinterpret_cast<const u4*>(qp + (size_t)(c * LPR + l) * 16);
-        decode<T>(v, qd[c]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < NE; ++i) qd[c][i] = 0.0;
-      }
+    for (int c = 0; c < CPL; ++c) {
+      const u4 v = *reinterpret_cast<const u4*>(qp + (size_t)(c * LPR + l) * 16);
+      decode<T>(v, qd[c]);
     }
   }
 
@@ -100,25 +95,22 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
                    (size_t)l * 16;
   const int64_t rstride = p.k_st * (int64_t)sizeof(T);
   for (int j0 = kb + g; j0 < kv; j0 += G * U) {
-    u4 v[U][MAXCPL];
+    u4 v[U][CPL];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const char* rp = kp + (int64_t)min(j0 + u * G, kv - 1) * rstride;   // clamped: tail rows re-read, not stored
 #pragma unroll
-      for (int c = 0; c < MAXCPL; ++c)
-        if (c < p.cpl) v[u][c] = *reinterpret_cast<const u4*>(rp + (size_t)c * LPR * 16);
+      for (int c = 0; c < CPL; ++c) v[u][c] = *reinterpret_cast<const u4*>(rp + (size_t)c * LPR * 16);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       double acc = 0.0;
 #pragma unroll
-      for (int c = 0; c < MAXCPL; ++c) {
-        if (c < p.cpl) {
-          double kd[NE];
-          decode<T>(v[u][c], kd);
+      for (int c = 0; c < CPL; ++c) {
+        double kd[NE];
+        decode<T>(v[u][c], kd);
 #pragma unroll
-          for (int i = 0; i < NE; ++i) acc = fma(qd[c][i], kd[i], acc);
-        }
+        for (int i = 0; i < NE; ++i) acc = fma(qd[c][i], kd[i], acc);
       }
 #pragma unroll
       for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, WAVE);
@@ -155,22 +147,26 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
   }
 }
 
-template <typename T, int LPR>
-static int launch_lpr(const void* q, const void* k, const Params& p, int B, void* probs, hipStream_t st) {
-  hipLaunchKernelGGL((attn_probe_kernel<T, LPR>), dim3(p.heads, B), dim3(NT), (size_t)p.kv * sizeof(float), st,
+template <typename T, int LPR, int CPL>
+static int launch_k(const void* q, const void* k, const Params& p, int B, void* probs, hipStream_t st) {
+  hipLaunchKernelGGL((attn_probe_kernel<T, LPR, CPL>), dim3(p.heads, B), dim3(NT), (size_t)p.kv * sizeof(float), st,
                      (const T*)q, (const T*)k, p, (T*)probs);
   return check_launch("attn_probe_kernel");
 }
 
+// chunks per row nc = LPR * CPL with LPR the largest power of two <= 16 dividing nc: below 16 lanes CPL is odd
 template <typename T>
-static int launch_t(const void* q, const void* k, const Params& p, int lpr, int B, void* probs, hipStream_t st) {
-  switch (lpr) {
-    case 16: return launch_lpr<T, 16>(q, k, p, B, probs, st);
-    case 8: return launch_lpr<T, 8>(q, k, p, B, probs, st);
-    case 4: return launch_lpr<T, 4>(q, k, p, B, probs, st);
-    case 2: return launch_lpr<T, 2>(q, k, p, B, probs, st);
-    default: return launch_lpr<T, 1>(q, k, p, B, probs, st);
-  }
+static int launch_t(const void* q, const void* k, const Params& p, int lpr, int cpl, int B, void* probs,
+                    hipStream_t st) {
+#define ATTWARP_PROBE_CASE(L, C) \
+  if (lpr == L && cpl == C) return launch_k<T, L, C>(q, k, p, B, probs, st);
+  ATTWARP_PROBE_CASE(16, 1) ATTWARP_PROBE_CASE(16, 2) ATTWARP_PROBE_CASE(16, 3) ATTWARP_PROBE_CASE(16, 4)
+  ATTWARP_PROBE_CASE(8, 1) ATTWARP_PROBE_CASE(8, 3)
+  ATTWARP_PROBE_CASE(4, 1) ATTWARP_PROBE_CASE(4, 3)
+  ATTWARP_PROBE_CASE(2, 1) ATTWARP_PROBE_CASE(2, 3)
+  ATTWARP_PROBE_CASE(1, 1) ATTWARP_PROBE_CASE(1, 3)
+#undef ATTWARP_PROBE_CASE
+  return fail(ATTWARP_E_UNSUPPORTED, "attn_probe_last_query: no kernel for %d lanes x %d chunks per lane", lpr, cpl);
 }
 
 static size_t esize(int dtype) { return dtype == ATTWARP_F32 ? 4 : 2; }
@@ -223,7 +219,7 @@ extern "C" int attwarp_attn_probe_last_query(const void* q, const void* k, int d
                 head_dim, cpl, probe::MAXCPL);
 
   probe::Params p;
-  p.heads = heads; p.group = heads / kv_heads; p.kv = kv_len; p.ntok = ntok; p.cpl = cpl;
+  p.heads = heads; p.group = heads / kv_heads; p.kv = kv_len; p.ntok = ntok;
   p.q_sb = q_stride_b; p.q_sh = q_stride_h; p.k_sb = k_stride_b; p.k_sh = k_stride_h; p.k_st = k_stride_t;
   p.kv_begin = kv_begin; p.starts = starts; p.scale = scaling;
   p.zero = reinterpret_cast<int32_t*>(ws);
@@ -231,9 +227,9 @@ extern "C" int attwarp_attn_probe_last_query(const void* q, const void* k, int d
   hipStream_t st = as_stream(stream);
   int rc;
   switch (dtype) {
-    case ATTWARP_F32: rc = probe::launch_t<float>(q, k, p, lpr, B, probs, st); break;
-    case ATTWARP_F16: rc = probe::launch_t<__half>(q, k, p, lpr, B, probs, st); break;
-    default: rc = probe::launch_t<__hip_bfloat16>(q, k, p, lpr, B, probs, st); break;
+    case ATTWARP_F32: rc = probe::launch_t<float>(q, k, p, lpr, cpl, B, probs, st); break;
+    case ATTWARP_F16: rc = probe::launch_t<__half>(q, k, p, lpr, cpl, B, probs, st); break;
+    default: rc = probe::launch_t<__hip_bfloat16>(q, k, p, lpr, cpl, B, probs, st); break;
   }
   if (rc) return rc;
   // A1 on the probed rows: probs [B,heads,ntok], slice start 0 for every sample
