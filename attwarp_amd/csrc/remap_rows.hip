@@ -69,6 +69,7 @@ struct RowsParams {
   int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
   int no_swz;        // 1: disable the XCD-aware block order (experiments)
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
+  int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
 };
 
 constexpr int RMAX = 64;
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   const float* src_b = p.src + (long long)b * p.img_stride;
   float* dst_b = p.dst + (long long)b * p.oimg_stride;
 
-  if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
+  const int bm = b / p.map_div;
+  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
 
   // ---- column taps, once per block, kept in registers.  Lanes past the end of the row duplicate
   //      the last element (same value to the same address): the row loop has no per-lane branches.
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     const int r = e - pl * p.orow_len;
     const int x = r / p.CS;
     const int c = r - x * p.CS;
-    const Taps tx = rtaps<ATTWARP_EXACT>(p.mx[(long long)b * p.Wo + x], p.W);
+    const Taps tx = rtaps<ATTWARP_EXACT>(p.mx[(long long)bm * p.Wo + x], p.W);
     const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;
     const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + c;
     pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
@@ -297,6 +299,20 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   RowsParams p;
   p.src = src; p.dst = dst; p.mx = mx; p.my = my;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+  p.map_div = 1;
+  // Planar images with rows of >= 3 KB: every plane is dispatched as a one-channel image of its own (the maps of
+  // image b serve planes b*C .. b*C+C-1).  A workgroup then streams ONE contiguous row at a time instead of C
+  // row segments H*W apart.  Measured on MI355X, [256,3,1024,1024] float32, two boxes: 1.10 / 1.22 ms against
+  // 1.24 / 1.28 ms for the all-planes-per-workgroup form (5.9 / 5.3 vs 5.2 / 5.0 TB/s); the crossover is near
+  // W = 700, below it the all-planes form wins (336: 252 of 256 lanes busy with three planes per row, 84 with one).
+  bool split = layout == ATTWARP_CHW && C > 1 && (long long)W * 4 >= 3072 && (long long)B * C <= 2147483647LL;
+  if (const char* se = getenv("ATTWARP_REMAP_CHW_SPLIT")) split = layout == ATTWARP_CHW && C > 1 && atoi(se) != 0;
+  if (split) {
+    p.map_div = C;
+    B *= C;
+    C = 1;
+    layout = ATTWARP_HWC;
+  }
   if (layout == ATTWARP_HWC) { p.NP = 1; p.CS = C; } else { p.NP = C; p.CS = 1; }
   p.row_len = W * p.CS;
   p.orow_len = Wo * p.CS;
