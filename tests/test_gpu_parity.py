@@ -554,6 +554,28 @@ def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
             assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (dt.__name__, variant, "chw")
 
 
+@pytest.mark.parametrize("kind", ["cdf", "wild"])
+@pytest.mark.parametrize("split", [None, "0", "1"])
+def test_remap_planar_plane_split(dev, kind, split):
+    """Planar float32 images with wide rows are dispatched plane by plane (maps of image b serve planes b*C..):
+    default heuristic, forced on and forced off must all equal the oracle bit-for-bit."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(77)
+    B, C, H, W, Ho, Wo = 3, 3, 40, 1024, 37, 768
+    img = rng.random((B, C, H, W), dtype=np.float32)
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    ref = np.stack([O.remap_bilinear(img[b].transpose(1, 2, 0), mx[b], my[b]) for b in range(B)]).transpose(0, 3, 1, 2)
+    if split is not None:
+        os.environ["ATTWARP_REMAP_CHW_SPLIT"] = split
+    try:
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev)))
+        two = N(cu.remap_separable(T(img[:, :2], dev), T(mx, dev), T(my, dev)))      # C = 2
+    finally:
+        os.environ.pop("ATTWARP_REMAP_CHW_SPLIT", None)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(two, ref[:, :2])
+
+
 @pytest.mark.parametrize("R", ["1", "5", "64"])
 def test_remap_rows_block_boundaries(dev, R):
     """Row-block size must not change a single bit (halo / slide logic at block seams)."""
