@@ -39,6 +39,8 @@ SIGNATURES = {
     "attwarp_attn_probe_last_query": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
                                                c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_float,
                                                c_void_p, c_void_p, c_void_p]),
+    "attwarp_masked_token_mean": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_film_axis_means": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "attwarp_mask_postproc": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "attwarp_mask_upsample_lanczos": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

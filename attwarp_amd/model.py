@@ -2,9 +2,11 @@
 
 ``safe_softmax`` (reference :8-14) is the "row/col marginal softmax" of the hot path and runs as a
 HIP kernel.  ``MarginalNet`` (:17-95) is the producer of the path's input in the end-to-end
-configuration; its dense convolutions are MFMA-class library work, so it runs on stock
-PyTorch-ROCm ops ("next" row 1) with the reference's parameter names so checkpoints
-saved by the reference trainer (``{"model": state_dict}``, MN/trainer.py:660-683) load unchanged.
+configuration ("next" row 1): its dense convolutions and linear layers are MFMA-class
+library work and run on stock PyTorch-ROCm ops, the memory-bound tail between them (masked text-token
+mean, FiLM + the two axis means) on HIP kernels that read each tensor once.  Parameter names are the
+reference's, so checkpoints saved by the reference trainer (``{"model": state_dict}``,
+MN/trainer.py:660-683) load unchanged.
 Its weights are the payload of the one RCCL broadcast of the multi-GPU path (``attwarp_amd.dist``).
 """
 from __future__ import annotations
@@ -13,6 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from ._lib import call, ptr, require_gpu, stream_ptr
 
 
@@ -34,6 +37,35 @@ def safe_softmax(logits: torch.Tensor, dim: int = 1, eps: float = 1e-6) -> torch
     if d != logits.dim() - 1:
         out = out.movedim(-1, d)
     return out.to(logits.dtype) if logits.dtype.is_floating_point else out
+
+
+def masked_token_mean(txt_tok: torch.Tensor, txt_mask: torch.Tensor) -> torch.Tensor:
+    """``(txt_tok * txt_mask).sum(1) / txt_mask.sum(1).clamp_min(1)`` (reference :77-78) in one pass.
+    txt_tok [B,Lt,D] float32/float16/bfloat16, txt_mask [B,Lt,1] or [B,Lt] -> [B,D] float32."""
+    dev = require_gpu(txt_tok, txt_mask)
+    tok = txt_tok.detach().contiguous()
+    B, Lt, D = tok.shape
+    mask = txt_mask.detach().float().reshape(B, Lt).contiguous()
+    out = torch.empty(B, D, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        call("attwarp_masked_token_mean", ptr(tok), _lib.dtype_id(tok), ptr(mask), B, Lt, D, ptr(out), stream_ptr(dev))
+    return out
+
+
+def film_axis_means(v: torch.Tensor, gamma_beta: torch.Tensor):
+    """``v = gamma*v + beta; vx = v.mean(2); vy = v.mean(3)`` (reference :80-88) in one pass over ``v``.
+    v [B,Ch,H,W] float32, gamma_beta [B,2*Ch] (``film`` output) -> (vx [B,Ch,W], vy [B,Ch,H])."""
+    dev = require_gpu(v, gamma_beta)
+    x = v.detach().float().contiguous()
+    gb = gamma_beta.detach().float().contiguous()
+    B, Ch, H, W = x.shape
+    if tuple(gb.shape) != (B, 2 * Ch):
+        raise ValueError(f"gamma_beta must be [B, 2*Ch] = {(B, 2 * Ch)}; got {tuple(gb.shape)}")
+    vx = torch.empty(B, Ch, W, device=dev, dtype=torch.float32)
+    vy = torch.empty(B, Ch, H, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        call("attwarp_film_axis_means", ptr(x), ptr(gb), B, Ch, H, W, ptr(vx), ptr(vy), stream_ptr(dev))
+    return vx, vy
 
 
 class MarginalNet(nn.Module):
@@ -70,8 +102,19 @@ class MarginalNet(nn.Module):
         logit_y = self.head_y(v.mean(dim=3)).squeeze(1)
         return logit_x, logit_y
 
+    def forward_logits_fused(self, fmap_v, H: int, W: int, txt_tok, txt_mask):
+        """GPU path of :meth:`forward`: the library GEMMs (convolutions, linear layers) on stock PyTorch-ROCm ops,
+        the memory-bound tail around them on two HIP kernels that read each tensor once
+        (``masked_token_mean``: reference :77-78; ``film_axis_means``: reference :80-88)."""
+        v = self.proj_v(fmap_v.float())
+        if tuple(v.shape[-2:]) != (H, W):       # same-size bilinear (align_corners=False) is the identity
+            v = F.interpolate(v, size=(H, W), mode="bilinear", align_corners=False)
+        t = masked_token_mean(txt_tok, txt_mask)
+        vx, vy = film_axis_means(v, self.film(self.txt_pool(t)))
+        return self.head_x(vx).squeeze(1), self.head_y(vy).squeeze(1)
+
     def forward(self, fmap_v, H: int, W: int, txt_tok, txt_mask):
-        lx, ly = self.forward_logits(fmap_v, H, W, txt_tok, txt_mask)
+        lx, ly = self.forward_logits_fused(fmap_v, H, W, txt_tok, txt_mask)
         return safe_softmax(lx, dim=1, eps=self.eps), safe_softmax(ly, dim=1, eps=self.eps)
 
 

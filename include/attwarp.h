@@ -129,6 +129,17 @@ ATTWARP_API int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int
                                const float* mean, const float* stdv, uint8_t* tmp, void* out, int out_dtype,
                                void* stream);
 
+/* ---- "next" row 1: the memory-bound tail of MarginalNet.forward, MN/model.py:73-88.
+ * masked_token_mean: tok [B,Lt,D] (F32/F16/BF16), mask [B,Lt] float32 (the reference's [B,Lt,1])
+ *   -> out [B,D] float32 = sum_l(float(tok)*mask) / max(sum_l mask, 1)            (model.py:77-78)
+ * film_axis_means: v [B,Ch,H,W] float32, gamma_beta [B,2*Ch] float32 (film output: gamma | beta)
+ *   -> vx [B,Ch,W] = mean over H of (gamma*v + beta), vy [B,Ch,H] = mean over W   (model.py:80-88)
+ *   H*(W+1) <= 4096. */
+ATTWARP_API int attwarp_masked_token_mean(const void* tok, int dtype, const float* mask, int B, int Lt, int D,
+                              float* out, void* stream);
+ATTWARP_API int attwarp_film_axis_means(const float* v, const float* gamma_beta, int B, int Ch, int H, int W,
+                            float* vx, float* vy, void* stream);
+
 /* ---- A5: F.adaptive_avg_pool2d(A,(oh,ow)), call sites MN/trainer.py:197,433,465
  * A [B,H,W] float32 -> out [B,oh,ow] float32 (oh,ow <= 64). */
 ATTWARP_API int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, float* out, void* stream);

@@ -420,6 +420,36 @@ def safe_softmax(logits: np.ndarray, eps: float = 1e-6) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------
+# "next" row 1: MarginalNet's text pooling and FiLM + axis means (MN/model.py:73-88)
+# ---------------------------------------------------------------------------
+
+def masked_token_mean(tok: np.ndarray, mask: np.ndarray) -> np.ndarray:
+    """MN/model.py:77-78: ``denom = mask.sum(1).clamp_min(1); t = (tok * mask).sum(1) / denom``.
+    tok [B,Lt,D] float32, mask [B,Lt] (the reference's [B,Lt,1]) -> [B,D] float32.
+    Products rounded to float32, the token sum accumulated in float64 and rounded once."""
+    tok = np.asarray(tok, F32)
+    m = np.asarray(mask, F32).reshape(tok.shape[0], tok.shape[1], 1)
+    denom = np.maximum(m.astype(F64).sum(axis=1).astype(F32), F32(1.0))              # [B,1]
+    prod = (tok * m).astype(F32)
+    return (prod.astype(F64).sum(axis=1).astype(F32) / denom).astype(F32)
+
+
+def film_axis_means(v: np.ndarray, gamma_beta: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """MN/model.py:80-88: ``gamma, beta = film(t).chunk(2, 1); v = gamma*v + beta; vx = v.mean(2); vy = v.mean(3)``.
+    v [B,Ch,H,W] float32, gamma_beta [B,2*Ch] -> (vx [B,Ch,W], vy [B,Ch,H]).
+    ``gamma*v`` and ``+ beta`` are two float32 roundings (two torch kernels); torch's mean = sum / N with an
+    implementation-defined float32 sum order: accumulated in float64 and rounded once here."""
+    v = np.asarray(v, F32)
+    gb = np.asarray(gamma_beta, F32)
+    B, Ch, H, W = v.shape
+    gamma, beta = gb[:, :Ch, None, None], gb[:, Ch:, None, None]
+    f = ((gamma * v).astype(F32) + beta).astype(F32)
+    vx = (f.astype(F64).sum(axis=2).astype(F32) / F32(H)).astype(F32)
+    vy = (f.astype(F64).sum(axis=3).astype(F32) / F32(W)).astype(F32)
+    return vx, vy
+
+
+# ---------------------------------------------------------------------------
 # A8  right-inverse PDF up-sample
 # ---------------------------------------------------------------------------
 

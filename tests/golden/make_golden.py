@@ -197,8 +197,40 @@ def make_probe_golden(eager_attention_forward, llava):
     np.savez_compressed(os.path.join(OUT, "attn_probe.npz"), **out)
 
 
+def make_marginalnet_tail_golden(model):
+    """"next" row 1 tail: the tensors around the reference MarginalNet's text pooling and FiLM + axis means
+    (MN/model.py:73-88), captured with hooks on the reference module: masked token mean (input of txt_pool),
+    film output, the map before FiLM (proj_v output, bilinearly up-sampled by the reference when sizes differ),
+    vx / vy (inputs of head_x / head_y)."""
+    out = {}
+    for name, (hv, wv, H, W) in {"same": (24, 24, 24, 24), "up": (12, 10, 24, 32)}.items():
+        torch.manual_seed(23)
+        net = model.MarginalNet(d_vis_in=20, d_txt_in=40, hidden=16).eval()
+        fmap = torch.randn(2, 20, hv, wv); ttok = torch.randn(2, 9, 40)
+        tmask = torch.ones(2, 9, 1); tmask[1, 3:] = 0
+        cap = {}
+        hs = [net.txt_pool.register_forward_pre_hook(lambda m, a: cap.__setitem__("tmean", a[0].detach().clone())),
+              net.film.register_forward_hook(lambda m, a, o: cap.__setitem__("gamma_beta", o.detach().clone())),
+              net.proj_v.register_forward_hook(lambda m, a, o: cap.__setitem__("v_proj", o.detach().clone())),
+              net.head_x.register_forward_pre_hook(lambda m, a: cap.__setitem__("vx", a[0].detach().clone())),
+              net.head_y.register_forward_pre_hook(lambda m, a: cap.__setitem__("vy", a[0].detach().clone()))]
+        with torch.no_grad():
+            px, py = net(fmap, H, W, ttok, tmask)
+            v_up = torch.nn.functional.interpolate(cap["v_proj"], size=(H, W), mode="bilinear", align_corners=False)
+        for h in hs:
+            h.remove()
+        out.update({f"{name}_ttok": ttok.numpy(), f"{name}_tmask": tmask.numpy(), f"{name}_tmean": cap["tmean"].numpy(),
+                    f"{name}_gamma_beta": cap["gamma_beta"].numpy(), f"{name}_v": v_up.numpy(),
+                    f"{name}_vx": cap["vx"].numpy(), f"{name}_vy": cap["vy"].numpy(),
+                    f"{name}_fmap": fmap.numpy(), f"{name}_px": px.numpy(), f"{name}_py": py.numpy(),
+                    f"{name}_HW": np.array([H, W])})
+        for k, v in net.state_dict().items():
+            out[f"{name}_sd|{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "marginalnet_tail.npz"), **out)
+
+
 def main():
-    if "--only-probe" not in sys.argv:
+    if "--only-probe" not in sys.argv and "--only-mntail" not in sys.argv:
         make_clip_goldens()
     from transformers.models.llama.modeling_llama import eager_attention_forward
     _install_stubs()
@@ -211,7 +243,11 @@ def main():
     sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
     llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
 
-    make_probe_golden(eager_attention_forward, llava)
+    make_marginalnet_tail_golden(model)
+    if "--only-mntail" in sys.argv:
+        return
+    if "--only-mntail" not in sys.argv:
+        make_probe_golden(eager_attention_forward, llava)
     if "--only-probe" in sys.argv:
         return
 

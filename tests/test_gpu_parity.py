@@ -928,6 +928,62 @@ def test_warp_to_clip_pipeline(dev, golden):
         assert np.array_equal(N(clip[b]), O.clip_preprocess(w[b], 336))
 
 
+@pytest.mark.parametrize("name", ["same", "up"])
+def test_marginalnet_tail_kernels(dev, golden, name):
+    """"next" row 1: masked token mean and FiLM + axis means -- bit-exact vs the oracle, float32-sum-order close
+    to the tensors hooked out of the reference model, and the whole forward (library GEMMs + these kernels +
+    safe_softmax) against the reference's (px, py)."""
+    from attwarp_amd import model
+    g = golden("marginalnet_tail")
+    tok, mask = g[f"{name}_ttok"], g[f"{name}_tmask"]
+    t = N(model.masked_token_mean(T(tok, dev), T(mask, dev)))
+    assert np.array_equal(t, O.masked_token_mean(tok, mask[..., 0]))
+    np.testing.assert_allclose(t, g[f"{name}_tmean"], rtol=0, atol=2e-7)
+    for dt in (torch.float16, torch.bfloat16):                      # the reference's .float() happens in the kernel
+        td = T(tok, dev).to(dt)
+        assert np.array_equal(N(model.masked_token_mean(td, T(mask, dev))),
+                              O.masked_token_mean(N(td.float()), mask[..., 0]))
+    v, gb = g[f"{name}_v"], g[f"{name}_gamma_beta"]
+    vx, vy = model.film_axis_means(T(v, dev), T(gb, dev))
+    ox, oy = O.film_axis_means(v, gb)
+    assert np.array_equal(N(vx), ox) and np.array_equal(N(vy), oy)
+    np.testing.assert_allclose(N(vx), g[f"{name}_vx"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(N(vy), g[f"{name}_vy"], rtol=0, atol=2e-7)
+    H, W = (int(x) for x in g[f"{name}_HW"])
+    net = model.MarginalNet(20, 40, 16).eval()
+    model.load_reference_checkpoint(net, {k.split("|", 1)[1]: torch.from_numpy(g[k]) for k in g.files
+                                          if k.startswith(f"{name}_sd|")})
+    net = net.to(dev)
+    with torch.no_grad():
+        px, py = net(T(g[f"{name}_fmap"], dev), H, W, T(tok, dev), T(mask, dev))
+        lx, ly = net.forward_logits(T(g[f"{name}_fmap"], dev), H, W, T(tok, dev), T(mask, dev))
+        fx, fy = net.forward_logits_fused(T(g[f"{name}_fmap"], dev), H, W, T(tok, dev), T(mask, dev))
+    np.testing.assert_allclose(N(px), g[f"{name}_px"], rtol=2e-4, atol=1e-7)      # MIOpen / rocBLAS vs CPU GEMMs
+    np.testing.assert_allclose(N(py), g[f"{name}_py"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(N(fx), N(lx), rtol=1e-4, atol=1e-5)                # fused tail vs stock-op tail
+    np.testing.assert_allclose(N(fy), N(ly), rtol=1e-4, atol=1e-5)
+
+
+def test_marginalnet_tail_shapes(dev):
+    from attwarp_amd import model, _lib
+    rng = np.random.default_rng(9)
+    for (B, Ch, H, W) in [(3, 5, 24, 24), (2, 7, 17, 33), (1, 3, 63, 64), (5, 2, 1, 9)]:
+        v = rng.standard_normal((B, Ch, H, W)).astype(np.float32)
+        gb = rng.standard_normal((B, 2 * Ch)).astype(np.float32)
+        vx, vy = model.film_axis_means(T(v, dev), T(gb, dev))
+        ox, oy = O.film_axis_means(v, gb)
+        assert np.array_equal(N(vx), ox) and np.array_equal(N(vy), oy), (B, Ch, H, W)
+    with pytest.raises(_lib.AttWarpError, match="4096"):
+        model.film_axis_means(torch.zeros(1, 1, 64, 64, device=dev), torch.zeros(1, 2, device=dev))
+    for (B, Lt, D) in [(2, 1, 5), (3, 37, 300), (1, 8, 4096)]:
+        tok = rng.standard_normal((B, Lt, D)).astype(np.float32)
+        mask = (rng.random((B, Lt)) > 0.4).astype(np.float32)
+        mask[0] = 0                                                       # fully masked sample -> zeros
+        t = N(model.masked_token_mean(T(tok, dev), T(mask, dev)))
+        assert np.array_equal(t, O.masked_token_mean(tok, mask))
+        assert not t[0].any()
+
+
 def test_marginalnet_to_warp_chain(dev, golden):
     """Config-5 chain at toy size: seeded reference weights -> MarginalNet on the GPU -> maps -> warp.
     The network runs on library convolutions (tolerance on px, py); given ITS px, py the rest is bit-exact."""

@@ -106,6 +106,21 @@ def test_register_probe_plumbing_on_hf_llama():
         ae.probe_last_query(torch.rand(2, 4, 16), torch.rand(2, 2, 12, 16), torch.zeros(2, dtype=torch.int32), 8)
 
 
+def test_marginalnet_tail_abi_validation_without_gpu(lib):
+    import ctypes
+    p = ctypes.cast(ctypes.create_string_buffer(256), ctypes.c_void_p)
+    assert lib.attwarp_masked_token_mean(p, 3, p, 1, 4, 8, p, None) == -1          # uint8 tokens
+    assert lib.attwarp_masked_token_mean(p, 0, None, 1, 4, 8, p, None) == -1       # null mask
+    assert lib.attwarp_masked_token_mean(p, 0, p, 1, 0, 8, p, None) == -1          # Lt = 0
+    assert lib.attwarp_film_axis_means(p, p, 1, 2, 64, 64, p, p, None) == -2       # tile too large
+    assert lib.attwarp_film_axis_means(p, None, 1, 2, 4, 4, p, p, None) == -1
+    from attwarp_amd import model
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.masked_token_mean(torch.rand(2, 3, 8), torch.ones(2, 3, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model.film_axis_means(torch.rand(2, 4, 6, 6), torch.rand(2, 8))
+
+
 def test_no_cpu_fallback():
     from attwarp_amd import checkpoint_utils as cu, model, attention_extraction as ae
     with pytest.raises(RuntimeError, match="no CPU fallback"):

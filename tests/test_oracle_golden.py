@@ -338,3 +338,19 @@ def test_clip_preprocess_vs_hf_processor(golden, name):
     d = clip_digest(out)
     assert np.array_equal(d["sub"], g[f"{name}_sub"])
     assert int(d["sum_bits"]) == int(g[f"{name}_sum_bits"]) and int(d["wsum_bits"]) == int(g[f"{name}_wsum_bits"])
+
+
+# ---- "next" row 1: MarginalNet tail ---------------------------------------------
+@pytest.mark.parametrize("name", ["same", "up"])
+def test_marginalnet_tail_vs_reference_hooks(golden, name):
+    """masked token mean and FiLM + axis means against tensors captured with hooks on the reference MarginalNet."""
+    g = golden("marginalnet_tail")
+    t = O.masked_token_mean(g[f"{name}_ttok"], g[f"{name}_tmask"][..., 0])
+    np.testing.assert_allclose(t, g[f"{name}_tmean"], rtol=0, atol=2e-7)          # torch's float32 sum order
+    vx, vy = O.film_axis_means(g[f"{name}_v"], g[f"{name}_gamma_beta"])
+    assert vx.shape == g[f"{name}_vx"].shape and vy.shape == g[f"{name}_vy"].shape
+    np.testing.assert_allclose(vx, g[f"{name}_vx"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(vy, g[f"{name}_vy"], rtol=0, atol=2e-7)
+    # a fully masked sample divides by the clamp, not by zero
+    z = O.masked_token_mean(g[f"{name}_ttok"], np.zeros_like(g[f"{name}_tmask"][..., 0]))
+    assert np.array_equal(z, np.zeros_like(z))

@@ -44,3 +44,25 @@ for (B, S) in [(256, 1024), (64, 336)]:
         rep(f"clip_preprocess 500->336 u8 -> f16 [B,3,336,336] B={B}", timeit(lambda: pipeline.clip_preprocess(w500)), B*(500*500*3 + 3*336*336*2))
         rep(f"pipeline.warp_from_masks (main_batched chain) B={B}", timeit(lambda: pipeline.warp_from_masks(img8, m24)), B*(S*S*3 + 500*500*3))
     del A, a3, au8, rows, r16, img8
+# "next" row 1: MarginalNet(1024, 4096, 256) tail at config-5 shapes, fused kernels vs the stock ops of the reference
+B = 256
+v = torch.randn(B, 256, 24, 24, device=dev); gb = torch.randn(B, 512, device=dev)
+tok = torch.randn(B, 32, 4096, device=dev); msk = (torch.rand(B, 32, 1, device=dev) > 0.3).float()
+def stock_film():
+    g, b_ = gb.chunk(2, dim=1)
+    w = g[:, :, None, None] * v + b_[:, :, None, None]
+    return w.mean(dim=2), w.mean(dim=3)
+def stock_tmean():
+    return (tok * msk).sum(dim=1) / msk.sum(dim=1).clamp_min(1.0)
+rep(f"film_axis_means fused B={B} Ch=256 24x24", timeit(lambda: model.film_axis_means(v, gb)), v.numel() * 4)
+rep(f"film + 2 means, stock torch ops B={B}", timeit(stock_film), v.numel() * 4)
+rep(f"masked_token_mean fused B={B} Lt=32 D=4096", timeit(lambda: model.masked_token_mean(tok, msk)), tok.numel() * 4)
+rep(f"masked mean, stock torch ops B={B}", timeit(stock_tmean), tok.numel() * 4)
+net = model.MarginalNet(1024, 4096, 256).to(dev).eval()
+fmap = torch.randn(B, 1024, 24, 24, device=dev)
+with torch.no_grad():
+    rep(f"MarginalNet forward (GEMMs stock + fused tail) B={B}", timeit(lambda: net(fmap, 24, 24, tok, msk), 5), fmap.numel() * 4)
+    def stock_fwd():
+        lx, ly = net.forward_logits(fmap, 24, 24, tok, msk)
+        return model.safe_softmax(lx), model.safe_softmax(ly)
+    rep(f"MarginalNet forward (all stock ops + safe_softmax) B={B}", timeit(stock_fwd, 5), fmap.numel() * 4)
