@@ -501,25 +501,17 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
   return ATTWARP_OK;
 }
 
-extern "C" int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int w, int C, int top, int left, int size,
-                                          const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
-                                          const int32_t* bounds_y, const int32_t* kk_y, int ksize_y,
-                                          const float* mean, const float* stdv /* host, C floats each */,
-                                          uint8_t* tmp, void* out, int out_dtype, void* stream) {
-  ATTWARP_REQUIRE(src && bounds_x && kk_x && bounds_y && kk_y && mean && stdv && tmp && out,
-                  "clip_preprocess_u8: null pointer");
-  ATTWARP_REQUIRE(B > 0 && h > 0 && w > 0 && size > 0 && top >= 0 && left >= 0 && ksize_x > 0 && ksize_y > 0,
-                  "clip_preprocess_u8: bad size");
-  ATTWARP_REQUIRE(C >= 1 && C <= 4, "clip_preprocess_u8: C must be 1..4 (got %d)", C);
-  ATTWARP_REQUIRE(out_dtype == ATTWARP_F32 || out_dtype == ATTWARP_F16, "clip_preprocess_u8: out dtype must be F32 or F16");
-  if (B > 65535 || h > 65535 || size > 65535) return fail(ATTWARP_E_UNSUPPORTED, "clip_preprocess_u8: dims > 65535");
-  hipStream_t st = as_stream(stream);
+namespace attwarp {
+// Generic two-kernel form (one thread per output element, global byte taps): any size; clip.hip holds the
+// LDS-staged kernels that take the common shapes and calls this one otherwise.
+int clip_preprocess_generic(const uint8_t* src, int B, int h, int w, int C, int top, int left, int size,
+                            const int32_t* bounds_x, const int32_t* kk_x, int ksize_x, const int32_t* bounds_y,
+                            const int32_t* kk_y, int ksize_y, const float* m, const float* s, uint8_t* tmp, void* out,
+                            int out_dtype, hipStream_t st) {
   hipLaunchKernelGGL(resample8_h_kernel, dim3((size * C + NT - 1) / NT, h, B), dim3(NT), 0, st, src, h, w, C, left, size,
                      bounds_x, kk_x, ksize_x, tmp);
   int rc = check_launch("resample8_h_kernel");
   if (rc) return rc;
-  float m[4] = {0, 0, 0, 0}, s[4] = {1, 1, 1, 1};
-  for (int c = 0; c < C; ++c) { m[c] = mean[c]; s[c] = stdv[c]; }
   const dim3 grid((size + NT - 1) / NT, size, B);
   if (out_dtype == ATTWARP_F32)
     hipLaunchKernelGGL((clip_v_kernel<float>), grid, dim3(NT), 0, st, tmp, h, C, top, size, size, bounds_y, kk_y,
@@ -529,3 +521,4 @@ extern "C" int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int 
                        ksize_y, m[0], m[1], m[2], m[3], s[0], s[1], s[2], s[3], (__half*)out);
   return check_launch("clip_v_kernel");
 }
+}  // namespace attwarp

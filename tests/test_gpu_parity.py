@@ -915,6 +915,39 @@ def test_clip_preprocess_bit_exact(dev, golden, name):
     assert np.array_equal(N(half[0]), got[0].astype(np.float16))
 
 
+@pytest.mark.parametrize("shape", [
+    (3, 500, 500, 3, 336),     # the main_batched output: 7 taps, rows of 1500 bytes (dword staging)
+    (2, 333, 517, 3, 224),     # landscape with crop, source rows not a multiple of 4 bytes (byte staging)
+    (2, 517, 333, 3, 224),     # portrait
+    (2, 1100, 1100, 3, 336),   # 15 taps: the 16-coefficient variant
+    (1, 2000, 1900, 3, 336),   # 25 taps: generic kernels
+    (2, 400, 400, 1, 336),     # one channel
+    (2, 400, 420, 4, 336),     # four channels
+    (2, 300, 300, 3, 335),     # output rows of 1005 bytes: generic kernels
+    (2, 200, 260, 3, 336),     # up-scaling
+])
+def test_clip_preprocess_staged_equals_generic(dev, shape):
+    """The LDS-staged kernels against the one-thread-per-output form (itself pinned to the HF processor by the
+    goldens) and, for RGB, against the oracle: bit-for-bit, float32 and float16."""
+    from attwarp_amd import pipeline
+    B, H, W, C, size = shape
+    rng = np.random.default_rng(H * 31 + W)
+    img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+    mean, std = (0.4, 0.5, 0.6, 0.7)[:C], (0.2, 0.3, 0.25, 0.35)[:C]
+    x = T(img, dev)
+    for dt in (torch.float32, torch.float16):
+        a = pipeline.clip_preprocess(x, size, dt, mean, std)
+        os.environ["ATTWARP_CLIP_VARIANT"] = "g"
+        try:
+            b = pipeline.clip_preprocess(x, size, dt, mean, std)
+        finally:
+            os.environ.pop("ATTWARP_CLIP_VARIANT", None)
+        assert a.shape == (B, C, size, size) and torch.equal(a, b), (shape, dt)
+    if C == 3 and H * W <= 600 * 600:
+        got = N(pipeline.clip_preprocess(x, size, torch.float32))
+        assert np.array_equal(got[0], O.clip_preprocess(img[0], size))
+
+
 def test_warp_to_clip_pipeline(dev, golden):
     """main_batched chain + CLIP epilogue with nothing leaving the GPU: masks -> 500x500 uint8 warp -> [B,3,336,336]."""
     from attwarp_amd import pipeline
