@@ -2,15 +2,18 @@
 // images, typically 336x336 -> 500x500).  Same decomposition as remap_rows_kernel (remap_rows.hip): one
 // workgroup owns R consecutive output rows of one image, vertical lerp first into an LDS float row, then
 // the horizontal gather.  Arithmetic is the uint8 "exact" path of remap_gather_kernel / the oracle:
-// bytes -> float32, three individually rounded lerps, round half to even, clamp to [0,255].
+// bytes -> float32, three individually rounded lerps, round half to even (a lerp of values in [0,255] with a
+// weight in [0,1) stays in [0,255] after every rounding, so no clamp is needed).
 //
-// uint8 rows are small (W*C <= 4096 bytes), so the structure is simpler than the float kernel:
-//   * each thread owns ONE 16-byte piece of a source row (global_load_dwordx4, 4-byte aligned); both
+// This kernel is bound by instruction issue, not by HBM (1500 output bytes per row, each needing two LDS taps
+// and a lerp), so the work per byte is kept minimal and spread over all four waves:
+//   * vertical pass: every thread owns dwords of the source row (4 bytes: global_load_dword, coalesced); both
 //     source rows of the NEXT output row are fetched while the current row is gathered (static double
-//     buffering, no row cache: the re-read of a shared row is an L1/L2 hit, HBM sees every byte once);
-//   * 16 lerps per thread -> 4 x ds_write_b128 into the float row;
-//   * gather: one output byte per lane per k-slice (consecutive lanes -> consecutive LDS banks), four
-//     neighbouring lanes are packed into one dword with DPP row shifts and every 4th lane stores it.
+//     buffering; the re-read of a shared row is an L1/L2 hit, HBM sees every byte once); 4 lerps ->
+//     one ds_write_b128 into the float row;
+//   * gather: one output byte per lane per k-slice (consecutive lanes -> consecutive LDS banks), the byte goes
+//     to an LDS output row; the row is written to global as dwords, 256 contiguous bytes per wave
+//     instruction, after the NEXT row's barrier (the barrier between the two passes is the only one per row).
 #include "common.hpp"
 
 namespace attwarp {
@@ -48,36 +51,18 @@ struct Params {
   int R, nblk, nblocks;
 };
 
-struct __attribute__((packed, aligned(4))) U4 {
-  uint32_t x, y, z, w;
-};
-
-__device__ __forceinline__ void blend16(const U4& a, const U4& c, float fy, float* out) {
-  const uint32_t wa[4] = {a.x, a.y, a.z, a.w}, wc[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float4 v;
-    v.x = lerp_rn((float)(wa[i] & 0xffu), (float)(wc[i] & 0xffu), fy);
-    v.y = lerp_rn((float)((wa[i] >> 8) & 0xffu), (float)((wc[i] >> 8) & 0xffu), fy);
-    v.z = lerp_rn((float)((wa[i] >> 16) & 0xffu), (float)((wc[i] >> 16) & 0xffu), fy);
-    v.w = lerp_rn((float)(wa[i] >> 24), (float)(wc[i] >> 24), fy);
-    reinterpret_cast<float4*>(out)[i] = v;
-  }
-}
-
-// row shift left by n inside a DPP row of 16 lanes: lane i reads lane i+n (0 if it leaves the row)
-template <int N>
-__device__ __forceinline__ uint32_t dpp_shl(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
-}
-
-template <int KO, bool HWC>
+// KI = dwords of the source row per thread, KO = output bytes per thread, KS = output dwords per thread
+template <int KI, int KO, bool HWC>
 __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KS = (KO + 3) / 4;
   float* s_my = smem;                      // RMAX
   float* row0 = smem + RMAX;               // 2 float rows of VLP floats
   const int VLP = (p.VL + 15) & ~15;
   float* row1 = row0 + VLP;
+  constexpr int OVP = NT * KO;                              // whole k-slices: no index clamp in the gather
+  uint8_t* out0 = reinterpret_cast<uint8_t*>(row1 + VLP);   // 2 output rows of OVP bytes
+  uint8_t* out1 = out0 + OVP;
   const int tid = threadIdx.x;
 
   int bid = blockIdx.x;
@@ -94,77 +79,137 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
 
   if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
 
-  // the 16-byte piece of a source row this thread owns: ppp pieces per plane, the last piece of a plane is
-  // shifted back so that it ends with the plane row (overlapping pieces write identical values)
-  const int ppp = (p.row_len + 15) >> 4;
-  const bool loader = tid < ppp * p.NP;
-  const int ppl = min(tid / ppp, p.NP - 1);
-  const int pin = min((tid - ppl * ppp) * 16, p.row_len - 16);
-  const int voff = ppl * p.row_len + pin;            // byte offset inside the virtual row (= float index in LDS)
-  const int goff = (int)(ppl * p.plane_stride) + pin; // byte offset inside the image, row 0
-
-  // column taps
+  // source dwords this thread owns (clamped: padding lanes re-read the last dword and write the same floats)
+  int goff[KI], voff[KI];   // byte offset inside the image (row 0) / float index in the LDS row
+  {
+    const int dpr = p.row_len >> 2, nd = p.VL >> 2;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int d = min(tid + NT * k, nd - 1);
+      const int pl = HWC ? 0 : d / dpr;
+      goff[k] = (int)(pl * p.plane_stride) + 4 * (d - pl * dpr);
+      voff[k] = 4 * d;
+    }
+  }
+  // column taps of the output bytes this thread gathers.  Interleaved rows: element e = x*CS + c advances by NT
+  // per k-slice, so (x, c) is stepped with one carry instead of a division per element.
   unsigned pk[KO];
   float fxr[KO];
-  unsigned ooff[KO];
+  {
+    const int dx = NT / p.CS, dc = NT - dx * p.CS;       // block uniform
+    int x = HWC ? tid / p.CS : 0, c = HWC ? tid - x * p.CS : 0;
 #pragma unroll
-  for (int k = 0; k < KO; ++k) {
-    const int e = min(tid + NT * k, p.OVL - 1);
-    const int pl = HWC ? 0 : e / p.orow_len;
-    const int r = e - pl * p.orow_len;
-    const int x = r / p.CS;
-    const int c = r - x * p.CS;
-    const Taps tx = taps(p.mx[(long long)b * p.Wo + x], p.W);
-    const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;
-    const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + c;
-    pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
-    fxr[k] = tx.f;
-    ooff[k] = (unsigned)(pl * p.oplane_stride) + (unsigned)r;
+    for (int k = 0; k < KO; ++k) {
+      int pl = 0, xe = x, ce = c;
+      if (HWC) {
+        if (tid + NT * k > p.OVL - 1) { xe = p.Wo - 1; ce = p.CS - 1; }     // padding lanes repeat the last element
+        x += dx; c += dc;
+        if (c >= p.CS) { c -= p.CS; ++x; }
+      } else {                                            // planar: CS == 1
+        const int e = min(tid + NT * k, p.OVL - 1);
+        pl = e / p.orow_len;
+        xe = e - pl * p.orow_len;
+        ce = 0;
+      }
+      const Taps tx = taps(p.mx[(long long)b * p.Wo + xe], p.W);
+      const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + ce;
+      const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + ce;
+      pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
+      fxr[k] = tx.f;
+    }
+  }
+  // output dwords this thread stores (byte offset inside an output row of the image, incl. plane)
+  int soff[KS], sld[KS];      // ... and where that dword sits in the LDS output row (clamped: padding lanes repeat the last)
+  {
+    const int dpo = p.orow_len >> 2, nd = p.OVL >> 2;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int d = min(tid + NT * k, nd - 1);
+      const int pl = HWC ? 0 : d / dpo;
+      soff[k] = (int)(pl * p.oplane_stride) + 4 * (d - pl * dpo);
+      sld[k] = 4 * d;
+    }
   }
   __syncthreads();
 
-  auto load_piece = [&](int srow) -> U4 {
-    U4 v = {0u, 0u, 0u, 0u};
-    if (loader) v = *reinterpret_cast<const U4*>(src_b + (long long)srow * p.row_len + goff);
-    return v;
-  };
-
   Taps tcur = taps(s_my[0], p.H);
-  U4 A = load_piece(tcur.i0), C = load_piece(tcur.i1);
-  for (int q = 0; q < nrows; ++q) {
-    float* rowbuf = (q & 1) ? row1 : row0;
-    if (loader) blend16(A, C, tcur.f, rowbuf + voff);
-    if (q + 1 < nrows) {                             // fetch the next output row's two source rows now
-      tcur = taps(s_my[q + 1], p.H);
-      A = load_piece(tcur.i0);
-      C = load_piece(tcur.i1);
-    }
-    __syncthreads();
-    const char* rowb = reinterpret_cast<const char*>(rowbuf);
-    uint8_t* orow = dst_b + (long long)(y0 + q) * p.orow_len;
-#pragma unroll
-    for (int k = 0; k < KO; ++k) {
-      unsigned w = pk[k];
-      asm volatile("" : "+v"(w));
-      const float v0 = *reinterpret_cast<const float*>(rowb + (w & 0xffffu));
-      const float v1 = *reinterpret_cast<const float*>(rowb + (w >> 16));
-      const float o = lerp_rn(v0, v1, fxr[k]);
-      const uint32_t r8 = (uint32_t)fminf(fmaxf(rintf(o), 0.0f), 255.0f);
-      const uint32_t packed = r8 | (dpp_shl<1>(r8) << 8) | (dpp_shl<2>(r8) << 16) | (dpp_shl<3>(r8) << 24);
-      if ((tid & 3) == 0 && tid + NT * k < p.OVL) *reinterpret_cast<uint32_t*>(orow + ooff[k]) = packed;
-    }
+  uint32_t A[KI], C[KI];
+#define ATTWARP_U8_FETCH()                                                                             \
+  _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                      \
+    A[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)tcur.i0 * p.row_len + goff[k]);        \
+    C[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)tcur.i1 * p.row_len + goff[k]);        \
   }
+  // the output row finished one iteration ago: LDS bytes -> global dwords
+#define ATTWARP_U8_FLUSH(obuf, yrow)                                                                   \
+  {                                                                                                    \
+    uint8_t* orow_ = dst_b + (long long)(yrow) * p.orow_len;                                            \
+    _Pragma("unroll") for (int k = 0; k < KS; ++k)                                                      \
+        *reinterpret_cast<uint32_t*>(orow_ + soff[k]) = *reinterpret_cast<const uint32_t*>((obuf) + sld[k]);  \
+  }
+  // one output row: vertical lerp -> rowbuf, prefetch, barrier, flush the previous row, gather -> outbuf.
+  // rowbuf / outbuf / prevbuf are the two fixed LDS buffers (immediate offsets), hence the 2x unrolled loop below.
+#define ATTWARP_U8_ROW(q_, rowbuf, outbuf, prevbuf)                                                    \
+  {                                                                                                    \
+    const float fy_ = tcur.f;                                                                          \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
+      float4 v_;                                                                                       \
+      v_.x = lerp_rn((float)(A[k] & 0xffu), (float)(C[k] & 0xffu), fy_);                               \
+      v_.y = lerp_rn((float)((A[k] >> 8) & 0xffu), (float)((C[k] >> 8) & 0xffu), fy_);                 \
+      v_.z = lerp_rn((float)((A[k] >> 16) & 0xffu), (float)((C[k] >> 16) & 0xffu), fy_);               \
+      v_.w = lerp_rn((float)(A[k] >> 24), (float)(C[k] >> 24), fy_);                                   \
+      *reinterpret_cast<float4*>((rowbuf) + voff[k]) = v_;                                             \
+    }                                                                                                  \
+    if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
+      tcur = taps(s_my[(q_) + 1], p.H);                                                                \
+      ATTWARP_U8_FETCH()                                                                               \
+    }                                                                                                  \
+    __syncthreads();                                                                                   \
+    if ((q_) > 0) ATTWARP_U8_FLUSH(prevbuf, y0 + (q_) - 1)                                             \
+    const char* rowb_ = reinterpret_cast<const char*>(rowbuf);                                         \
+    _Pragma("unroll") for (int k = 0; k < KO; ++k) {                                                    \
+      unsigned w_ = pk[k];                                                                             \
+      asm volatile("" : "+v"(w_));                                                                     \
+      const float v0_ = *reinterpret_cast<const float*>(rowb_ + (w_ & 0xffffu));                       \
+      const float v1_ = *reinterpret_cast<const float*>(rowb_ + (w_ >> 16));                           \
+      /* round half to even: the low byte of (x + 2^23) for 0 <= x <= 255 */                           \
+      const float r_ = fadd(lerp_rn(v0_, v1_, fxr[k]), 8388608.0f);                                    \
+      (outbuf)[tid + NT * k] = (uint8_t)__float_as_uint(r_);                                           \
+    }                                                                                                  \
+  }
+  ATTWARP_U8_FETCH()
+  int q = 0;
+  for (; q + 1 < nrows; q += 2) {
+    ATTWARP_U8_ROW(q, row0, out0, out1)
+    ATTWARP_U8_ROW(q + 1, row1, out1, out0)
+  }
+  if (q < nrows) ATTWARP_U8_ROW(q, row0, out0, out1)
+  __syncthreads();
+  if ((nrows - 1) & 1) ATTWARP_U8_FLUSH(out1, y0 + nrows - 1) else ATTWARP_U8_FLUSH(out0, y0 + nrows - 1)
+#undef ATTWARP_U8_ROW
+#undef ATTWARP_U8_FLUSH
+#undef ATTWARP_U8_FETCH
+}
+
+template <int KI, int KO>
+static int launch_kiko(const Params& p, hipStream_t st) {
+  const int VLP = (p.VL + 15) & ~15, OVP = NT * KO;
+  const size_t lds = (size_t)(RMAX + 2 * VLP) * sizeof(float) + 2 * (size_t)OVP;
+  if (p.NP == 1)
+    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, true>), dim3(p.nblocks), dim3(NT), lds, st, p);
+  else
+    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, false>), dim3(p.nblocks), dim3(NT), lds, st, p);
+  return check_launch("remap_rows_u8_kernel");
 }
 
 template <int KO>
 static int launch_ko(const Params& p, hipStream_t st) {
-  const int VLP = (p.VL + 15) & ~15;
-  const size_t lds = (size_t)(RMAX + 2 * VLP) * sizeof(float);
-  if (p.NP == 1)
-    hipLaunchKernelGGL((remap_rows_u8_kernel<KO, true>), dim3(p.nblocks), dim3(NT), lds, st, p);
-  else
-    hipLaunchKernelGGL((remap_rows_u8_kernel<KO, false>), dim3(p.nblocks), dim3(NT), lds, st, p);
-  return check_launch("remap_rows_u8_kernel");
+  const int ki = ((p.VL >> 2) + NT - 1) / NT;
+  switch (ki) {
+    case 1: return launch_kiko<1, KO>(p, st);
+    case 2: return launch_kiko<2, KO>(p, st);
+    case 3: return launch_kiko<3, KO>(p, st);
+    default: return launch_kiko<4, KO>(p, st);
+  }
 }
 
 }  // namespace u8k
@@ -184,13 +229,12 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.orow_len = Wo * p.CS;
   const long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
   // dword loads / stores: every plane row must start on a 4-byte boundary, both sides
-  if (p.row_len % 4 != 0 || p.orow_len % 4 != 0 || p.row_len < 16) return ATTWARP_OK;
+  if (p.row_len % 4 != 0 || p.orow_len % 4 != 0) return ATTWARP_OK;
   if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0) return ATTWARP_OK;
   if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
                             : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0)
     return ATTWARP_OK;
   if (VL > 4096 || OVL > 4096) return ATTWARP_OK;           // 16-bit LDS offsets
-  if ((long long)p.NP * ((p.row_len + 15) / 16) > u8k::NT) return ATTWARP_OK;   // one 16-byte piece per thread
   p.VL = (int)VL;
   p.OVL = (int)OVL;
   p.plane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)H * W;
@@ -198,7 +242,7 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.img_stride = (long long)H * W * C;
   p.oimg_stride = (long long)Ho * Wo * C;
   if (p.plane_stride * p.NP > 2147483647LL || p.oplane_stride * p.NP > 2147483647LL) return ATTWARP_OK;
-  int R = 16;
+  int R = (OVL >= 2048) ? 32 : 16;   // measured: 1024x1024x3 R=32 7 % faster than 16, 336->500 equal
   if (const char* renv = getenv("ATTWARP_REMAP_ROWS")) { int v = atoi(renv); if (v >= 1 && v <= u8k::RMAX) R = v; }
   if (R > Ho) R = Ho;
   p.R = R;
