@@ -71,10 +71,43 @@ static bool pw_build(int n, PairwisePlan& P) {
   return true;
 }
 
+// The same plan built on the device into LDS (by one thread; <= 2*128 steps): a plan passed by value and
+// indexed dynamically is copied to scratch by the compiler (2.5 KB per lane for the two plans of the A13 finalize
+// kernel, which then spent most of its 34 us on that copy).
+struct PlanLds {
+  int off[PW_MAX_LEAVES];
+  int len[PW_MAX_LEAVES];
+  unsigned char prog[2 * PW_MAX_LEAVES];
+  int nleaves, nprog;
+  int stack[3 * 24];          // explicit recursion stack: (offset, n, phase)
+};
+__device__ inline void pw_build_lds(int n, PlanLds* P) {   // call from ONE thread, then barrier
+  int sp = 0, nl = 0, np = 0;
+  int* st = P->stack;
+  st[0] = 0; st[1] = n; st[2] = 0; sp = 1;
+  while (sp > 0) {
+    --sp;
+    const int o = st[3 * sp], m = st[3 * sp + 1], ph = st[3 * sp + 2];
+    if (ph == 1) { P->prog[np++] = 1; continue; }
+    if (m <= 128) {
+      P->off[nl] = o; P->len[nl] = m; ++nl;
+      P->prog[np++] = 0;
+      continue;
+    }
+    int n2 = m / 2;
+    n2 -= n2 % 8;
+    st[3 * sp] = o; st[3 * sp + 1] = m; st[3 * sp + 2] = 1; ++sp;                 // combine after both halves
+    st[3 * sp] = o + n2; st[3 * sp + 1] = m - n2; st[3 * sp + 2] = 0; ++sp;       // right half (popped second)
+    st[3 * sp] = o; st[3 * sp + 1] = n2; st[3 * sp + 2] = 0; ++sp;                // left half (popped first)
+  }
+  P->nleaves = nl;
+  P->nprog = np;
+}
+
 // Evaluate the postfix program for one row given its leaf sums (`leaf(j)` returns leaf j).
 // `stack` is per-thread storage with stride `sstride` doubles (LDS), depth <= 10.
-template <typename LeafFn>
-__device__ __forceinline__ double pw_combine(const PairwisePlan& P, LeafFn leaf, double* stack, int sstride) {
+template <typename Plan, typename LeafFn>
+__device__ __forceinline__ double pw_combine(const Plan& P, LeafFn leaf, double* stack, int sstride) {
   int sp = 0, next = 0;
   for (int i = 0; i < P.nprog; ++i) {
     if (P.prog[i] == 0) {
@@ -93,7 +126,8 @@ __device__ __forceinline__ double pw_combine(const PairwisePlan& P, LeafFn leaf,
 // eight strided accumulators of one leaf (32 leaves per pass), an xor-butterfly over those lanes is exactly
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), lane 0 of the group adds the leaf's tail, thread 0 runs the tree.
 // leafbuf: LDS, PW_MAX_LEAVES doubles.  Result valid in ALL threads.  Ends with a barrier.
-__device__ inline double pw_sum_block(const double* a, const PairwisePlan& P, double* leafbuf) {
+template <typename Plan>
+__device__ __forceinline__ double pw_sum_block(const double* a, const Plan& P, double* leafbuf) {
   const int tid = threadIdx.x, k = tid & 7;
   for (int l0 = 0; l0 < P.nleaves; l0 += NT / 8) {
     const int j = l0 + (tid >> 3);
@@ -120,13 +154,13 @@ __device__ inline double pw_sum_block(const double* a, const PairwisePlan& P, do
   }
   __syncthreads();
   if (tid == 0) {
-    double stack[12];
+    // the postfix program never needs more stack than leaves consumed: run it in place on leafbuf
+    // (slot sp <= next - 1 at every push, so a push never overwrites an unread leaf)
     int sp = 0, next = 0;
     for (int i = 0; i < P.nprog; ++i) {
-      if (P.prog[i] == 0) { if (sp < 12) stack[sp] = leafbuf[next]; ++next; ++sp; }
-      else { stack[sp - 2] = stack[sp - 2] + stack[sp - 1]; --sp; }
+      if (P.prog[i] == 0) { leafbuf[sp] = leafbuf[next]; ++next; ++sp; }
+      else { leafbuf[sp - 2] = leafbuf[sp - 2] + leafbuf[sp - 1]; --sp; }
     }
-    leafbuf[0] = stack[0];
   }
   __syncthreads();
   const double tot = leafbuf[0];
@@ -134,67 +168,99 @@ __device__ inline double pw_sum_block(const double* a, const PairwisePlan& P, do
   return tot;
 }
 
-template <typename T> struct TileT { using type = float; };        // uint8 / float32 are exact in float
-template <> struct TileT<double> { using type = double; };
-
-constexpr int RBAND = 64;    // rows per LDS tile
-constexpr int TSTR = RBAND + 1;
+constexpr int RBAND = 32;     // rows per LDS tile
+constexpr int TSTR = 128 + 8; // tile row stride in doubles: 8 rows x 8 accumulators spread evenly over the banks
 
 // ---- single pass over [B,H,W]: column sums AND per-leaf row sums ---------------------------------
-// grid = (nleaves, B); block = 256.  The block owns one leaf (a strip of <= 128 columns) and walks all
-// H rows in bands of 64 through an LDS tile (raw values, transposed, padded):
-//   threads   0..127 : column c of the strip, running sum over rows in ascending order = the order
-//                      np.sum(axis=0) uses, so the x profile is bit-identical to numpy's;
-//   threads 128..191 : row r of the band, numpy's 8-accumulator leaf sum over the strip's columns;
-//   all 256 threads load (coalesced along the row).
+// grid = (nleaves, B); block = 256.  The block owns one leaf (a strip of <= 128 columns) and walks all H rows
+// in bands of 32 through an LDS tile of TRANSFORMED values (double, row major): the element transform (clamp,
+// square / sqrt / exp / log, bias) runs once per element, by the thread that loaded it.
+//   load     : thread (quad q = tid & 31, row tid >> 5 (+8 per pass)) reads 4 consecutive columns with one
+//              vector load when the rows are 4-element aligned; the NEXT band's loads are issued before this
+//              band is reduced;
+//   columns  : thread c < len keeps the running sum of column c over rows in ascending order = the order
+//              np.sum(axis=0) uses, so the x profile is bit-identical to numpy's;
+//   rows     : 8 lanes per row own numpy's 8 strided accumulators of the leaf, an xor butterfly over them is
+//              exactly ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), lane 0 adds the tail.
 // leaf sums go to ls[b][row][leaf]; the per-row tree over leaves runs in the finalize kernels.
+template <typename T>
+struct alignas(4 * sizeof(T)) Quad4 {
+  T v[4];
+};
+
 template <typename T, typename XF>
 __global__ __launch_bounds__(NT) void profiles_kernel(const T* __restrict__ A, int H, int W, XF xf,
                                                       const PairwisePlan P, double* __restrict__ col,
-                                                      double* __restrict__ ls) {
-  using TT = typename TileT<T>::type;
-  __shared__ TT tile[128 * TSTR];
+                                                      double* __restrict__ ls, int vec_ok) {
+  __shared__ __attribute__((aligned(16))) double tile[RBAND * TSTR];
   const int leaf = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int off = P.off[leaf], len = P.len[leaf], nleaves = P.nleaves;
   const T* base = A + (size_t)b * H * W + off;
-  const int c = tid & 127, rr = tid >> 7;
+  const int qc = 4 * (tid & 31), qr = tid >> 5;          // this thread's 4 columns / first row of a band
+  const int rrow = tid >> 3, rk = tid & 7;               // row task: (row of the band, accumulator)
+  const int len8 = len - (len % 8);
+  constexpr int NPASS = RBAND / 8;
+  Quad4<T> raw[NPASS];
+
+  // (vector loads may run up to 3 elements past the strip inside the row: W % 4 == 0 keeps them inside the image)
+#define ATTWARP_PROFILES_FETCH(row0_)                                                        \
+  _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                      \
+    const int r_ = (row0_) + qr + 8 * ps;                                                    \
+    if (r_ < H && qc < len) {                                                                \
+      const T* src_ = base + (size_t)r_ * W + qc;                                            \
+      if (vec_ok) {                                                                          \
+        raw[ps] = *reinterpret_cast<const Quad4<T>*>(src_);                                  \
+      } else {                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) raw[ps].v[j] = (qc + j < len) ? src_[j] : T(0); \
+      }                                                                                      \
+    }                                                                                        \
+  }
+  ATTWARP_PROFILES_FETCH(0)
   double cacc = 0.0;
   for (int row0 = 0; row0 < H; row0 += RBAND) {
     const int nb = min(RBAND, H - row0);
-    if (c < len) {
-      for (int r = rr; r < nb; r += 2) tile[c * TSTR + r] = (TT)base[(size_t)(row0 + r) * W + c];
+    if (qc < len) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int r = qr + 8 * ps;
+        if (r < nb) {
+          double* d = tile + r * TSTR + qc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[j] = xf((double)raw[ps].v[j]);
+        }
+      }
     }
     __syncthreads();
-    if (tid < 128) {
-      if (tid < len) {
-        const TT* tc = tile + tid * TSTR;
-        for (int r = 0; r < nb; ++r) cacc = cacc + xf((double)tc[r]);
+    if (row0 + RBAND < H) ATTWARP_PROFILES_FETCH(row0 + RBAND)
+    // rows: numpy's leaf sum of row rrow over the strip
+    {
+      const double* tr = tile + rrow * TSTR;
+      double r = 0.0;
+      if (rrow < nb && len >= 8) {
+        r = tr[rk];
+        for (int j = 8; j < len8; j += 8) r += tr[j + rk];
       }
-    } else if (tid < 128 + RBAND) {
-      const int r = tid - 128;
-      if (r < nb) {
-        const TT* tr = tile + r;
-        double res;
+      r += __shfl_xor(r, 1, WAVE);
+      r += __shfl_xor(r, 2, WAVE);
+      r += __shfl_xor(r, 4, WAVE);
+      if (rrow < nb && rk == 0) {
         if (len < 8) {
-          res = 0.0;
-          for (int j = 0; j < len; ++j) res += xf((double)tr[j * TSTR]);
+          r = 0.0;
+          for (int j = 0; j < len; ++j) r += tr[j];
         } else {
-          double acc8[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc8[k] = xf((double)tr[k * TSTR]);
-          int j = 8;
-          for (; j < len - (len % 8); j += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc8[k] += xf((double)tr[(j + k) * TSTR]);
-          }
-          res = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
-          for (; j < len; ++j) res += xf((double)tr[j * TSTR]);
+          for (int j = len8; j < len; ++j) r += tr[j];
         }
-        ls[((size_t)b * H + row0 + r) * nleaves + leaf] = res;
+        ls[((size_t)b * H + row0 + rrow) * nleaves + leaf] = r;
       }
+    }
+    // columns: ascending rows
+    if (tid < len) {
+      const double* tc = tile + tid;
+      for (int r = 0; r < nb; ++r) cacc = cacc + tc[r * TSTR];
     }
     __syncthreads();
   }
+#undef ATTWARP_PROFILES_FETCH
   if (tid < len) col[(size_t)b * W + off + tid] = cacc;
 }
 
@@ -274,7 +340,6 @@ __device__ __forceinline__ double inverse_transform(double x, int transform, dou
 
 __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const double* __restrict__ col,
                                                                      const double* __restrict__ ls, int h, int w,
-                                                                     const PairwisePlan Pw, const PairwisePlan Ph,
                                                                      int new_w, int new_h, int transform,
                                                                      double exp_scale, double exp_divisor,
                                                                      int apply_inverse, float* __restrict__ map_x,
@@ -283,7 +348,11 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
   __shared__ double red[NT / WAVE];
   __shared__ double pstack[10 * NT];     // per-thread stack of the leaf-combine program
   __shared__ double leafbuf[PW_MAX_LEAVES];
+  __shared__ PlanLds Pw, Ph;             // numpy's pairwise plans of a row (w terms) and of a column profile (h terms)
   const int b = blockIdx.x, axis = blockIdx.y;
+  if (threadIdx.x == 0) pw_build_lds(w, &Pw);
+  if (threadIdx.x == WAVE) pw_build_lds(h, &Ph);
+  __syncthreads();
   const int n = axis ? h : w;            // profile length
   const int other = axis ? w : h;        // number of terms summed into each profile entry
   const int n_out = axis ? new_h : new_w;
@@ -315,7 +384,7 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
   acc_other = block_sum(acc_other, red);
   all = block_sum(all, red);
   __syncthreads();
-  const double total_self = pw_sum_block(xn + 1, axis ? Ph : Pw, leafbuf);   // np.sum(profile), numpy's order
+  const double total_self = axis ? pw_sum_block(xn + 1, Ph, leafbuf) : pw_sum_block(xn + 1, Pw, leafbuf);   // np.sum(profile)
   double total = total_self;
   const bool fallback = (total_self < 1e-9) || (acc_other < 1e-9);
   if (fallback) {
@@ -356,7 +425,11 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
 template <typename T, typename XF>
 static int launch_profiles(const void* A, int B, int H, int W, XF xf, const PairwisePlan& P, double* col, double* ls,
                            hipStream_t st) {
-  hipLaunchKernelGGL((profiles_kernel<T, XF>), dim3(P.nleaves, B), dim3(NT), 0, st, (const T*)A, H, W, xf, P, col, ls);
+  // one vector load per 4 columns when every strip row starts on a 4-element boundary (leaf offsets are
+  // multiples of 8) and the last quad of a row stays inside the image
+  const int vec_ok = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % (4 * sizeof(T)) == 0);
+  hipLaunchKernelGGL((profiles_kernel<T, XF>), dim3(P.nleaves, B), dim3(NT), 0, st, (const T*)A, H, W, xf, P, col, ls,
+                     vec_ok);
   return check_launch("profiles_kernel");
 }
 
@@ -436,6 +509,6 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
 #undef ATTWARP_PROFILES
   if (rc) return rc;
   hipLaunchKernelGGL(attention_maps_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)(n + 2) * sizeof(double), st, col,
-                     ls, h, w, Pw, Ph, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
+                     ls, h, w, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
   return check_launch("attention_maps_finalize_kernel");
 }
