@@ -296,6 +296,78 @@ __global__ __launch_bounds__(NT) void lanczos_v4_kernel(const uint8_t* __restric
   *reinterpret_cast<uchar4*>(out + ((size_t)b * out_h + yy) * out_w + (size_t)x4 * 4) = o;
 }
 
+// Both passes in one launch for SMALL sources (the 24 x 24 token grid): the workgroup of (image, block of R output
+// rows) quantises the source rows it needs into LDS, runs the horizontal pass for them into an LDS uint8 tile
+// [h][out_w] and the vertical pass from that tile, 4 output pixels per thread (one ds_read_b32 per tap row, one
+// dword store).  Same integer arithmetic as the two-kernel form; no tmp round trip, one launch instead of two.
+// grid = (ceil(out_h / R), B); out_w % 4 == 0; ksize_x <= KS.  LDS: src[h*w] | tile[h*out_w]
+template <int KS>
+__global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
+                                                           int h, int w, int out_h, int out_w,
+                                                           const int32_t* __restrict__ bounds_x,
+                                                           const int32_t* __restrict__ kk_x, int ksize_x,
+                                                           const int32_t* __restrict__ bounds_y,
+                                                           const int32_t* __restrict__ kk_y, int ksize_y, int R,
+                                                           uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lz[];
+  __shared__ int32_t s_ky[16 * 32];                  // vertical coefficients and bounds of the block's rows
+  __shared__ int32_t s_by[16 * 2];
+  const int srcp = (h * w + 3) & ~3;
+  uint8_t* src = lz;
+  uint8_t* tile = lz + srcp;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int yy0 = blockIdx.x * R, yy1 = min(yy0 + R, out_h), nrows = yy1 - yy0;
+  const int ys = bounds_y[2 * yy0];                                          // first / one-past-last source row
+  const int ye = bounds_y[2 * (yy1 - 1)] + bounds_y[2 * (yy1 - 1) + 1];
+  const size_t ib = (size_t)b * h * w;
+  for (int i = ys * w + tid; i < ye * w; i += NT) src[i] = mf ? to_pil_u8(mf[ib + i]) : mu[ib + i];
+  for (int i = tid; i < nrows * ksize_y; i += NT) s_ky[i] = kk_y[(size_t)yy0 * ksize_y + i];
+  if (tid < 2 * nrows) s_by[tid] = bounds_y[2 * yy0 + tid];
+  __syncthreads();
+  for (int xx = tid; xx < out_w; xx += NT) {
+    const int xmin = bounds_x[2 * xx], cnt = bounds_x[2 * xx + 1];
+    int kreg[KS], toff[KS];
+#pragma unroll
+    for (int x = 0; x < KS; ++x) {
+      kreg[x] = (x < cnt) ? kk_x[(size_t)xx * ksize_x + min(x, ksize_x - 1)] : 0;
+      toff[x] = xmin + min(x, cnt - 1);
+    }
+    for (int r = ys; r < ye; ++r) {
+      const uint8_t* row = src + r * w;
+      int ss = 1 << (PIL_PRECISION_BITS - 1);
+#pragma unroll
+      for (int x = 0; x < KS; ++x) ss += (int)row[toff[x]] * kreg[x];
+      tile[r * out_w + xx] = pil_clip8(ss);
+    }
+  }
+  __syncthreads();
+  // vertical pass: a thread owns dword q of an output row; rows are spread over the threads left
+  const int nq = out_w >> 2;
+  const int rstep = nq >= NT ? 1 : NT / nq;          // rows in flight per sweep
+  const int q0 = nq >= NT ? tid : tid % nq, r0 = nq >= NT ? 0 : tid / nq;
+  if (r0 < rstep) {
+    for (int ry = r0; ry < nrows; ry += rstep) {
+      const int yy = yy0 + ry;
+      const int ymin = s_by[2 * ry], cnt = s_by[2 * ry + 1];
+      const int32_t* k = s_ky + ry * ksize_y;
+      for (int q = q0; q < nq; q += NT) {
+        int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+        for (int y = 0; y < cnt; ++y) {
+          const uint32_t wv = reinterpret_cast<const uint32_t*>(tile + (ymin + y) * out_w)[q];
+          const int kv = k[y];
+          s0 += (int)(wv & 0xffu) * kv;
+          s1 += (int)((wv >> 8) & 0xffu) * kv;
+          s2 += (int)((wv >> 16) & 0xffu) * kv;
+          s3 += (int)(wv >> 24) * kv;
+        }
+        const uint32_t o = (uint32_t)pil_clip8(s0) | ((uint32_t)pil_clip8(s1) << 8) | ((uint32_t)pil_clip8(s2) << 16) |
+                           ((uint32_t)pil_clip8(s3) << 24);
+        reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + yy) * out_w)[q] = o;
+      }
+    }
+  }
+}
+
 // copy / quantise pass used when an axis keeps its size (Pillow skips that pass)
 __global__ __launch_bounds__(NT) void quantise_copy_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
                                                            size_t n, uint8_t* __restrict__ out) {
@@ -471,6 +543,19 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     const size_t n = (size_t)B * h * w;
     hipLaunchKernelGGL(quantise_copy_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, mask_f32, mask_u8, n, out);
     return check_launch("quantise_copy_kernel");
+  }
+  // small source (the 24 x 24 token grid) and both passes needed: one fused launch
+  {
+    const char* fe = getenv("ATTWARP_LANCZOS_VARIANT");
+    const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * out_w;
+    if (need_h && need_v && !(fe && fe[0] == 'g') && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
+        ksize_y <= 32 &&
+        lds <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
+      const int R = 16;
+      hipLaunchKernelGGL((lanczos_fused_kernel<8>), dim3((out_h + R - 1) / R, B), dim3(NT), lds, st, mask_f32, mask_u8,
+                         h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, ksize_y, R, out);
+      return check_launch("lanczos_fused_kernel");
+    }
   }
   const uint8_t* vsrc = mask_u8;
   if (need_h) {

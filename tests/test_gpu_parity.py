@@ -279,13 +279,19 @@ def test_revise_mask(dev, golden):
         ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
 
 
+@pytest.mark.parametrize("variant", [None, "g"])       # fused single launch (small sources) / two-kernel form
 @pytest.mark.parametrize("wh", [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24), (24, 24)])
-def test_mask_upsample_lanczos_bit_exact(dev, golden, wh):
+def test_mask_upsample_lanczos_bit_exact(dev, golden, wh, variant):
     from attwarp_amd import attention_extraction as ae
     g = golden("mask_postproc")
     w, h = wh
-    got_f = N(ae.upsample_mask_lanczos(T(g["revised"][:2], dev), (w, h)))      # float mask: x255 truncation inside
-    got_u = N(ae.upsample_mask_lanczos(T(g["u8"][:2], dev), (w, h)))
+    if variant:
+        os.environ["ATTWARP_LANCZOS_VARIANT"] = variant
+    try:
+        got_f = N(ae.upsample_mask_lanczos(T(g["revised"][:2], dev), (w, h)))      # float mask: x255 truncation inside
+        got_u = N(ae.upsample_mask_lanczos(T(g["u8"][:2], dev), (w, h)))
+    finally:
+        os.environ.pop("ATTWARP_LANCZOS_VARIANT", None)
     if wh == (24, 24):
         assert np.array_equal(got_f, g["u8"][:2]) and np.array_equal(got_u, g["u8"][:2])
     else:
