@@ -310,8 +310,8 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
                                                            const int32_t* __restrict__ kk_y, int ksize_y, int R,
                                                            uint8_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz[];
-  __shared__ int32_t s_ky[16 * 32];                  // vertical coefficients and bounds of the block's rows
-  __shared__ int32_t s_by[16 * 2];
+  __shared__ int32_t s_ky[64 * 32];                  // vertical coefficients and bounds of the block's rows (R <= 64)
+  __shared__ int32_t s_by[64 * 2];
   const int srcp = (h * w + 3) & ~3;
   uint8_t* src = lz;
   uint8_t* tile = lz + srcp;
@@ -551,7 +551,8 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     if (need_h && need_v && !(fe && fe[0] == 'g') && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
         ksize_y <= 32 &&
         lds <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
-      const int R = 16;
+      int R = out_h >= 448 ? 64 : 32;   // measured: 24->336 R=32 27 us (two-kernel form 34), 24->1024 B=256 R=64 258 us (287)
+      if (const char* re = getenv("ATTWARP_LANCZOS_ROWS")) { const int v = atoi(re); if (v >= 1 && v <= 64) R = v; }
       hipLaunchKernelGGL((lanczos_fused_kernel<8>), dim3((out_h + R - 1) / R, B), dim3(NT), lds, st, mask_f32, mask_u8,
                          h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, ksize_y, R, out);
       return check_launch("lanczos_fused_kernel");

@@ -38,7 +38,7 @@ for (B, S) in [(256, 1024), (64, 336)]:
     rep(f"axis_maps_from_cdf (2 launches) B={B} S={S}", timeit(lambda: cu.axis_maps_from_cdf(F, F, (S, S))), B*2*S*8)
     img8 = (torch.rand(B, S, S, 3, device=dev) * 255).to(torch.uint8)
     mx, my = pipeline.axis_maps_from_pdf(px, px, (S, S), (500, 500))
-    rep(f"remap u8 HWC {S}->500 (gather) B={B}", timeit(lambda: nm.remap_hwc(img8, mx, my)), B*(S*S*3 + 500*500*3))
+    rep(f"remap u8 HWC {S}->500 B={B}", timeit(lambda: nm.remap_hwc(img8, mx, my)), B*(S*S*3 + 500*500*3))
     if S == 336:
         w500 = (torch.rand(B, 500, 500, 3, device=dev) * 255).to(torch.uint8)
         rep(f"clip_preprocess 500->336 u8 -> f16 [B,3,336,336] B={B}", timeit(lambda: pipeline.clip_preprocess(w500)), B*(500*500*3 + 3*336*336*2))
