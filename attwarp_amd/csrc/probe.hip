@@ -64,7 +64,7 @@ struct Params {
   int32_t* zero;                          // workspace word the chained reduction reads as its slice start
 };
 
-// grid = (heads, B).  CPL = 16-byte chunks of a row per lane; U rows per lane group in flight (8 loads per lane).
+// grid = heads * B.  CPL = 16-byte chunks of a row per lane; U rows per lane group in flight (8 loads per lane).
 template <typename T, int LPR, int CPL>
 __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                         const Params p, T* __restrict__ probs) {
@@ -74,7 +74,15 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
   constexpr int NE = Chunk<T>::NE;
   constexpr int G = NT / LPR;                      // lane groups = rows per sweep
   constexpr int U = CPL == 1 ? 8 : (CPL == 2 ? 4 : 2);
-  const int h = blockIdx.x, b = blockIdx.y;
+  // XCD-aware block order (blocks bid, bid+8, ... share an XCD and its L2): each XCD gets a contiguous range of
+  // (sample, head) pairs, so the query heads of one key head run next to each other on ONE L2 and grouped-query
+  // attention fetches a key row from HBM once per group instead of once per head.
+  int bid = blockIdx.x;
+  {
+    const int n = gridDim.x, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+  }
+  const int b = bid / p.heads, h = bid - b * p.heads;
   const int tid = threadIdx.x, g = tid / LPR, l = tid % LPR;
   const int kv = p.kv;
   const int kb = p.kv_begin ? min(max(p.kv_begin[b], 0), kv) : 0;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
 
 template <typename T, int LPR, int CPL>
 static int launch_k(const void* q, const void* k, const Params& p, int B, void* probs, hipStream_t st) {
-  hipLaunchKernelGGL((attn_probe_kernel<T, LPR, CPL>), dim3(p.heads, B), dim3(NT), (size_t)p.kv * sizeof(float), st,
+  hipLaunchKernelGGL((attn_probe_kernel<T, LPR, CPL>), dim3((unsigned)(p.heads * B)), dim3(NT), (size_t)p.kv * sizeof(float), st,
                      (const T*)q, (const T*)k, p, (T*)probs);
   return check_launch("attn_probe_kernel");
 }
@@ -195,7 +203,7 @@ extern "C" int attwarp_attn_probe_last_query(const void* q, const void* k, int d
   ATTWARP_REQUIRE(heads % kv_heads == 0, "attn_probe_last_query: heads=%d is not a multiple of kv_heads=%d", heads,
                   kv_heads);
   ATTWARP_REQUIRE(ntok <= kv_len, "attn_probe_last_query: ntok=%d > kv_len=%d", ntok, kv_len);
-  if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "attn_probe_last_query: B=%d > 65535", B);
+  if ((long long)B * heads > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "attn_probe_last_query: B*heads too large");
   if (ntok > 1024) return fail(ATTWARP_E_UNSUPPORTED, "attn_probe_last_query: ntok=%d > 1024", ntok);
   if (kv_len > probe::MAX_KV)
     return fail(ATTWARP_E_UNSUPPORTED, "attn_probe_last_query: kv_len=%d > %d", kv_len, probe::MAX_KV);
