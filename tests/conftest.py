@@ -49,3 +49,11 @@ def clip_digest(out: np.ndarray) -> dict:
     pos = (np.arange(out.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1)
     return {"sub": out[:, ::7, ::5].copy(), "sum_bits": np.array(bits.sum(dtype=np.uint64)),
             "wsum_bits": np.array((bits.ravel() * pos).sum(dtype=np.uint64))}
+
+
+def config1_inputs():
+    """BASELINE configs[0] (SURVEY 8d "config 1"): same recipe as tests/golden/make_golden.py::config1_inputs."""
+    img = np.random.default_rng(0).integers(0, 256, (336, 336, 3), dtype=np.uint8)
+    att = np.random.default_rng(1).random((24, 24))
+    att = (att / att.sum()).astype(np.float32)
+    return img, att

@@ -197,6 +197,35 @@ def make_probe_golden(eager_attention_forward, llava):
     np.savez_compressed(os.path.join(OUT, "attn_probe.npz"), **out)
 
 
+def config1_inputs():
+    """BASELINE configs[0] / SURVEY 8d "config 1": one 336x336x3 uint8 RGB image and one 24x24 float32 attention
+    map normalised to sum 1.  Recipe shared with the tests (the image itself is not stored)."""
+    img = np.random.default_rng(0).integers(0, 256, (336, 336, 3), dtype=np.uint8)
+    att = np.random.default_rng(1).random((24, 24))
+    att = (att / att.sum()).astype(np.float32)
+    return img, att
+
+
+def make_config1_golden(llava, new_method):
+    """The reference's own CPU-runnable case end to end (main.py / main_batched.py inner loop): revise_mask ->
+    toImg -> PIL LANCZOS to the image size (blend_mask's mask branch, llava.py:241-253) -> warp_image_by_attention
+    with the identity transform, at the input size and at the reference default 500x500; the maps handed to
+    cv2.remap are captured by the stub."""
+    img, att = config1_inputs()
+    mask = llava.revise_mask(torch.from_numpy(att).float(), kernel_size=3, enhance_coe=10).detach().cpu()
+    mask_pil = llava.toImg(mask.reshape(1, 24, 24))
+    mota = llava.invtrans(mask_pil, Image.fromarray(img), method=Image.LANCZOS)
+    mota_u8 = np.array(mota.convert("L"))
+    out = {"att": att, "mota": mota_u8, "img_sum": np.array(int(img.sum()))}
+    new_method.set_transform_function("identity", 1.0, 1.0, False)
+    bgr = img[..., ::-1].copy()
+    for (w, h) in [(336, 336), (500, 500)]:
+        new_method.warp_image_by_attention(bgr, mota_u8, w, h)
+        out[f"mx_{w}"] = CAPTURED["map_x"][0].copy()
+        out[f"my_{h}"] = CAPTURED["map_y"][:, 0].copy()
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), **out)
+
+
 def make_marginalnet_tail_golden(model):
     """"next" row 1 tail: the tensors around the reference MarginalNet's text pooling and FiLM + axis means
     (MN/model.py:73-88), captured with hooks on the reference module: masked token mean (input of txt_pool),
@@ -230,7 +259,7 @@ def make_marginalnet_tail_golden(model):
 
 
 def main():
-    if "--only-probe" not in sys.argv and "--only-mntail" not in sys.argv:
+    if not any(a.startswith("--only-") for a in sys.argv):
         make_clip_goldens()
     from transformers.models.llama.modeling_llama import eager_attention_forward
     _install_stubs()
@@ -243,6 +272,9 @@ def main():
     sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
     llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
 
+    make_config1_golden(llava, new_method)
+    if "--only-config1" in sys.argv:
+        return
     make_marginalnet_tail_golden(model)
     if "--only-mntail" in sys.argv:
         return

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import warp_oracle as O
-from conftest import pool_input, clip_input, clip_digest
+from conftest import pool_input, clip_input, clip_digest, config1_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -751,6 +751,30 @@ def test_pipeline_masks_chain_main_batched(dev, golden):
         bad += (d > 0).sum()
         assert d.max() <= 1
     assert bad <= 1e-4 * out.size
+
+
+def test_config1_single_image_chain(dev, golden):
+    """BASELINE configs[0] on the GPU: the reference's single-image case (main.py): attention map -> mask ->
+    LANCZOS -> float64 marginals -> maps -> uint8 warp, against the maps captured from the reference and the
+    oracle's resample."""
+    from attwarp_amd import new_method as nm, pipeline, attention_extraction as ae
+    g = golden("config1")
+    img, att = config1_inputs()
+    bgr = img[..., ::-1].copy()
+    mota = N(ae.upsample_mask_lanczos(ae.revise_mask(T(att, dev)), (336, 336)))
+    d = np.abs(mota.astype(np.int32) - g["mota"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    for n in (336, 500):
+        mx, my = nm.attention_axis_maps(T(g["mota"][None], dev), n, n, "identity")
+        assert np.array_equal(N(mx)[0], g[f"mx_{n}"]) and np.array_equal(N(my)[0], g[f"my_{n}"])     # == reference
+        nm.set_transform_function("identity", 1.0, 1.0, False)
+        out = nm.warp_image_by_attention(bgr, g["mota"], n, n)                                        # numpy in -> numpy out
+        assert isinstance(out, np.ndarray) and out.dtype == np.uint8
+        assert np.array_equal(out, O.remap_bilinear(bgr, g[f"mx_{n}"], g[f"my_{n}"]))
+    # the batched launcher with the same single image: only the <= 1-grey-level mask cells can differ
+    w = N(pipeline.warp_from_masks(T(bgr[None], dev), T(att[None], dev), (500, 500)))[0]
+    ref = O.remap_bilinear(bgr, g["mx_500"], g["my_500"])
+    assert (w != ref).mean() < 2e-3 and np.abs(w.astype(np.int32) - ref.astype(np.int32)).max() <= 2
 
 
 # =============================== full-size properties =========================

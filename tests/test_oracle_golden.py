@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import warp_oracle as O
-from conftest import pool_input, clip_input, clip_digest
+from conftest import pool_input, clip_input, clip_digest, config1_inputs
 
 
 def ulps(a, b):
@@ -354,3 +354,23 @@ def test_marginalnet_tail_vs_reference_hooks(golden, name):
     # a fully masked sample divides by the clamp, not by zero
     z = O.masked_token_mean(g[f"{name}_ttok"], np.zeros_like(g[f"{name}_tmask"][..., 0]))
     assert np.array_equal(z, np.zeros_like(z))
+
+
+# ---- BASELINE configs[0]: the reference's own CPU-runnable case, end to end -------
+def test_config1_single_image_chain_vs_reference(golden):
+    """One 336x336 image + a 24x24 attention map through revise_mask -> x255 uint8 -> PIL LANCZOS ->
+    warp_image_by_attention (identity transform), at 336x336 and at the reference default 500x500: the mask the
+    reference hands to the warp and the 1-D maps it hands to cv2.remap, against the oracle chain."""
+    g = golden("config1")
+    img, att = config1_inputs()
+    assert int(img.sum()) == int(g["img_sum"]) and np.array_equal(att, g["att"])
+    mota = O.lanczos_resize_u8(O.mask_to_u8(O.revise_mask(att, 3, 10)), 336, 336)
+    # A3's float32 reductions differ from torch's by ulps; the x255 truncation can turn that into one grey level
+    d = np.abs(mota.astype(np.int32) - g["mota"].astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    for n in (336, 500):
+        mx, my = O.maps_from_attention(g["mota"], n, n, "identity")
+        assert np.array_equal(mx, g[f"mx_{n}"]) and np.array_equal(my, g[f"my_{n}"])      # bit-exact vs the reference
+        out = O.warp_image_by_attention(img[..., ::-1].copy(), g["mota"], n, n)
+        assert out.shape == (n, n, 3) and out.dtype == np.uint8
+        assert np.array_equal(out, O.remap_bilinear(img[..., ::-1].copy(), g[f"mx_{n}"], g[f"my_{n}"]))
