@@ -70,6 +70,7 @@ struct RowsParams {
   int no_swz;        // 1: disable the XCD-aware block order (experiments)
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
+  int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
 };
 
 constexpr int RMAX = 64;
@@ -93,7 +94,12 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // Wo % 256 == 0 so that a k-slice never straddles two planes): no per-element offset table in VGPRs.
 // (forcing >= 4 waves per SIMD on the planar variants, which allocate 130-138 VGPRs, was measured: the
 //  register-limited code is 4-8 % slower than running them at 3 workgroups per CU)
-template <int NT, int KI, int KO, bool HWC, bool AFF>
+// TILED (interleaved / one-plane rows wider than the 4096-float LDS row): a workgroup owns a COLUMN TILE of KO*NT
+// output elements of its rows.  The source span the tile needs, [min tap, max tap], is found with a block
+// reduction; it is staged relative to its 4-float-aligned start, so everything after the prologue is the same
+// code.  A tile whose span exceeds KI*NT*4 floats (a map that minifies more than ~1.3x inside the tile) falls back
+// to direct global taps for that tile only.
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED = false>
 __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_my = smem;                                   // RMAX floats
@@ -109,8 +115,17 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
     if (!p.no_swz) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
   }
-  const int b = bid / p.nblk;
-  const int rb = bid - b * p.nblk;
+  int b, rb, tile = 0;
+  if (TILED) {          // (image, tile, row block): row blocks of one tile stay neighbours (halo rows meet in L2)
+    const int per_img = p.nblk * p.ntiles;
+    b = bid / per_img;
+    const int rem = bid - b * per_img;
+    tile = rem / p.nblk;
+    rb = rem - tile * p.nblk;
+  } else {
+    b = bid / p.nblk;
+    rb = bid - b * p.nblk;
+  }
   const int y0 = rb * p.R;
   const int y1 = min(y0 + p.R, p.Ho);
   const int nrows = y1 - y0;
@@ -126,6 +141,43 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   unsigned pk[KO];     // LDS BYTE offset of tap 0 | tap 1 << 16   (row buffers are <= 16 KB)
   float fxr[KO];
   unsigned ooff[AFF ? 1 : KO];   // BYTE offset of the element inside an output row (incl. plane)
+  unsigned goff[KI];   // BYTE offset inside a source row (incl. plane) of the float4s this thread owns
+  bool direct = false; // TILED: the tile's source span does not fit the LDS row -> global taps
+  unsigned f0s[TILED ? KO : 1], f1s[TILED ? KO : 1];   // TILED: absolute float indices of the two taps
+  if (TILED) {
+    __shared__ int s_lo[NT / WAVE], s_hi[NT / WAVE];
+    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
+    int lo = 0x7fffffff, hi = 0;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) {
+      const int e = min(e0 + tid + NT * k, e1 - 1);
+      const int x = e / p.CS;
+      const int c = e - x * p.CS;
+      const Taps tx = rtaps<ATTWARP_EXACT>(p.mx[(long long)bm * p.Wo + x], p.W);
+      f0s[k] = tx.i0 * p.CS + c;
+      f1s[k] = tx.i1 * p.CS + c;
+      fxr[k] = tx.f;
+      ooff[k] = (unsigned)e * 4u;
+      lo = min(lo, (int)f0s[k]);
+      hi = max(hi, (int)f1s[k]);
+    }
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, WAVE));
+      hi = max(hi, __shfl_xor(hi, o, WAVE));
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_lo[tid / WAVE] = lo; s_hi[tid / WAVE] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / WAVE; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+    const int abase = lo & ~3;                          // 4-float aligned start of the staged span
+    const int nf4 = (hi - abase + 4) >> 2;              // float4s covering [abase, hi]
+    direct = nf4 > KI * NT;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) pk[k] = ((f0s[k] - abase) * 4u) | (((f1s[k] - abase) * 4u) << 16);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) goff[k] = (unsigned)(abase + 4 * min(tid + NT * k, nf4 - 1)) * 4u;
+  } else {
 #pragma unroll
   for (int k = 0; k < KO; ++k) {
     const int e = min(tid + NT * k, p.OVL - 1);
@@ -141,14 +193,30 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     if (!AFF) ooff[k] = ((unsigned)(pl * p.oplane_stride) + (unsigned)r) * 4u;
   }
   // ---- which float4 of a source row this thread owns (clamped: padding lanes re-read the last one)
-  unsigned goff[KI];   // BYTE offset inside a source row (incl. plane)
 #pragma unroll
   for (int k = 0; k < KI; ++k) {
     const int f = min(tid + NT * k, p.VLV - 1) * 4;
     const int pl = HWC ? 0 : f / p.row_len;
     goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
   }
+  }
   __syncthreads();
+
+  if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
+    for (int q = 0; q < nrows; ++q) {
+      const Taps ty = rtaps<ATTWARP_EXACT>(s_my[q], p.H);
+      const float* ra = src_b + (long long)ty.i0 * p.row_len;
+      const float* rc = src_b + (long long)ty.i1 * p.row_len;
+      char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + q) * p.orow_len);
+#pragma unroll
+      for (int k = 0; k < KO; ++k) {
+        const float v0 = lerp_rn(ra[f0s[k]], rc[f0s[k]], ty.f);      // vertical first, as the staged path
+        const float v1 = lerp_rn(ra[f1s[k]], rc[f1s[k]], ty.f);
+        *reinterpret_cast<float*>(orow + ooff[k]) = lerp_rn(v0, v1, fxr[k]);
+      }
+    }
+    return;
+  }
 
   float4 X0[KI], X1[KI];
   int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
@@ -321,9 +389,14 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   if (p.row_len % 4 != 0) return ATTWARP_OK;
   if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0) return ATTWARP_OK;
   if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 : ((long long)H * W) % 4 != 0) return ATTWARP_OK;
-  if (VL > 4096 || OVL > 4096) return ATTWARP_OK;  // LDS indices are 16 bit, tables live in VGPRs
+  // LDS indices are 16 bit and the tap tables live in VGPRs: up to 4096 floats per staged row.  Wider interleaved /
+  // one-plane rows are processed in column tiles; wider multi-plane rows take the generic kernel.
+  const bool tiled = VL > 4096 || OVL > 4096;
+  if (tiled && (p.NP != 1 || VL > 2147483647LL / 8 || OVL > 2147483647LL / 8)) return ATTWARP_OK;
+  if (const char* te = getenv("ATTWARP_REMAP_TILED")) { if (atoi(te) == 0 && tiled) return ATTWARP_OK; }
   p.VLV = (int)(VL / 4);
   p.OVL = (int)OVL;
+  p.ntiles = 1;
   p.plane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)H * W;
   p.oplane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)Ho * Wo;
   p.img_stride = (long long)H * W * C;
@@ -333,16 +406,23 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // window of memory (DRAM page locality), and with alternating sweep directions the halo row two
   // neighbouring blocks share is read by both at about the same time (L2 hit).  Measured on MI355X,
   // 1024x1024x3 float32, B=256: R=4 1.07 ms, R=8 1.08, R=16 1.10, R=32 1.11, R=2 1.15.
-  const long long row_bytes = VL * 4;
+  // 2048 output elements per column tile against 3072 staged floats: maps may minify up to 1.5x inside a tile.
+  // Measured, 2048x2048x3 float32 B=64 (near-identity / peaked maps): KO=8 R=8 5.1 / 5.2 TB/s, KO=12 R=8 5.2 / 4.3
+  // (more tiles on the direct path), generic gather kernel 2.4.
+  int TILE_KO = 8;
+  if (const char* te = getenv("ATTWARP_REMAP_TILE_KO")) { const int v = atoi(te); if (v == 8 || v == 12) TILE_KO = v; }
+  if (tiled) p.ntiles = (int)((OVL + TILE_KO * NT_BIG - 1) / (TILE_KO * NT_BIG));
+  const long long row_bytes = tiled ? (long long)TILE_KO * NT_BIG * 4 : VL * 4;
   // (4 KB rows, 336x336x3: R=6 4.85 TB/s, R=12 4.62 at B=256; flat at B=64)
   int R = (int)((24 * 1024 + row_bytes / 2) / row_bytes);
   R = R < 4 ? 4 : (R > 16 ? 16 : R);
+  if (tiled) R = 8;
   const char* renv = getenv("ATTWARP_REMAP_ROWS");
   if (renv) { int v = atoi(renv); if (v >= 1 && v <= RMAX) R = v; }
   if (R > Ho) R = Ho;
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
-  const long long nb = (long long)p.nblk * B;
+  const long long nb = (long long)p.nblk * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   p.alt_dir = 1;
@@ -353,6 +433,16 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   *handled = true;
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)
+  if (tiled) {
+    if (TILE_KO == 8) {
+      const size_t lds = (size_t)(RMAX + 2 * 3 * NT_BIG * 4) * sizeof(float) + (size_t)p.lds_pad;
+      hipLaunchKernelGGL((remap_rows_kernel<NT_BIG, 3, 8, true, false, true>), dim3(p.nblocks), dim3(NT_BIG), lds, st, p);
+    } else {
+      const size_t lds = (size_t)(RMAX + 2 * 4 * NT_BIG * 4) * sizeof(float) + (size_t)p.lds_pad;
+      hipLaunchKernelGGL((remap_rows_kernel<NT_BIG, 4, 12, true, false, true>), dim3(p.nblocks), dim3(NT_BIG), lds, st, p);
+    }
+    return check_launch("remap_rows_kernel");
+  }
   return launch_rows_nt<NT_BIG>(p, st);
 }
 

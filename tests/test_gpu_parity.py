@@ -582,6 +582,35 @@ def test_remap_planar_plane_split(dev, kind, split):
     assert np.array_equal(two, ref[:, :2])
 
 
+@pytest.mark.parametrize("shape", [
+    (2, 37, 1500, 33, 1400, 3, "hwc"),     # rows of 4500 / 4200 floats: two column tiles
+    (2, 29, 1368, 40, 2900, 3, "hwc"),     # strong magnification: three tiles, narrow source spans
+    (1, 33, 5000, 31, 4200, 1, "chw"),     # single plane wider than 4096
+    (2, 30, 4400, 26, 1400, 3, "chw"),     # planar, split into one-channel images wider than 4096 -> tiled
+    (2, 26, 1100, 26, 1100, 4, "hwc"),     # 4 channels, 4400 floats
+])
+@pytest.mark.parametrize("kind", ["cdf", "wild", "identity"])
+def test_remap_wide_rows_column_tiles(dev, shape, kind):
+    """Rows wider than the 4096-float LDS row run in column tiles ("cdf": every tile staged; "wild": spans that do not
+    fit take the per-tile direct path); both must equal the oracle and the generic kernel bit-for-bit."""
+    from attwarp_amd import checkpoint_utils as cu
+    B, H, W, Ho, Wo, C, layout = shape
+    rng = np.random.default_rng(hash((shape, kind)) % 2**32)
+    img = rng.random((B, H, W, C), dtype=np.float32)
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+    x = T(img if layout == "hwc" else img.transpose(0, 3, 1, 2), dev)
+    got = N(cu.remap_separable(x, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
+    os.environ["ATTWARP_REMAP_TILED"] = "0"          # generic gather kernel
+    try:
+        gen = N(cu.remap_separable(x, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
+    finally:
+        os.environ.pop("ATTWARP_REMAP_TILED", None)
+    if layout == "chw":
+        got, gen = got.transpose(0, 2, 3, 1), gen.transpose(0, 2, 3, 1)
+    assert np.array_equal(got, ref) and np.array_equal(gen, ref)
+
+
 @pytest.mark.parametrize("R", ["1", "5", "64"])
 def test_remap_rows_block_boundaries(dev, R):
     """Row-block size must not change a single bit (halo / slide logic at block seams)."""
