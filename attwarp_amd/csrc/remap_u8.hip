@@ -49,16 +49,21 @@ struct Params {
   int VL, OVL;             // bytes per virtual row (all planes)
   long long img_stride, plane_stride, oimg_stride, oplane_stride;
   int R, nblk, nblocks;
+  int ntiles;              // TILED: column tiles per row (each KO*NT output bytes), else 1
+  int map_div;             // maps belong to image b / map_div (planes of a planar image dispatched as images)
 };
 
 // KI = dwords of the source row per thread, KO = output bytes per thread, KS = output dwords per thread
-template <int KI, int KO, bool HWC>
+// TILED (rows wider than 4096 bytes, one plane): a workgroup owns a column tile of KO*NT output bytes of its rows,
+// stages the source span [min tap, max tap] relative to its dword-aligned start; a span that does not fit KI*NT
+// dwords is read tap by tap from global memory for that tile (same scheme as remap_rows_kernel's TILED).
+template <int KI, int KO, bool HWC, bool TILED = false>
 __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KS = (KO + 3) / 4;
   float* s_my = smem;                      // RMAX
   float* row0 = smem + RMAX;               // 2 float rows of VLP floats
-  const int VLP = (p.VL + 15) & ~15;
+  const int VLP = TILED ? KI * NT * 4 : (p.VL + 15) & ~15;
   float* row1 = row0 + VLP;
   constexpr int OVP = NT * KO;                              // whole k-slices: no index clamp in the gather
   uint8_t* out0 = reinterpret_cast<uint8_t*>(row1 + VLP);   // 2 output rows of OVP bytes
@@ -70,17 +75,75 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
   }
-  const int b = bid / p.nblk;
-  const int rb = bid - b * p.nblk;
+  int b, rb, tile = 0;
+  if (TILED) {
+    const int per_img = p.nblk * p.ntiles;
+    b = bid / per_img;
+    const int rem = bid - b * per_img;
+    tile = rem / p.nblk;
+    rb = rem - tile * p.nblk;
+  } else {
+    b = bid / p.nblk;
+    rb = bid - b * p.nblk;
+  }
   const int y0 = rb * p.R;
   const int nrows = min(y0 + p.R, p.Ho) - y0;
   const uint8_t* src_b = p.src + (long long)b * p.img_stride;
   uint8_t* dst_b = p.dst + (long long)b * p.oimg_stride;
+  const int bm = b / p.map_div;
 
-  if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
+  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
 
+  int goff[KI], voff[KI];   // byte offset inside the image (row 0) / float index in the LDS row of this thread's dwords
+  unsigned pk[KO];
+  float fxr[KO];
+  int soff[KS], sld[KS];    // byte offset of this thread's output dwords inside an output row (incl. plane) / in the LDS row
+  bool direct = false;
+  unsigned f0s[TILED ? KO : 1], f1s[TILED ? KO : 1];
+  if (TILED) {
+    __shared__ int s_lo[NT / WAVE], s_hi[NT / WAVE];
+    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
+    int lo = 0x7fffffff, hi = 0;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) {
+      const int e = min(e0 + tid + NT * k, e1 - 1);
+      const int x = e / p.CS, c = e - x * p.CS;
+      const Taps tx = taps(p.mx[(long long)bm * p.Wo + x], p.W);
+      f0s[k] = tx.i0 * p.CS + c;
+      f1s[k] = tx.i1 * p.CS + c;
+      fxr[k] = tx.f;
+      lo = min(lo, (int)f0s[k]);
+      hi = max(hi, (int)f1s[k]);
+    }
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, WAVE));
+      hi = max(hi, __shfl_xor(hi, o, WAVE));
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_lo[tid / WAVE] = lo; s_hi[tid / WAVE] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / WAVE; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+    const int abase = lo & ~3;                       // dword-aligned start of the staged span
+    const int nd4 = (hi - abase + 4) >> 2;           // dwords covering [abase, hi]
+    direct = nd4 > KI * NT;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) pk[k] = ((f0s[k] - abase) * 4u) | (((f1s[k] - abase) * 4u) << 16);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int d = min(tid + NT * k, nd4 - 1);
+      goff[k] = abase + 4 * d;
+      voff[k] = 4 * d;
+    }
+    const int nd = (e1 - e0) >> 2;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      const int d = min(tid + NT * k, nd - 1);
+      soff[k] = e0 + 4 * d;
+      sld[k] = 4 * d;
+    }
+  } else {
   // source dwords this thread owns (clamped: padding lanes re-read the last dword and write the same floats)
-  int goff[KI], voff[KI];   // byte offset inside the image (row 0) / float index in the LDS row
   {
     const int dpr = p.row_len >> 2, nd = p.VL >> 2;
 #pragma unroll
@@ -93,8 +156,6 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
   }
   // column taps of the output bytes this thread gathers.  Interleaved rows: element e = x*CS + c advances by NT
   // per k-slice, so (x, c) is stepped with one carry instead of a division per element.
-  unsigned pk[KO];
-  float fxr[KO];
   {
     const int dx = NT / p.CS, dc = NT - dx * p.CS;       // block uniform
     int x = HWC ? tid / p.CS : 0, c = HWC ? tid - x * p.CS : 0;
@@ -111,15 +172,14 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
         xe = e - pl * p.orow_len;
         ce = 0;
       }
-      const Taps tx = taps(p.mx[(long long)b * p.Wo + xe], p.W);
+      const Taps tx = taps(p.mx[(long long)bm * p.Wo + xe], p.W);
       const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + ce;
       const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + ce;
       pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
       fxr[k] = tx.f;
     }
   }
-  // output dwords this thread stores (byte offset inside an output row of the image, incl. plane)
-  int soff[KS], sld[KS];      // ... and where that dword sits in the LDS output row (clamped: padding lanes repeat the last)
+  // output dwords this thread stores (clamped: padding lanes repeat the last)
   {
     const int dpo = p.orow_len >> 2, nd = p.OVL >> 2;
 #pragma unroll
@@ -130,7 +190,26 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
       sld[k] = 4 * d;
     }
   }
+  }
   __syncthreads();
+
+  if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
+    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
+    for (int q = 0; q < nrows; ++q) {
+      const Taps ty = taps(s_my[q], p.H);
+      const uint8_t* ra = src_b + (long long)ty.i0 * p.row_len;
+      const uint8_t* rc = src_b + (long long)ty.i1 * p.row_len;
+      uint8_t* orow = dst_b + (long long)(y0 + q) * p.orow_len;
+#pragma unroll
+      for (int k = 0; k < KO; ++k) {
+        const int e = e0 + tid + NT * k;
+        const float v0 = lerp_rn((float)ra[f0s[k]], (float)rc[f0s[k]], ty.f);
+        const float v1 = lerp_rn((float)ra[f1s[k]], (float)rc[f1s[k]], ty.f);
+        if (e < e1) orow[e] = (uint8_t)__float_as_uint(fadd(lerp_rn(v0, v1, fxr[k]), 8388608.0f));
+      }
+    }
+    return;
+  }
 
   Taps tcur = taps(s_my[0], p.H);
   uint32_t A[KI], C[KI];
@@ -234,23 +313,49 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
                             : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0)
     return ATTWARP_OK;
-  if (VL > 4096 || OVL > 4096) return ATTWARP_OK;           // 16-bit LDS offsets
-  p.VL = (int)VL;
-  p.OVL = (int)OVL;
+  p.map_div = 1;
+  p.ntiles = 1;
+  // up to 4096 bytes per staged row (16-bit LDS offsets); wider rows run in column tiles, planar ones plane by plane
+  const bool tiled = VL > 4096 || OVL > 4096;
+  if (tiled) {
+    const char* te = getenv("ATTWARP_REMAP_TILED");
+    if (te && atoi(te) == 0) return ATTWARP_OK;
+    if ((long long)p.row_len > 2147483647LL / 8 || (long long)p.orow_len > 2147483647LL / 8 ||
+        (long long)B * C > 2147483647LL)
+      return ATTWARP_OK;
+    if (p.NP > 1) {          // every plane becomes a one-channel image served by the maps of image b / C
+      p.map_div = C;
+      B *= C;
+      C = 1;
+      p.NP = 1;
+      p.CS = 1;
+      layout = ATTWARP_HWC;
+    }
+  }
+  p.VL = (int)(tiled ? p.row_len : VL);
+  p.OVL = (int)(tiled ? p.orow_len : OVL);
   p.plane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)H * W;
   p.oplane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)Ho * Wo;
   p.img_stride = (long long)H * W * C;
   p.oimg_stride = (long long)Ho * Wo * C;
   if (p.plane_stride * p.NP > 2147483647LL || p.oplane_stride * p.NP > 2147483647LL) return ATTWARP_OK;
   int R = (OVL >= 2048) ? 32 : 16;   // measured: 1024x1024x3 R=32 7 % faster than 16, 336->500 equal
+  constexpr int TILE_KO = 8, TILE_KI = 3;      // 2048 output bytes per tile against 3072 staged source bytes
+  // (2048x2048x3 uint8, B=64: tiled R=32 0.51 ms, R=16 0.55, R=8 0.67; generic gather kernel 2.32 ms)
+  if (tiled) { R = 32; p.ntiles = (p.OVL + TILE_KO * u8k::NT - 1) / (TILE_KO * u8k::NT); }
   if (const char* renv = getenv("ATTWARP_REMAP_ROWS")) { int v = atoi(renv); if (v >= 1 && v <= u8k::RMAX) R = v; }
   if (R > Ho) R = Ho;
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
-  const long long nb = (long long)p.nblk * B;
+  const long long nb = (long long)p.nblk * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   *handled = true;
+  if (tiled) {
+    const size_t lds = (size_t)(u8k::RMAX + 2 * TILE_KI * u8k::NT * 4) * sizeof(float) + 2 * (size_t)(u8k::NT * TILE_KO);
+    hipLaunchKernelGGL((u8k::remap_rows_u8_kernel<TILE_KI, TILE_KO, true, true>), dim3(p.nblocks), dim3(u8k::NT), lds, st, p);
+    return check_launch("remap_rows_u8_kernel");
+  }
   const int ko = (p.OVL + u8k::NT - 1) / u8k::NT;
   if (ko <= 4) return u8k::launch_ko<4>(p, st);
   if (ko <= 8) return u8k::launch_ko<8>(p, st);

@@ -609,6 +609,15 @@ def test_remap_wide_rows_column_tiles(dev, shape, kind):
     if layout == "chw":
         got, gen = got.transpose(0, 2, 3, 1), gen.transpose(0, 2, 3, 1)
     assert np.array_equal(got, ref) and np.array_equal(gen, ref)
+    # the uint8 kernel tiles rows wider than 4096 BYTES: same shapes, 4x the width in bytes is not needed --
+    # these rows (4200 .. 5000 bytes) already exceed it
+    img8 = (img * 255).astype(np.uint8)
+    ref8 = np.stack([O.remap_bilinear(img8[b], mx[b], my[b]) for b in range(B)])
+    x8 = T(img8 if layout == "hwc" else img8.transpose(0, 3, 1, 2), dev)
+    got8 = N(cu.remap_separable(x8, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
+    if layout == "chw":
+        got8 = got8.transpose(0, 2, 3, 1)
+    assert np.array_equal(got8, ref8)
 
 
 @pytest.mark.parametrize("R", ["1", "5", "64"])
