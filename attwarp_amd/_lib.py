@@ -48,7 +48,7 @@ SIGNATURES = {
     "attwarp_clip_preprocess_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                             c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_int, c_void_p]),
-    "attwarp_adaptive_avg_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_adaptive_avg_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "attwarp_axis_sums_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "attwarp_gt_marginals": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_safe_softmax": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),

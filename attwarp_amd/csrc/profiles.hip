@@ -293,7 +293,7 @@ __global__ __launch_bounds__(NT) void marginals_finalize_kernel(const double* __
 
 // ---- A5: adaptive average pool.  grid = (oh, B), one band of rows per block ---------------
 __global__ __launch_bounds__(NT) void adaptive_pool_kernel(const float* __restrict__ A, int H, int W, int oh, int ow,
-                                                           float* __restrict__ out) {
+                                                           int sanitize, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double colsum[];   // W doubles
   const int b = blockIdx.y, i = blockIdx.x;
   const int ys = (int)(((long long)i * H) / oh);
@@ -319,7 +319,10 @@ __global__ __launch_bounds__(NT) void adaptive_pool_kernel(const float* __restri
     double acc = 0.0;
     for (int x = xs; x < xe; ++x) acc += colsum[x];
     const float cnt = (float)((ye - ys) * (xe - xs));
-    out[((size_t)b * oh + i) * ow + j] = (float)acc / cnt;
+    float v = (float)acc / cnt;
+    // trainer.py:202: torch.nan_to_num(A, nan=0, posinf=0, neginf=0).clamp_min(0)
+    if (sanitize) v = (v > 0.0f && v <= 3.402823466e38f) ? v : 0.0f;
+    out[((size_t)b * oh + i) * ow + j] = v;
   }
 }
 
@@ -461,14 +464,14 @@ extern "C" int attwarp_gt_marginals(const float* A, int B, int H, int W, float* 
   return check_launch("marginals_finalize_kernel");
 }
 
-extern "C" int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, float* out,
+extern "C" int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, int sanitize, float* out,
                                          void* stream) {
   ATTWARP_REQUIRE(A && out, "adaptive_avg_pool: null pointer");
   ATTWARP_REQUIRE(B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "adaptive_avg_pool: non-positive size");
   if (oh > 65535 || B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "adaptive_avg_pool: oh/B > 65535");
   if (W > 16384) return fail(ATTWARP_E_UNSUPPORTED, "adaptive_avg_pool: W=%d > 16384", W);
   hipLaunchKernelGGL(adaptive_pool_kernel, dim3(oh, B), dim3(NT), (size_t)W * sizeof(double), as_stream(stream), A, H,
-                     W, oh, ow, out);
+                     W, oh, ow, sanitize, out);
   return check_launch("adaptive_pool_kernel");
 }
 

@@ -31,6 +31,24 @@ from . import new_method as nm
 GRID = 24
 
 
+def adaptive_avg_pool2d(A: torch.Tensor, output_size=(GRID, GRID), sanitize: bool = False) -> torch.Tensor:
+    """``F.adaptive_avg_pool2d(A, output_size)`` as the reference calls it on full-resolution attention maps
+    (MN/trainer.py:197,433,465): A [B,C,H,W] or [B,H,W] float -> same rank with (H,W) replaced by ``output_size``.
+    Window rows ``[floor(i*H/oh), ceil((i+1)*H/oh))``, float64 accumulation rounded once (DESIGN.md "parity").
+    ``sanitize=True`` also applies the trainer's ``nan_to_num(nan=0, posinf=0, neginf=0).clamp_min(0)`` (:202)."""
+    dev = require_gpu(A)
+    if A.dim() not in (3, 4):
+        raise ValueError(f"adaptive_avg_pool2d expects [B,C,H,W] or [B,H,W]; got {tuple(A.shape)}")
+    oh, ow = (int(output_size), int(output_size)) if isinstance(output_size, int) else (int(output_size[0]), int(output_size[1]))
+    x = A.detach().float().contiguous()
+    H, W = x.shape[-2], x.shape[-1]
+    planes = x.numel() // (H * W)
+    out = torch.empty(*x.shape[:-2], oh, ow, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        call("attwarp_adaptive_avg_pool", ptr(x), planes, H, W, oh, ow, int(bool(sanitize)), ptr(out), stream_ptr(dev))
+    return out
+
+
 def axis_maps_from_pdf(px: torch.Tensor, py: torch.Tensor, size_hw: Tuple[int, int],
                        out_size: Optional[Tuple[int, int]] = None, eps: float = 1e-8
                        ) -> Tuple[torch.Tensor, torch.Tensor]:

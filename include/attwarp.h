@@ -141,8 +141,10 @@ ATTWARP_API int attwarp_film_axis_means(const float* v, const float* gamma_beta,
                             float* vx, float* vy, void* stream);
 
 /* ---- A5: F.adaptive_avg_pool2d(A,(oh,ow)), call sites MN/trainer.py:197,433,465
- * A [B,H,W] float32 -> out [B,oh,ow] float32 (oh,ow <= 64). */
-ATTWARP_API int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, float* out, void* stream);
+ * A [B,H,W] float32 -> out [B,oh,ow] float32.  sanitize != 0 also applies the trainer's
+ * torch.nan_to_num(A, nan=0, posinf=0, neginf=0).clamp_min(0) (MN/trainer.py:202) to the pooled map. */
+ATTWARP_API int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, int oh, int ow, int sanitize, float* out,
+                              void* stream);
 
 /* ---- A6: gt_marginals, MN/checkpoint_utils.py:43-51
  * A [B,H,W] float32 -> px [B,W], py [B,H] float32.  ws: workspace of

@@ -313,6 +313,33 @@ def test_blend_mask_surface(dev, golden):
         ae.blend_mask(3.14, T(g["masks"][1], dev), 10, 3, Image.LANCZOS, 0)
 
 
+def test_adaptive_avg_pool2d_drop_in(dev, golden):
+    """F.adaptive_avg_pool2d's call shape (MN/trainer.py:197,433,465) + the trainer's sanitise (:202)."""
+    from attwarp_amd import pipeline
+    g = golden("pool_marginals")
+    A = pool_input(336)                                                   # [2,1,336,336]
+    out = pipeline.adaptive_avg_pool2d(T(A, dev), (24, 24))
+    assert out.shape == (2, 1, 24, 24)
+    assert np.array_equal(N(out), O.adaptive_avg_pool24(A))
+    np.testing.assert_allclose(N(out), g["P_336"], rtol=3e-6)
+    # 3-D input, non-square output, torch's own result on the GPU as a cross-check
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((3, 45, 70)).astype(np.float32)
+    got = pipeline.adaptive_avg_pool2d(T(X, dev), (7, 12))
+    ref = torch.nn.functional.adaptive_avg_pool2d(T(X, dev)[:, None], (7, 12))[:, 0]
+    assert got.shape == (3, 7, 12)
+    np.testing.assert_allclose(N(got), N(ref), rtol=2e-6, atol=1e-7)
+    # sanitise: NaN / inf windows and negative means become 0, everything else is untouched
+    Y = X.copy()
+    Y[0, :10, :10] = np.nan
+    Y[1, 20:, 30:] = np.inf
+    Y[2] = -np.abs(Y[2])
+    raw = N(pipeline.adaptive_avg_pool2d(T(Y, dev), (7, 12)))
+    san = N(pipeline.adaptive_avg_pool2d(T(Y, dev), (7, 12), sanitize=True))
+    expect = np.maximum(np.nan_to_num(raw, nan=0.0, posinf=0.0, neginf=0.0), 0)
+    assert np.array_equal(san, expect) and np.isnan(raw).any() and np.isinf(raw).any() and not san[2].any()
+
+
 # =============================== A5 / A6 / A7 ================================
 @pytest.mark.parametrize("S", [336, 512, 1024])
 def test_adaptive_pool_and_marginals(dev, golden, S):
@@ -322,7 +349,7 @@ def test_adaptive_pool_and_marginals(dev, golden, S):
     A = pool_input(S)
     a = T(A[:, 0], dev)
     out = torch.empty(2, 24, 24, device=dev)
-    call("attwarp_adaptive_avg_pool", ptr(a), 2, S, S, 24, 24, ptr(out), stream_ptr(dev))
+    call("attwarp_adaptive_avg_pool", ptr(a), 2, S, S, 24, 24, 0, ptr(out), stream_ptr(dev))
     assert np.array_equal(N(out), O.adaptive_avg_pool24(A)[:, 0])
     np.testing.assert_allclose(N(out), g[f"P_{S}"][:, 0], rtol=3e-6)
     px, py = cu.gt_marginals(T(g[f"P_{S}"], dev))

@@ -16,7 +16,7 @@ for (B, S) in [(256, 1024), (64, 336)]:
     A = torch.rand(B, 1, S, S, device=dev)
     out = torch.empty(B, 24, 24, device=dev)
     a3 = A[:, 0].contiguous()
-    rep(f"pool24 fp32 B={B} S={S}", timeit(lambda: call("attwarp_adaptive_avg_pool", ptr(a3), B, S, S, 24, 24, ptr(out), stream_ptr(dev))), B*S*S*4)
+    rep(f"pool24 fp32 B={B} S={S}", timeit(lambda: call("attwarp_adaptive_avg_pool", ptr(a3), B, S, S, 24, 24, 0, ptr(out), stream_ptr(dev))), B*S*S*4)
     rep(f"gt_marginals full-res fp32 B={B} S={S}", timeit(lambda: cu.gt_marginals(A)), B*S*S*4)
     au8 = (A[:, 0] * 255).to(torch.uint8).contiguous()
     rep(f"attention_axis_maps u8 identity B={B} S={S}", timeit(lambda: nm.attention_axis_maps(au8, 500, 500, "identity")), B*S*S)
