@@ -243,6 +243,23 @@ class BatchMaskHookLogger(object):
             self._probe_saved = None
 
 
+def batch_image_token_ranges(unpadded_lens: Sequence[int], image_token_positions: Sequence[int],
+                             num_image_tokens: int = NUM_IMAGE_TOKENS):
+    """Range bookkeeping of the batched driver (reference ``functions.py:276-291``): every prompt holds ONE image
+    placeholder that the multimodal expansion replaces by ``num_image_tokens`` embeddings, the batch is then
+    LEFT-padded to the longest expanded prompt.  Returns ``(starts, ends, pad_offsets)`` -- what
+    ``set_batch_image_token_ranges`` takes, plus the per-sample left padding (the ``kv_begin`` of
+    ``probe_last_query``)."""
+    if len(unpadded_lens) != len(image_token_positions):
+        raise ValueError("unpadded_lens and image_token_positions differ in length")
+    expanded = [int(ul) - 1 + num_image_tokens for ul in unpadded_lens]
+    longest = max(expanded) if expanded else 0
+    pads = [longest - e for e in expanded]
+    starts = [pad + int(pos) for pad, pos in zip(pads, image_token_positions)]
+    ends = [st + num_image_tokens for st in starts]
+    return starts, ends, pads
+
+
 def batch_hook_logger(model, device, layer_index: int = 20) -> BatchMaskHookLogger:
     """Reference :451-462."""
     prs = BatchMaskHookLogger(model, device, layer_index)

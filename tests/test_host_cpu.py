@@ -121,6 +121,20 @@ def test_marginalnet_tail_abi_validation_without_gpu(lib):
         model.film_axis_means(torch.rand(2, 4, 6, 6), torch.rand(2, 8))
 
 
+def test_batch_image_token_ranges_bookkeeping():
+    """reference functions.py:276-291: starts shift by the left padding of the expanded prompts."""
+    from attwarp_amd import attention_extraction as ae
+    starts, ends, pads = ae.batch_image_token_ranges([40, 47, 43], [35, 36, 35])
+    assert pads == [7, 0, 4]                                 # expanded lengths 615, 622, 618
+    assert starts == [42, 36, 39] and ends == [618, 612, 615]
+    assert ae.batch_image_token_ranges([], []) == ([], [], [])
+    with pytest.raises(ValueError):
+        ae.batch_image_token_ranges([1, 2], [0])
+    hl = ae.BatchMaskHookLogger(None, "cpu")
+    hl.set_batch_image_token_ranges(starts, ends)
+    assert hl.batch_size == 3 and hl.image_token_starts == starts
+
+
 def test_no_cpu_fallback():
     from attwarp_amd import checkpoint_utils as cu, model, attention_extraction as ae
     with pytest.raises(RuntimeError, match="no CPU fallback"):
