@@ -842,6 +842,39 @@ def test_config1_single_image_chain(dev, golden):
     assert (w != ref).mean() < 2e-3 and np.abs(w.astype(np.int32) - ref.astype(np.int32)).max() <= 2
 
 
+def test_run_to_run_determinism(dev):
+    """Every reduction has a fixed order (no atomics anywhere): repeated launches and launches on a side stream give
+    bit-identical results for the whole chain, including the probe and the uint8 / CLIP kernels."""
+    from attwarp_amd import pipeline, attention_extraction as ae
+    gen = torch.Generator(device=dev).manual_seed(5)
+    B, S = 8, 336
+    img = torch.rand(B, S, S, 3, device=dev, generator=gen)
+    rows = torch.softmax(torch.randn(6, B, 32, 640, device=dev, generator=gen), -1)
+    starts = (35 + torch.arange(B, device=dev) % 8).int()
+    img8 = (img * 255).to(torch.uint8)
+    m24 = torch.rand(B, 24, 24, device=dev, generator=gen)
+    q = torch.randn(B, 32, 128, device=dev, generator=gen).half()
+    k = torch.randn(B, 32, 640, 128, device=dev, generator=gen).half()
+
+    def run():
+        a = pipeline.warp_from_attention_stack(img, rows, starts, channels_last=True)
+        w = pipeline.warp_from_masks(img8, m24, (500, 500))
+        c = pipeline.clip_preprocess(w)
+        p = ae.probe_last_query(q, k, starts, 576)
+        return a.clone(), w.clone(), c.clone(), p.clone()
+
+    first = run()
+    for _ in range(3):
+        again = run()
+        assert all(torch.equal(x, y) for x, y in zip(first, again))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        other = run()
+    side.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(first, other))
+
+
 # =============================== full-size properties =========================
 @pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
 def test_full_size_properties(dev, cfg):
