@@ -875,6 +875,43 @@ def test_run_to_run_determinism(dev):
     assert all(torch.equal(x, y) for x, y in zip(first, other))
 
 
+def test_two_host_threads_two_streams(dev):
+    """The library keeps no global mutable state (include/attwarp.h): two host threads driving their own streams
+    concurrently produce what each would produce alone."""
+    import threading
+    from attwarp_amd import pipeline
+    gen = torch.Generator(device=dev).manual_seed(9)
+    jobs = []
+    for t in range(2):
+        B, S = 4, 128 + 64 * t
+        img = torch.rand(B, 3, S, S, device=dev, generator=gen)
+        px = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * (1 + t), 1)
+        py = torch.softmax(torch.randn(B, 24, device=dev, generator=gen), 1)
+        jobs.append((img, px, py, pipeline.warp_from_pdf(img, px, py).clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i):
+        try:
+            img, px, py, ref = jobs[i]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                for _ in range(30):
+                    out = pipeline.warp_from_pdf(img, px, py)
+                stream.synchronize()
+                if not torch.equal(out, ref):
+                    errors.append(f"thread {i}: result differs")
+        except Exception as e:          # noqa: BLE001 - report through the list, the assert below fails the test
+            errors.append(f"thread {i}: {e!r}")
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 # =============================== full-size properties =========================
 @pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
 def test_full_size_properties(dev, cfg):
