@@ -1016,8 +1016,8 @@ def test_hook_plumbing_with_dummy_decoder(dev):
     assert model.model.layers[1].self_attn.calls[-1] is False and len(hl.step_attentions) == 2
 
 
-def test_wide_rows_fall_back_to_gather(dev):
-    """Rows wider than the fast kernels' 4096-element limit take the generic kernel; same bits."""
+def test_wide_rows_sorted_random_maps(dev):
+    """Rows wider than one staged LDS row (4500 floats / bytes) with irregular but sorted maps: column tiles; same bits."""
     from attwarp_amd import checkpoint_utils as cu
     rng = np.random.default_rng(81)
     H, W, C = 12, 1500, 3                                  # 4500 floats per row
