@@ -7,6 +7,7 @@ non-GPU tensor raises.  Build with ``python __graft_entry__.py`` or
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p, c_char_p
@@ -29,6 +30,7 @@ _DTYPE_IDS = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torc
 SIGNATURES = {
     "attwarp_version": (c_int, []),
     "attwarp_last_error": (c_char_p, []),
+    "attwarp_debug_set": (c_int, [c_char_p, c_int]),
     "attwarp_attn_reduce_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "attwarp_attn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -101,6 +103,20 @@ def call(name: str, *args):
         raise AttWarpError(f"{name} failed ({rc}): {msg}")
 
 
+@contextlib.contextmanager
+def debug_override(**settings: int):
+    """Test / measurement hook: force kernel variants (``attwarp_debug_set``), restored to "automatic" on exit.
+    e.g. ``with debug_override(remap_variant=1): ...`` runs the generic gather kernel."""
+    lib = load()
+    try:
+        for k, v in settings.items():
+            call("attwarp_debug_set", k.encode(), int(v))
+        yield
+    finally:
+        for k in settings:
+            lib.attwarp_debug_set(k.encode(), -1)
+
+
 def ptr(t: torch.Tensor | None):
     return None if t is None else c_void_p(t.data_ptr())
 
@@ -128,6 +144,14 @@ def require_gpu(*tensors: torch.Tensor) -> torch.device:
     if dev is None:
         raise RuntimeError("attwarp_amd: no tensor given")
     return dev
+
+
+def needs_grad(*tensors) -> bool:
+    """True when autograd has to see through the call (grad mode on and some input requires grad).  The HIP kernels
+    are forward-only; the training-time call sites of the reference (``net(...)`` and
+    ``upsample_pdf_right_inverse(px_s, ...)`` on the loss path, MN/trainer.py:210-260) then take a differentiable
+    route: stock PyTorch-ROCm ops on the same GPU, or an autograd.Function around the kernel."""
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
 def stream_ptr(dev: torch.device):

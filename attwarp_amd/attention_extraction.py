@@ -224,6 +224,44 @@ class BatchMaskHookLogger(object):
         private._attn_implementation = name
         layer_attn.config = private
 
+    def register_probe_legacy(self):
+        """``register_probe`` for transformers 4.36 - 4.47 (the reference pins 4.37.2, which predates
+        ``AttentionInterface``): a forward hook (``with_kwargs``) on the target ``LlamaAttention`` that, after the layer
+        ran on its own fast kernel, rebuilds the post-RoPE query of the LAST token the way that version's forward does
+        (``q_proj`` -> heads -> ``rotary_emb(x, seq_len)`` tables gathered at ``position_ids`` -> ``q*cos +
+        rotate_half(q)*sin``, modeling_llama.py of 4.37.2) and reads the layer's post-RoPE keys from
+        ``past_key_value.key_cache[layer_idx]`` -- the one projection of one token instead of eager attention over the
+        whole prompt.  Needs ``use_cache=True`` (what ``generate`` does)."""
+        self.remove_hook_and_unpatch()
+        layer_attn = self.model.model.layers[self.layer_index].self_attn
+        logger = self
+
+        @torch.no_grad()
+        def hook(module, args, kwargs, output):
+            if logger.image_token_starts is None:
+                return
+            hidden = kwargs.get("hidden_states", args[0] if args else None)
+            cache = kwargs.get("past_key_value", None)
+            pos = kwargs.get("position_ids", None)
+            if hidden is None or cache is None:
+                raise RuntimeError("register_probe_legacy: the hooked attention ran without hidden_states / past_key_value "
+                                   "(use_cache=True is required)")
+            key = cache.key_cache[getattr(module, "layer_idx", logger.layer_index)]          # [B, kv_heads, kv, D]
+            B, kv = key.shape[0], key.shape[2]
+            heads = getattr(module, "num_heads", None) or module.config.num_attention_heads
+            D = key.shape[-1]
+            q = module.q_proj(hidden[:, -1:, :]).view(B, 1, heads, D).transpose(1, 2)            # [B, heads, 1, D]
+            if pos is None:
+                pos = torch.full((B, 1), kv - 1, dtype=torch.long, device=hidden.device)
+            cos, sin = module.rotary_emb(q, seq_len=kv)
+            cos, sin = cos[pos[:, -1:]].unsqueeze(1), sin[pos[:, -1:]].unsqueeze(1)           # [B, 1, 1, D]
+            half = D // 2
+            rot = torch.cat((-q[..., half:], q[..., :half]), dim=-1)
+            q = (q * cos) + (rot * sin)
+            logger._probe_attention(q, key, kwargs.get("attention_mask", None), D ** -0.5)
+
+        self.hook_handle = layer_attn.register_forward_hook(hook, with_kwargs=True)
+
     def remove_hook_and_unpatch(self):
         if self.hook_handle is not None:
             self.hook_handle.remove()
@@ -287,6 +325,29 @@ class MaskHookLogger(object):
         self.image_token_start = start
         self.image_token_end = end
 
+    def _find_image_token_range(self, input_ids):
+        """Reference :52-72 -- a fixed heuristic: the image tokens follow the BOS token."""
+        return 1, 1 + self.num_image_tokens
+
+    @torch.no_grad()
+    def _attention_hook(self, module, input, output):
+        """Forward hook of the target ``self_attn`` (reference :74-92): consumes ``output[1]`` when the layer
+        returned 4-D attention weights, silently ignores anything else."""
+        w = output[1] if isinstance(output, tuple) and len(output) >= 2 else None
+        if isinstance(w, torch.Tensor) and w.dim() == 4:
+            self._process_attention(w)
+
+    def register_hook(self):
+        """Reference :141-147."""
+        self.remove_hook()
+        self.hook_handle = self.model.model.layers[self.layer_index].self_attn.register_forward_hook(self._attention_hook)
+
+    def remove_hook(self):
+        """Reference :149-153."""
+        if self.hook_handle is not None:
+            self.hook_handle.remove()
+            self.hook_handle = None
+
     @torch.no_grad()
     def _process_attention(self, attn_weights: torch.Tensor):
         kv = attn_weights.shape[-1]
@@ -308,6 +369,19 @@ class MaskHookLogger(object):
         self.attns = []
         self.image_token_start = None
         self.image_token_end = None
+
+
+def hook_logger(model, device, layer_index: int = 20) -> MaskHookLogger:
+    """Reference :156-187 (what ``main.py:38,307`` and ``new_method.py:45`` import): switches
+    ``model.config.output_attentions`` on for the whole model, hooks the target layer and parks the logger and the
+    previous config value on the model."""
+    prs = MaskHookLogger(model, device, layer_index)
+    previous = getattr(model.config, "output_attentions", False)
+    model.config.output_attentions = True
+    prs.register_hook()
+    model.hooklogger = prs
+    model._original_output_attentions = previous
+    return prs
 
 
 def revise_mask(patch_mask: torch.Tensor, kernel_size: int = 3, enhance_coe: float = 10) -> torch.Tensor:

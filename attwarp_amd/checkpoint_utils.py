@@ -8,8 +8,10 @@ Differences by design (MI355X-first):
   resamples the whole batch;
 * ``upsample_pdf_right_inverse`` applies a cached 24x24 inverse instead of rebuilding the pooling
   matrix with 48 host syncs and an LU per call (:104-121);
-* the resample arithmetic is exact bilinear (``mode="exact"``); ``mode="cv2"`` emulates OpenCV's
-  1/32-pixel coordinate quantisation.  See DESIGN.md "parity".
+* the resample arithmetic defaults to what ``cv2.remap(INTER_LINEAR)`` computes (``mode="cv2"``: coordinates
+  rounded to 1/32 pixel, 4 table weights for float32, 15-bit fixed point for uint8 -- OpenCV's published algorithm);
+  ``mode="exact"`` is bilinear on the unquantised coordinates (= ``F.grid_sample(bilinear, border,
+  align_corners=True)``).  Both run on the same staged kernels.  See DESIGN.md "parity".
 """
 from __future__ import annotations
 
@@ -26,8 +28,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
 
 
 def _make_strictly_increasing(Fcdf: torch.Tensor, eps: float = 1e-4) -> torch.Tensor:
-    """Reference :17-28.  Fcdf (B,N) -> repaired CDF (B,N) float32."""
+    """Reference :17-28.  Fcdf (B,N) -> repaired CDF (B,N) float32.  (Forward-only kernel; when autograd has to see
+    through it the same steps run on differentiable stock ops, see ``_lib.needs_grad``.)"""
     dev = require_gpu(Fcdf)
+    if _lib.needs_grad(Fcdf):
+        Fn = torch.cummax(torch.nan_to_num(Fcdf, nan=0.0, posinf=1.0, neginf=0.0), dim=1)[0]
+        d = (Fn[:, 1:] - Fn[:, :-1]).clamp(min=eps / max(Fn.shape[1], 1))
+        Fx = torch.cat([Fn[:, :1], Fn[:, :1] + torch.cumsum(d, dim=1)], dim=1)
+        Fx = (Fx / Fx[:, -1:].clamp_min(1e-6)).clamp(0.0, 1.0)
+        return torch.cat([Fx[:, :-1], torch.ones_like(Fx[:, -1:])], dim=1)
     F = _f32c(Fcdf)
     B, N = F.shape
     out = torch.empty_like(F)
@@ -39,6 +48,10 @@ def _make_strictly_increasing(Fcdf: torch.Tensor, eps: float = 1e-4) -> torch.Te
 def cdf_from_density(p: torch.Tensor) -> torch.Tensor:
     """Reference :30-41.  p (B,N) -> non-decreasing CDF in [0,1] ending at 1 (float32)."""
     dev = require_gpu(p)
+    if _lib.needs_grad(p):
+        q = torch.nan_to_num(p.float().clamp_min(0), nan=0.0, posinf=0.0, neginf=0.0)
+        Fp = torch.cumsum(q / q.sum(dim=1, keepdim=True).clamp_min(1e-6), dim=1)
+        return torch.cat([Fp[:, :-1], torch.ones_like(Fp[:, -1:])], dim=1)
     x = _f32c(p)
     B, N = x.shape
     out = torch.empty_like(x)
@@ -50,6 +63,10 @@ def cdf_from_density(p: torch.Tensor) -> torch.Tensor:
 def gt_marginals(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Reference :43-51.  A (B,1,H,W) -> (px (B,W), py (B,H)), normalised."""
     dev = require_gpu(A)
+    if _lib.needs_grad(A):
+        Ap = A.clamp_min(0)
+        mx, my = Ap.sum(dim=2).squeeze(1), Ap.sum(dim=3).squeeze(1)
+        return mx / mx.sum(dim=1, keepdim=True).clamp_min(1e-6), my / my.sum(dim=1, keepdim=True).clamp_min(1e-6)
     B, _, H, W = A.shape
     x = _f32c(A[:, 0])
     px = torch.empty(B, W, device=dev, dtype=torch.float32)
@@ -64,6 +81,10 @@ def gt_marginals(A: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
 def resample_cdf(Fcdf: torch.Tensor, target_len: int) -> torch.Tensor:
     """Reference :53-62."""
     dev = require_gpu(Fcdf)
+    if _lib.needs_grad(Fcdf):
+        up = torch.nn.functional.interpolate(_make_strictly_increasing(Fcdf.float()).unsqueeze(1), size=int(target_len),
+                                             mode="linear", align_corners=True).squeeze(1)
+        return _make_strictly_increasing(up)
     F = _f32c(Fcdf)
     B, N = F.shape
     out = torch.empty(B, int(target_len), device=dev, dtype=torch.float32)
@@ -72,19 +93,47 @@ def resample_cdf(Fcdf: torch.Tensor, target_len: int) -> torch.Tensor:
     return out
 
 
+def _right_inverse_forward(yN: torch.Tensor, L_in: int, eps: float):
+    dev = yN.device
+    L_out = yN.shape[1]
+    inv = _tables.right_inverse_inv(L_out, L_in, eps, dev)
+    y32 = _f32c(yN)
+    out = torch.empty(y32.shape[0], L_in, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        call("attwarp_upsample_pdf_right_inverse", ptr(y32), y32.shape[0], L_out, L_in, ptr(inv), ptr(out),
+             stream_ptr(dev))
+    return out, inv
+
+
+class _RightInverse(torch.autograd.Function):
+    """x_hat = A^T (A A^T + eps I)^-1 y is linear in y: forward on the HIP kernel, backward
+    dy = (A A^T + eps I)^-1 (A dx) = adaptive_avg_pool1d(dx) @ inv (inv is symmetric).  The reference keeps this
+    call on the autograd path of the training loss (MN/trainer.py:217-218)."""
+
+    @staticmethod
+    def forward(ctx, yN, L_in, eps):
+        out, inv = _right_inverse_forward(yN, L_in, eps)
+        ctx.inv, ctx.L_out, ctx.in_dtype = inv, yN.shape[1], yN.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled = torch.nn.functional.adaptive_avg_pool1d(g.float().unsqueeze(1), ctx.L_out).squeeze(1)
+        return (pooled.double() @ ctx.inv).to(ctx.in_dtype), None, None
+
+
 def upsample_pdf_right_inverse(y: torch.Tensor, target_len: int, eps: float = 1e-8) -> torch.Tensor:
-    """Reference :64-131: x_hat = A^T (A A^T + eps I)^-1 y for (L,), (B,L) or (B,C,L) inputs."""
+    """Reference :64-131: x_hat = A^T (A A^T + eps I)^-1 y for (L,), (B,L) or (B,C,L) inputs.  Differentiable
+    with respect to ``y`` (autograd.Function around the kernel)."""
     if y.dim() not in (1, 2, 3):
         raise ValueError(f"upsample_pdf_right_inverse expects 1D/2D/3D y; got shape {tuple(y.shape)}")
-    dev = require_gpu(y)
+    require_gpu(y)
     L_out = y.shape[-1]
     L_in = int(target_len)
-    yN = _f32c(y).reshape(-1, L_out)
-    inv = _tables.right_inverse_inv(L_out, L_in, eps, dev)
-    out = torch.empty(yN.shape[0], L_in, device=dev, dtype=torch.float32)
-    with torch.cuda.device(dev):
-        call("attwarp_upsample_pdf_right_inverse", ptr(yN), yN.shape[0], L_out, L_in, ptr(inv), ptr(out),
-             stream_ptr(dev))
+    if _lib.needs_grad(y):
+        out = _RightInverse.apply(y.reshape(-1, L_out), L_in, float(eps))
+    else:
+        out = _right_inverse_forward(y.reshape(-1, L_out), L_in, float(eps))[0]
     out = out.reshape(*y.shape[:-1], L_in)
     return out.to(y.dtype) if y.dtype.is_floating_point else out
 
@@ -106,7 +155,7 @@ def axis_maps_from_cdf(Fx_img: torch.Tensor, Fy_img: torch.Tensor, out_size: Tup
     return mx, my
 
 
-def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "exact",
+def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "cv2",
                     channels_last: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps on a batch.
     img (B,C,H,W) [or (B,H,W,C) if channels_last] uint8/float32; maps (B,W_out), (B,H_out)."""
@@ -132,7 +181,7 @@ def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor,
 
 
 def warp_from_cdf_torch(img: torch.Tensor, Fx_img: torch.Tensor, Fy_img: torch.Tensor,
-                        out_size: Optional[tuple] = None, mode: str = "exact") -> torch.Tensor:
+                        out_size: Optional[tuple] = None, mode: str = "cv2") -> torch.Tensor:
     """Reference :133-204.
 
     img (B,C,H,W) uint8 or float; Fx_img (B,W), Fy_img (B,H) CDFs in [0,1];

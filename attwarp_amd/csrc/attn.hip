@@ -40,12 +40,14 @@ template <typename T, int NPL, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restrict__ attn, int heads, int64_t sb,
                                                               int64_t sh, int64_t row_off, int64_t skv,
                                                               const int32_t* __restrict__ starts, int starts_mod,
-                                                              int ntok, T* __restrict__ out) {
+                                                              int max_start, int ntok, T* __restrict__ out) {
   __shared__ double part[NT / WAVE][NPL * WAVE];
   constexpr int NW = NT / WAVE;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-  const int st = starts[b % starts_mod];
+  // a slice start outside [0, kv_len - ntok] is clamped (the reference's Python slice clamps too, llava.py:390;
+  // an unclamped start would read outside the attention row)
+  const int st = min(max(starts[b % starts_mod], 0), max_start);
   const T* base = attn + (int64_t)b * sb + row_off + (int64_t)st * skv;
   double acc[NPL];
 #pragma unroll
@@ -97,12 +99,14 @@ template <int NV, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* __restrict__ attn, int heads,
                                                                    int64_t sb, int64_t sh, int64_t row_off,
                                                                    const int32_t* __restrict__ starts, int starts_mod,
-                                                                   int ntok, float* __restrict__ out) {
+                                                                   int max_start, int ntok, float* __restrict__ out) {
   __shared__ double part[NT / WAVE][NV * 4 * WAVE];
   constexpr int NW = NT / WAVE;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-  const int st = starts[b % starts_mod];
+  // a slice start outside [0, kv_len - ntok] is clamped (the reference's Python slice clamps too, llava.py:390;
+  // an unclamped start would read outside the attention row)
+  const int st = min(max(starts[b % starts_mod], 0), max_start);
   const float* base = attn + (int64_t)b * sb + row_off + st;
   double acc[NV][4];
 #pragma unroll
@@ -420,21 +424,21 @@ __global__ __launch_bounds__(NT) void clip_v_kernel(const uint8_t* __restrict__ 
 
 template <typename T>
 static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
-                       const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
+                       const int32_t* starts, int starts_mod, int max_start, int ntok, void* out, hipStream_t st) {
   if constexpr (sizeof(T) == 4) {
     // float32, contiguous kv, slice length a multiple of 4 and <= 768: 16-byte loads
     if (skv == 1 && ntok % 4 == 0 && ntok >= 4 && ntok <= 3 * 4 * WAVE && sb % 1 == 0) {
       hipLaunchKernelGGL((attn_reduce_step_f32v_kernel<3, 4>), dim3(nb), dim3(NT), 0, st, (const float*)attn, heads,
-                         sb, sh, row_off, starts, starts_mod, ntok, (float*)out);
+                         sb, sh, row_off, starts, starts_mod, max_start, ntok, (float*)out);
       return check_launch("attn_reduce_step_f32v_kernel");
     }
   }
   if (ntok <= 9 * WAVE)      // 576 image tokens (LLaVA-1.5): 9 per lane, 4 heads in flight
     hipLaunchKernelGGL((attn_reduce_step_kernel<T, 9, 4>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh,
-                       row_off, skv, starts, starts_mod, ntok, (T*)out);
+                       row_off, skv, starts, starts_mod, max_start, ntok, (T*)out);
   else
     hipLaunchKernelGGL((attn_reduce_step_kernel<T, MAXPL, 2>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb,
-                       sh, row_off, skv, starts, starts_mod, ntok, (T*)out);
+                       sh, row_off, skv, starts, starts_mod, max_start, ntok, (T*)out);
   return check_launch("attn_reduce_step_kernel");
 }
 template <typename T>
@@ -446,11 +450,12 @@ static int launch_finalize(const void* steps, int Tn, int64_t n, void* out, hipS
 
 // dtype-dispatched A1 launch for other translation units (probe.hip chains into it)
 int launch_attn_step_dtype(int dtype, const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off,
-                           int64_t skv, const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st) {
+                           int64_t skv, const int32_t* starts, int starts_mod, int max_start, int ntok, void* out,
+                           hipStream_t st) {
   switch (dtype) {
-    case ATTWARP_F32: return launch_step<float>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
-    case ATTWARP_F16: return launch_step<__half>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
-    default: return launch_step<__hip_bfloat16>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, ntok, out, st);
+    case ATTWARP_F32: return launch_step<float>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, max_start, ntok, out, st);
+    case ATTWARP_F16: return launch_step<__half>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, max_start, ntok, out, st);
+    default: return launch_step<__hip_bfloat16>(attn, nb, heads, sb, sh, row_off, skv, starts, starts_mod, max_start, ntok, out, st);
   }
 }
 
@@ -468,14 +473,15 @@ extern "C" int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int 
                                         const int32_t* starts, int ntok, void* out, void* stream) {
   ATTWARP_REQUIRE(attn && starts && out, "attn_reduce_step: null pointer");
   ATTWARP_REQUIRE(B > 0 && heads > 0 && q_len > 0 && kv_len > 0 && ntok > 0, "attn_reduce_step: non-positive size");
+  ATTWARP_REQUIRE(ntok <= kv_len, "attn_reduce_step: ntok=%d > kv_len=%d", ntok, kv_len);
   if (check_attn_dtype(dtype, "attn_reduce_step")) return ATTWARP_E_ARG;
   if (ntok > MAX_NTOK) return fail(ATTWARP_E_UNSUPPORTED, "attn_reduce_step: ntok=%d > %d", ntok, MAX_NTOK);
   const int64_t row_off = (int64_t)(q_len - 1) * stride_q;
   hipStream_t st = as_stream(stream);
   switch (dtype) {
-    case ATTWARP_F32: return launch_step<float>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
-    case ATTWARP_F16: return launch_step<__half>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
-    default: return launch_step<__hip_bfloat16>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, ntok, out, st);
+    case ATTWARP_F32: return launch_step<float>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, kv_len - ntok, ntok, out, st);
+    case ATTWARP_F16: return launch_step<__half>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, kv_len - ntok, ntok, out, st);
+    default: return launch_step<__hip_bfloat16>(attn, B, heads, stride_b, stride_h, row_off, stride_kv, starts, B, kv_len - ntok, ntok, out, st);
   }
 }
 
@@ -501,15 +507,16 @@ extern "C" int attwarp_attn_reduce_stack(const void* rows, int dtype, int T, int
                                          const int32_t* starts, int ntok, void* out, void* ws, void* stream) {
   ATTWARP_REQUIRE(rows && starts && out && ws, "attn_reduce_stack: null pointer");
   ATTWARP_REQUIRE(T > 0 && B > 0 && heads > 0 && kv_len > 0 && ntok > 0, "attn_reduce_stack: non-positive size");
+  ATTWARP_REQUIRE(ntok <= kv_len, "attn_reduce_stack: ntok=%d > kv_len=%d", ntok, kv_len);
   if (check_attn_dtype(dtype, "attn_reduce_stack")) return ATTWARP_E_ARG;
   if (ntok > MAX_NTOK) return fail(ATTWARP_E_UNSUPPORTED, "attn_reduce_stack: ntok=%d > %d", ntok, MAX_NTOK);
   hipStream_t st = as_stream(stream);
   const int64_t sb = (int64_t)heads * kv_len, sh = kv_len;
   int rc;
   switch (dtype) {
-    case ATTWARP_F32: rc = launch_step<float>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
-    case ATTWARP_F16: rc = launch_step<__half>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
-    default: rc = launch_step<__hip_bfloat16>(rows, T * B, heads, sb, sh, 0, 1, starts, B, ntok, ws, st); break;
+    case ATTWARP_F32: rc = launch_step<float>(rows, T * B, heads, sb, sh, 0, 1, starts, B, kv_len - ntok, ntok, ws, st); break;
+    case ATTWARP_F16: rc = launch_step<__half>(rows, T * B, heads, sb, sh, 0, 1, starts, B, kv_len - ntok, ntok, ws, st); break;
+    default: rc = launch_step<__hip_bfloat16>(rows, T * B, heads, sb, sh, 0, 1, starts, B, kv_len - ntok, ntok, ws, st); break;
   }
   if (rc) return rc;
   return attwarp_attn_finalize(ws, dtype, T, B, ntok, out, stream);
@@ -546,13 +553,13 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
   }
   // small source (the 24 x 24 token grid) and both passes needed: one fused launch
   {
-    const char* fe = getenv("ATTWARP_LANCZOS_VARIANT");
+    const bool two_kernel = tune(TUNE_LANCZOS_VARIANT) == 1;
     const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * out_w;
-    if (need_h && need_v && !(fe && fe[0] == 'g') && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
+    if (need_h && need_v && !two_kernel && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
         ksize_y <= 32 &&
         lds <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
       int R = out_h >= 448 ? 64 : 32;   // measured: 24->336 R=32 27 us (two-kernel form 34), 24->1024 B=256 R=64 258 us (287)
-      if (const char* re = getenv("ATTWARP_LANCZOS_ROWS")) { const int v = atoi(re); if (v >= 1 && v <= 64) R = v; }
+      if (const int v = tune(TUNE_LANCZOS_ROWS); v >= 1 && v <= 64) R = v;
       hipLaunchKernelGGL((lanczos_fused_kernel<8>), dim3((out_h + R - 1) / R, B), dim3(NT), lds, st, mask_f32, mask_u8,
                          h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, ksize_y, R, out);
       return check_launch("lanczos_fused_kernel");

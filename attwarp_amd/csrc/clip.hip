@@ -194,8 +194,7 @@ extern "C" int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int 
   float m[4] = {0, 0, 0, 0}, s[4] = {1, 1, 1, 1};
   for (int c = 0; c < C; ++c) { m[c] = mean[c]; s[c] = stdv[c]; }
 
-  const char* env = getenv("ATTWARP_CLIP_VARIANT");
-  const bool force_generic = env && env[0] == 'g';
+  const bool force_generic = tune(TUNE_CLIP_VARIANT) == 1;
   const long long wc = (long long)w * C, oc = (long long)size * C;
   const long long wcp = (wc + 3) & ~3LL, ocp = (oc + 3) & ~3LL;
   long long RB = (48 * 1024) / (wcp + ocp);               // LDS per workgroup of the horizontal pass

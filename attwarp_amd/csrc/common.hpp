@@ -104,4 +104,26 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_f64<__hip_bfloat16>(d
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- test / measurement overrides -----------------------------------------------
+// Kernel selection is automatic.  The A/B tools and the parity tests need to force a particular variant
+// (e.g. "the generic gather kernel") to check the variants against each other; that goes through
+// attwarp_debug_set() (include/attwarp.h), which stores into this table of relaxed atomics.  -1 = automatic.
+// No environment variable is ever read by the library.
+enum TuneKey {
+  TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only
+  TUNE_REMAP_ROWS,          // output rows per workgroup (1..64)
+  TUNE_REMAP_CHW_SPLIT,     // 0 / 1: planar images plane by plane
+  TUNE_REMAP_TILED,         // 0: rows wider than the LDS row take the generic kernel
+  TUNE_REMAP_TILE_KO,       // 8 / 12
+  TUNE_REMAP_ALT,           // 0: every row block sweeps top-down
+  TUNE_REMAP_NOSWZ,         // 1: no XCD-aware block order
+  TUNE_REMAP_LDSPAD,        // extra dynamic LDS bytes (occupancy experiments)
+  TUNE_LANCZOS_VARIANT,     // 1: two-kernel form
+  TUNE_LANCZOS_ROWS,
+  TUNE_CLIP_VARIANT,        // 1: generic kernels
+  TUNE_PROFILES_VARIANT,    // 1: generic (non byte-packed) profile kernel for uint8 attention
+  TUNE_COUNT
+};
+int tune(TuneKey k);        // current override or -1
+
 }  // namespace attwarp

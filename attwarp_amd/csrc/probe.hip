@@ -22,7 +22,8 @@
 namespace attwarp {
 
 int launch_attn_step_dtype(int dtype, const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off,
-                           int64_t skv, const int32_t* starts, int starts_mod, int ntok, void* out, hipStream_t st);
+                           int64_t skv, const int32_t* starts, int starts_mod, int max_start, int ntok, void* out,
+                           hipStream_t st);
 
 namespace probe {
 
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NT) void attn_probe_kernel(const T* __restrict__ q,
     s += (double)e;
   }
   const float den = (float)block_sum(s, red);      // (block_sum's barriers also publish the e values)
-  const int st = p.starts[b];
+  const int st = min(max(p.starts[b], 0), p.kv - p.ntok);   // clamped like the hook slice (no out-of-row reads)
   T* pr = probs + ((int64_t)b * p.heads + h) * p.ntok;
   for (int t = tid; t < p.ntok; t += NT) {
     const int j = st + t;
@@ -241,5 +242,5 @@ extern "C" int attwarp_attn_probe_last_query(const void* q, const void* k, int d
   }
   if (rc) return rc;
   // A1 on the probed rows: probs [B,heads,ntok], slice start 0 for every sample
-  return launch_attn_step_dtype(dtype, probs, B, heads, (int64_t)heads * ntok, ntok, 0, 1, p.zero, 1, ntok, out, st);
+  return launch_attn_step_dtype(dtype, probs, B, heads, (int64_t)heads * ntok, ntok, 0, 1, p.zero, 1, 0, ntok, out, st);
 }

@@ -1,0 +1,449 @@
+// K7 fast path: float32 bilinear resample with separable monotone maps at (close to) the HBM
+// roofline.  Replaces cv2.remap in AGW/new_method.py:268-271 / MN/checkpoint_utils.py:195-198.
+// The kernel template lives in this header so that the two arithmetic modes are compiled in separate
+// translation units (remap_rows.hip: EXACT, remap_rows_cv2.hip: CV2).
+//
+// Why this shape.  The maps are separable (map_x depends on x only, map_y on y only) and
+// non-decreasing, so (1) an output row needs exactly two source rows, and consecutive output rows
+// need the same or the next source rows; (2) every output row of an image uses the same column taps.
+// One workgroup (256 threads = 4 waves) owns a block of R consecutive output rows of one image:
+//
+//   HBM --16-B coalesced loads--> registers (two register sets = a 2-entry row cache; each thread owns
+//   the same float4 columns of every row) --> LDS row buffer, double buffered
+//   --horizontal gather (taps precomputed once per block in VGPRs)--> coalesced 256-B-per-wave stores --> HBM.
+//
+// EXACT mode stages ONE row per output row, the vertical lerp of the two source rows (2 x ds_read_b32 per
+// output).  CV2 mode cannot: OpenCV's float path evaluates ((p00*w00 + p01*w01) + p10*w10) + p11*w11 with the
+// table weights w = (1-ty|ty)*(1-tx|tx) (exact in float32 because t = k/32), which two nested lerps do not
+// reproduce bit for bit.  It therefore stages BOTH source rows unblended, [top | bottom] exactly one row
+// buffer apart, so that the (p00, p10) pair of a tap is one ds_read2st64_b32 (two dwords a multiple of 256
+// bytes apart with one address register): 2 LDS instructions per output as in EXACT mode, twice the LDS
+// footprint, no vertical lerp.
+//
+// Every source row of the block is read from HBM once, the block re-reads at most one halo row of its
+// neighbour (1/R extra), and the XCD-aware block order makes that halo an L2 hit.  Algorithmic bytes per
+// image = 2*S*S*C*4; no MFMA: there is no contraction here, the kernel is HBM-bound.
+//
+// Arithmetic is identical to remap_gather_kernel / the oracle in both modes.
+#pragma once
+#include "common.hpp"
+
+// Measurement build only (-DATTWARP_EXPERIMENT): lds_pad bit 0 = no global loads (registers keep their old
+// contents), bit 1 = stores only for values that never occur.  Splits the kernel time into its read and write sides.
+#ifdef ATTWARP_EXPERIMENT
+#define ATTWARP_EXP_LOAD(X, rp_)                                                                                   \
+  if (!(p.lds_pad & 1)) { _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
+#define ATTWARP_EXP_STORE(ptr_, v_)                                                                                \
+  if (!(p.lds_pad & 2) || (v_) == -12345.678f) *reinterpret_cast<float*>(ptr_) = (v_)
+#define ATTWARP_EXP_FLAG(b) (p.lds_pad & (b))
+#else
+#define ATTWARP_EXP_FLAG(b) false
+#define ATTWARP_EXP_LOAD(X, rp_) \
+  _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);
+#define ATTWARP_EXP_STORE(ptr_, v_) *reinterpret_cast<float*>(ptr_) = (v_)
+#endif
+
+namespace attwarp {
+
+struct Taps {
+  int i0, i1;
+  float f;
+};
+__device__ __forceinline__ Taps rtaps_exact(float m, int size) {
+  const float fl = floorf(m);
+  Taps t;
+  t.f = fsub(m, fl);
+  const float cl = fminf(fmaxf(fl, -1.0f), (float)size);
+  const int i = (int)cl;
+  t.i0 = min(max(i, 0), size - 1);
+  t.i1 = min(max(i + 1, 0), size - 1);
+  return t;
+}
+// OpenCV's INTER_BITS=5 coordinate quantisation: q = cvRound(m*32), index q>>5, fraction (q&31)/32.
+__device__ __forceinline__ Taps rtaps_cv2(float m, int size) {
+  const float s = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
+  const int q = __float2int_rn(s);
+  const int i = q >> 5;
+  Taps t;
+  t.f = (float)(q & 31) * 0.03125f;
+  t.i0 = min(max(i, 0), size - 1);
+  t.i1 = min(max(i + 1, 0), size - 1);
+  return t;
+}
+template <int MODE>
+__device__ __forceinline__ Taps rtaps(float m, int size) {
+  return MODE == ATTWARP_CV2 ? rtaps_cv2(m, size) : rtaps_exact(m, size);
+}
+// OpenCV float path: ((p00*w00 + p01*w01) + p10*w10) + p11*w11, every operation rounded (same as blend<float,CV2>
+// of remap.hip; the weights are products of k/32 fractions and exact).
+__device__ __forceinline__ float cv2_sum(float p00, float p01, float p10, float p11, float w00, float w01, float w10,
+                                         float w11) {
+  return fadd(fadd(fadd(fmul(p00, w00), fmul(p01, w01)), fmul(p10, w10)), fmul(p11, w11));
+}
+
+struct RowsParams {
+  const float* src;
+  float* dst;
+  const float* mx;  // [B, Wo]
+  const float* my;  // [B, Ho]
+  int H, W, Ho, Wo;
+  int NP, CS;        // planes per image, channel stride inside a row (HWC: 1,C ; CHW: C,1)
+  int row_len;       // W*CS   floats per source row of one plane
+  int orow_len;      // Wo*CS
+  int VLV;           // NP*row_len/4  float4 per "virtual" source row (all planes)
+  int OVL;           // NP*orow_len   output floats per virtual row
+  long long img_stride, plane_stride, oimg_stride, oplane_stride;  // in floats
+  int R;             // output rows per block
+  int nblk;          // blocks per image
+  int nblocks;       // total
+  int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
+  int no_swz;        // 1: disable the XCD-aware block order (experiments)
+  int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
+  int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
+  int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
+};
+
+constexpr int RMAX = 64;
+constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
+
+// Per output row the kernel issues, per thread: KI x (3 lerps x 4) vertical blend + KI ds_write_b128 (CV2: 2 KI
+// ds_write_b128, no blend), one barrier, KO x (2 unpack + 2 LDS reads + lerp / 4-term sum + 1 global_store_dword).
+// Everything that does not depend on the row (taps, store offsets) lives in registers, packed to keep the
+// allocation low enough for >= 3-4 resident workgroups per CU: bytes in flight per CU, not ALU, bound this kernel.
+//
+// Source rows live in TWO register sets X0/X1 used as a 2-entry cache with tags: an output row uses
+// (top, bottom) = whichever sets hold rows (i0, i1).  Right after a row's staging has consumed the
+// registers, the rows the NEXT output row needs are looked up and any missing one is loaded into the
+// set that became dead -- the load then flies during this row's barrier, LDS gather and stores.  The
+// cache logic is correct for arbitrary (also non-monotone) maps; monotone maps simply never miss.
+// AFF: output offsets are tid*4 + a block-uniform term per k (OVL == KO*256 exactly; for planar images also
+// Wo % 256 == 0 so that a k-slice never straddles two planes): no per-element offset table in VGPRs.
+// (forcing >= 4 waves per SIMD on the planar variants, which allocate 130-138 VGPRs, was measured: the
+//  register-limited code is 4-8 % slower than running them at 3 workgroups per CU)
+// TILED (interleaved / one-plane rows wider than the 4096-float LDS row): a workgroup owns a COLUMN TILE of KO*NT
+// output elements of its rows.  The source span the tile needs, [min tap, max tap], is found with a block
+// reduction; it is staged relative to its 4-float-aligned start, so everything after the prologue is the same
+// code.  A tile whose span exceeds KI*NT*4 floats (a map that minifies more than ~1.3x inside the tile) falls back
+// to direct global taps for that tile only.
+// SINGLE (CV2, rows wider than 8 KB): one [top | bottom] buffer and two barriers per row instead of two
+// buffers and one barrier (half the LDS, more resident workgroups).
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>
+__global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
+  constexpr bool CV = MODE == ATTWARP_CV2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_my = smem;                                   // RMAX floats
+  constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
+  constexpr int BUF = CV ? 2 * ROWF : ROWF;             // floats per LDS buffer (CV2: top row, then bottom row)
+  float* rows0 = smem + RMAX;                           // two buffers, addressed with immediates
+  float* rows1 = SINGLE ? rows0 : rows0 + BUF;
+  const int tid = threadIdx.x;
+
+  // XCD-aware block order: blocks bid, bid+8, ... share an XCD (and its L2); hand each XCD a
+  // contiguous range of (image, row-block) pairs so neighbouring row blocks hit the same L2.
+  int bid = blockIdx.x;
+  {
+    const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    if (!p.no_swz) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+  }
+  int b, rb, tile = 0;
+  if (TILED) {          // (image, tile, row block): row blocks of one tile stay neighbours (halo rows meet in L2)
+    const int per_img = p.nblk * p.ntiles;
+    b = bid / per_img;
+    const int rem = bid - b * per_img;
+    tile = rem / p.nblk;
+    rb = rem - tile * p.nblk;
+  } else {
+    b = bid / p.nblk;
+    rb = bid - b * p.nblk;
+  }
+  const int y0 = rb * p.R;
+  const int y1 = min(y0 + p.R, p.Ho);
+  const int nrows = y1 - y0;
+
+  const float* src_b = p.src + (long long)b * p.img_stride;
+  float* dst_b = p.dst + (long long)b * p.oimg_stride;
+
+  const int bm = b / p.map_div;
+  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
+
+  // ---- column taps, once per block, kept in registers.  Lanes past the end of the row duplicate
+  //      the last element (same value to the same address): the row loop has no per-lane branches.
+  unsigned pk[KO];     // LDS BYTE offset of tap 0 | tap 1 << 16   (staged rows are <= 16 KB)
+  float fxr[KO];
+  unsigned ooff[AFF ? 1 : KO];   // BYTE offset of the element inside an output row (incl. plane)
+  unsigned goff[KI];   // BYTE offset inside a source row (incl. plane) of the float4s this thread owns
+  bool direct = false; // TILED: the tile's source span does not fit the LDS row -> global taps
+  unsigned f0s[TILED ? KO : 1], f1s[TILED ? KO : 1];   // TILED: absolute float indices of the two taps
+  if (TILED) {
+    __shared__ int s_lo[NT / WAVE], s_hi[NT / WAVE];
+    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
+    int lo = 0x7fffffff, hi = 0;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) {
+      const int e = min(e0 + tid + NT * k, e1 - 1);
+      const int x = e / p.CS;
+      const int c = e - x * p.CS;
+      const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
+      f0s[k] = tx.i0 * p.CS + c;
+      f1s[k] = tx.i1 * p.CS + c;
+      fxr[k] = tx.f;
+      ooff[k] = (unsigned)e * 4u;
+      lo = min(lo, (int)min(f0s[k], f1s[k]));
+      hi = max(hi, (int)max(f0s[k], f1s[k]));
+    }
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o, WAVE));
+      hi = max(hi, __shfl_xor(hi, o, WAVE));
+    }
+    if ((tid & (WAVE - 1)) == 0) { s_lo[tid / WAVE] = lo; s_hi[tid / WAVE] = hi; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / WAVE; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
+    const int abase = lo & ~3;                          // 4-float aligned start of the staged span
+    const int nf4 = (hi - abase + 4) >> 2;              // float4s covering [abase, hi]
+    direct = nf4 > KI * NT;
+#pragma unroll
+    for (int k = 0; k < KO; ++k) pk[k] = ((f0s[k] - abase) * 4u) | (((f1s[k] - abase) * 4u) << 16);
+#pragma unroll
+    for (int k = 0; k < KI; ++k) goff[k] = (unsigned)(abase + 4 * min(tid + NT * k, nf4 - 1)) * 4u;
+  } else {
+#pragma unroll
+  for (int k = 0; k < KO; ++k) {
+    const int e = min(tid + NT * k, p.OVL - 1);
+    const int pl = HWC ? 0 : e / p.orow_len;
+    const int r = e - pl * p.orow_len;
+    const int x = r / p.CS;
+    const int c = r - x * p.CS;
+    const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
+    const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;
+    const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + c;
+    pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
+    fxr[k] = tx.f;
+    if (!AFF) ooff[k] = ((unsigned)(pl * p.oplane_stride) + (unsigned)r) * 4u;
+  }
+  // ---- which float4 of a source row this thread owns (clamped: padding lanes re-read the last one)
+#pragma unroll
+  for (int k = 0; k < KI; ++k) {
+    const int f = min(tid + NT * k, p.VLV - 1) * 4;
+    const int pl = HWC ? 0 : f / p.row_len;
+    goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
+  }
+  }
+  __syncthreads();
+
+  if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
+    for (int q = 0; q < nrows; ++q) {
+      const Taps ty = rtaps<MODE>(s_my[q], p.H);
+      const float* ra = src_b + (long long)ty.i0 * p.row_len;
+      const float* rc = src_b + (long long)ty.i1 * p.row_len;
+      char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + q) * p.orow_len);
+      const float oy = fsub(1.0f, ty.f);
+#pragma unroll
+      for (int k = 0; k < KO; ++k) {
+        float o_;
+        if (CV) {
+          const float ox = fsub(1.0f, fxr[k]);
+          o_ = cv2_sum(ra[f0s[k]], ra[f1s[k]], rc[f0s[k]], rc[f1s[k]], fmul(oy, ox), fmul(oy, fxr[k]),
+                       fmul(ty.f, ox), fmul(ty.f, fxr[k]));
+        } else {
+          const float v0 = lerp_rn(ra[f0s[k]], rc[f0s[k]], ty.f);      // vertical first, as the staged path
+          const float v1 = lerp_rn(ra[f1s[k]], rc[f1s[k]], ty.f);
+          o_ = lerp_rn(v0, v1, fxr[k]);
+        }
+        *reinterpret_cast<float*>(orow + ooff[k]) = o_;
+      }
+    }
+    return;
+  }
+
+  float4 X0[KI], X1[KI];
+  int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
+  // (macros, not lambdas: the register sets must stay scalar-replaced, never addressed through a pointer)
+#define ATTWARP_LOAD_ROW(X, srow)                                                                   \
+  do {                                                                                              \
+    const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)(srow) * p.row_len);         \
+    ATTWARP_EXP_LOAD(X, rp_)                                                                        \
+  } while (0)
+  // EXACT: the vertical lerp of (XA, XC) into the row buffer; CV2: XA, then XC one row further
+#define ATTWARP_BLEND(rowbuf, XA, XC, fy)                                                           \
+  do {                                                                                              \
+    float4* rowv_ = reinterpret_cast<float4*>(rowbuf);                                              \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                \
+      if (CV) {                                                                                     \
+        rowv_[tid + NT * k] = XA[k];                                                                \
+        rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                                     \
+      } else {                                                                                      \
+        float4 v_;                                                                                  \
+        if (ATTWARP_EXP_FLAG(8)) { rowv_[tid + NT * k] = XA[k]; continue; }                         \
+        v_.x = lerp_rn(XA[k].x, XC[k].x, fy);                                                       \
+        v_.y = lerp_rn(XA[k].y, XC[k].y, fy);                                                       \
+        v_.z = lerp_rn(XA[k].z, XC[k].z, fy);                                                       \
+        v_.w = lerp_rn(XA[k].w, XC[k].w, fy);                                                       \
+        rowv_[tid + NT * k] = v_;                                                                   \
+      }                                                                                             \
+    }                                                                                               \
+  } while (0)
+  // make rows (i0, i1) resident; a set is only overwritten if it holds neither of them
+#define ATTWARP_ENSURE(i0_, i1_)                                                                    \
+  do {                                                                                              \
+    if (t0 != (i0_) && t1 != (i0_)) {                                                               \
+      if (t0 == (i1_)) { ATTWARP_LOAD_ROW(X1, i0_); t1 = (i0_); } else { ATTWARP_LOAD_ROW(X0, i0_); t0 = (i0_); } \
+    }                                                                                               \
+    if (t0 != (i1_) && t1 != (i1_)) {                                                               \
+      if (t0 == (i0_)) { ATTWARP_LOAD_ROW(X1, i1_); t1 = (i1_); } else { ATTWARP_LOAD_ROW(X0, i1_); t0 = (i1_); } \
+    }                                                                                               \
+  } while (0)
+  // byte offset of k-slice k inside an output row (block uniform: scalar registers)
+  auto kbase = [&](int k) -> unsigned {
+    if (HWC) return (unsigned)(NT * 4 * k);
+    const int pl = (NT * k) / p.orow_len;
+    return ((unsigned)(pl * p.oplane_stride) + (unsigned)(NT * k - pl * p.orow_len)) * 4u;
+  };
+  // one output row: stage, prefetch for the next row, gather, store
+#define ATTWARP_DO_ROW(q_, rowbuf)                                                                  \
+  do {                                                                                              \
+    const int yi_ = ybeg + (q_) * ystep;                                                            \
+    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
+    ATTWARP_ENSURE(ty.i0, ty.i1); /* no-op unless the look-ahead missed */                          \
+    const bool top0 = (t0 == ty.i0);                                                                \
+    const bool bot0 = (ty.i1 == ty.i0) ? top0 : (t0 == ty.i1);                                      \
+    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
+    if (top0) {                                                                                     \
+      if (bot0) ATTWARP_BLEND(rowbuf, X0, X0, ty.f); else ATTWARP_BLEND(rowbuf, X0, X1, ty.f);      \
+    } else {                                                                                        \
+      if (bot0) ATTWARP_BLEND(rowbuf, X1, X0, ty.f); else ATTWARP_BLEND(rowbuf, X1, X1, ty.f);      \
+    }                                                                                               \
+    if ((q_) + 1 < nrows) { /* look-ahead: fetch what the next row needs */                         \
+      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
+      ATTWARP_ENSURE(tn.i0, tn.i1);                                                                 \
+    }                                                                                               \
+    __syncthreads();                                                                                \
+    const char* rowb = reinterpret_cast<const char*>(rowbuf);                                       \
+    char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + yi_) * p.orow_len);               \
+    const float fy_ = ty.f, oy_ = fsub(1.0f, ty.f);                                                 \
+    /* gather in two halves: the LDS reads of a half in flight, then their arithmetic + stores */   \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                        \
+      constexpr int KH = (KO + 1) / 2;                                                              \
+      float v0[KH], v1[KH], u0[CV ? KH : 1], u1[CV ? KH : 1];                                       \
+      _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
+        const int k = half * KH + kk;                                                               \
+        if (k < KO) {                                                                               \
+          unsigned w = pk[k];                                                                       \
+          asm volatile("" : "+v"(w)); /* keep the packed form live: no hoisted unpacked offsets */  \
+          v0[kk] = *reinterpret_cast<const float*>(rowb + (w & 0xffffu));                           \
+          v1[kk] = *reinterpret_cast<const float*>(rowb + (w >> 16));                               \
+          if (CV) {                                                                                 \
+            u0[kk] = *reinterpret_cast<const float*>(rowb + (w & 0xffffu) + ROWF * 4);              \
+            u1[kk] = *reinterpret_cast<const float*>(rowb + (w >> 16) + ROWF * 4);                  \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+      _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
+        const int k = half * KH + kk;                                                               \
+        if (k < KO) {                                                                               \
+          const unsigned off = AFF ? (unsigned)(tid * 4) + kbase(k) : ooff[k];                      \
+          float o_;                                                                                 \
+          if (CV) {                                                                                 \
+            const float fx_ = fxr[k], ox_ = fsub(1.0f, fx_);                                        \
+            o_ = cv2_sum(v0[kk], v1[kk], u0[kk], u1[kk], fmul(oy_, ox_), fmul(oy_, fx_),            \
+                         fmul(fy_, ox_), fmul(fy_, fx_));                                           \
+          } else {                                                                                  \
+            o_ = ATTWARP_EXP_FLAG(4) ? v0[kk] : lerp_rn(v0[kk], v1[kk], fxr[k]);                    \
+          }                                                                                         \
+          ATTWARP_EXP_STORE(orow + off, o_);                                                        \
+        }                                                                                           \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }                                                                                               \
+  } while (0)
+
+  // Odd row blocks sweep bottom-up: block i ends, and block i+1 starts, at their shared halo rows at
+  // about the same time, so the second read of those rows is an L2 hit instead of HBM traffic.
+  const bool up = p.alt_dir && (rb & 1);
+  const int ybeg = up ? nrows - 1 : 0, ystep = up ? -1 : 1;
+#pragma unroll
+  for (int k = 0; k < KI; ++k) X0[k] = X1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const Taps tf = rtaps<MODE>(s_my[ybeg], p.H);
+    ATTWARP_ENSURE(tf.i0, tf.i1);
+  }
+  // rows alternate between the two LDS buffers (one barrier per row is enough: a thread can only be
+  // one row ahead of the slowest reader, and then it writes the OTHER buffer)
+  int q = 0;
+  if (ATTWARP_EXP_FLAG(16)) { if (pk[0] == 0xdeadbeef) dst_b[tid] = fxr[1] + X0[0].x; return; }
+  for (; q + 1 < nrows; q += 2) {
+    ATTWARP_DO_ROW(q, rows0);
+    ATTWARP_DO_ROW(q + 1, rows1);
+  }
+  if (q < nrows) ATTWARP_DO_ROW(q, rows0);
+#undef ATTWARP_DO_ROW
+#undef ATTWARP_ENSURE
+#undef ATTWARP_BLEND
+#undef ATTWARP_LOAD_ROW
+}
+
+template <int MODE, bool SINGLE>
+constexpr size_t rows_lds_bytes(int KI, int NT) {
+  return (size_t)(RMAX + (SINGLE ? 1 : 2) * (MODE == ATTWARP_CV2 ? 2 : 1) * KI * NT * 4) * sizeof(float);
+}
+
+template <int NT, int KI, int KO, int MODE, bool SINGLE>
+static int launch_rows_t(const RowsParams& p, hipStream_t st) {
+  const size_t lds = rows_lds_bytes<MODE, SINGLE>(KI, NT) + (size_t)p.lds_pad;
+  const dim3 g(p.nblocks), t(NT);
+  if (p.NP == 1 && p.OVL == KO * NT)   // every (lane, k) is a distinct in-row element: affine store offsets
+    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, true, false, MODE, SINGLE>), g, t, lds, st, p);
+  else if (p.NP == 1)
+    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, false, false, MODE, SINGLE>), g, t, lds, st, p);
+  else if (p.OVL == KO * NT && p.orow_len % NT == 0)   // planar, every k-slice inside one plane
+    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, true, false, MODE, SINGLE>), g, t, lds, st, p);
+  else
+    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, false, false, MODE, SINGLE>), g, t, lds, st, p);
+  return check_launch("remap_rows_kernel");
+}
+
+template <int NT, int KI, int MODE, bool SINGLE>
+static int launch_rows_ki(const RowsParams& p, int ko, hipStream_t st) {
+  if (ko <= 4) return launch_rows_t<NT, KI, 4, MODE, SINGLE>(p, st);
+  if (ko <= 8) return launch_rows_t<NT, KI, 8, MODE, SINGLE>(p, st);
+  if (ko <= 12) return launch_rows_t<NT, KI, 12, MODE, SINGLE>(p, st);
+  return launch_rows_t<NT, KI, 16, MODE, SINGLE>(p, st);
+}
+
+// all staged variants of one arithmetic mode; tile_ko != 0 selects the column-tiled kernel.
+// KIMIN..KIMAX bounds the float4-per-thread counts this instantiation serves (the CV2 kernel with two
+// [top | bottom] buffers needs 64 KB + of LDS at KI = 4, above the 64 KB a launch gets by default: KI = 4 runs
+// the SINGLE-buffer form there).
+template <int MODE, bool SINGLE, int KIMIN, int KIMAX>
+static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st) {
+  constexpr int NT = NT_BIG;
+  if (tile_ko == 8) {
+    if constexpr (KIMIN <= 3 && 3 <= KIMAX) {
+      const size_t lds = rows_lds_bytes<MODE, SINGLE>(3, NT) + (size_t)p.lds_pad;
+      hipLaunchKernelGGL((remap_rows_kernel<NT, 3, 8, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+      return check_launch("remap_rows_kernel");
+    }
+    return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
+  }
+  if (tile_ko == 12) {
+    if constexpr (KIMIN <= 4 && 4 <= KIMAX) {
+      const size_t lds = rows_lds_bytes<MODE, SINGLE>(4, NT) + (size_t)p.lds_pad;
+      hipLaunchKernelGGL((remap_rows_kernel<NT, 4, 12, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+      return check_launch("remap_rows_kernel");
+    }
+    return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
+  }
+  const int ki = (p.VLV + NT - 1) / NT, ko = (p.OVL + NT - 1) / NT;
+  if constexpr (KIMIN <= 1 && 1 <= KIMAX) if (ki <= 1) return launch_rows_ki<NT, 1, MODE, SINGLE>(p, ko, st);
+  if constexpr (KIMIN <= 2 && 2 <= KIMAX) if (ki == 2) return launch_rows_ki<NT, 2, MODE, SINGLE>(p, ko, st);
+  if constexpr (KIMIN <= 3 && 3 <= KIMAX) if (ki == 3) return launch_rows_ki<NT, 3, MODE, SINGLE>(p, ko, st);
+  if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE>(p, ko, st);
+  return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: variant for %d float4 per thread not built", ki);
+}
+
+// defined in remap_rows.hip / remap_rows_cv2.hip
+int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st);
+int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st);
+
+}  // namespace attwarp

@@ -5,6 +5,15 @@
 // bytes -> float32, three individually rounded lerps, round half to even (a lerp of values in [0,255] with a
 // weight in [0,1) stays in [0,255] after every rounding, so no clamp is needed).
 //
+// CV2 mode (OpenCV's uint8 path: 1/32-pixel coordinates, int16 weights w = (32-ky|ky)*(32-kx|kx)*32 scaled to 2^15,
+// result (sum + 2^14) >> 15) runs on the SAME structure: the weighted sum is an integer identity,
+//   sum = 32 * [ (32-kx)*v0 + kx*v1 ],   v = (32-ky)*top + ky*bottom      (v <= 8160, [..] <= 255*1024)
+//   (sum + 2^14) >> 15 = floor(([..] + 512) / 1024)
+// and every intermediate is an integer below 2^24, i.e. exact in float32 whatever the association: the vertical
+// pass stages v, the gather forms t = [..] + 0.5 and takes the low byte of fma(t, 2^-10, 2^23) (round to nearest
+// of y + 2^-11 where y = [..]/1024 has 10 fractional bits: never a tie, equals floor(y + 1/2)).  OpenCV's
+// saturation of the (ky,kx) = (0,0) weight 32768 -> 32767 is not observable ((p*32767 + 2^14) >> 15 = p).
+//
 // This kernel is bound by instruction issue, not by HBM (1500 output bytes per row, each needing two LDS taps
 // and a lerp), so the work per byte is kept minimal and spread over all four waves:
 //   * vertical pass: every thread owns dwords of the source row (4 bytes: global_load_dword, coalesced); both
@@ -25,17 +34,40 @@ constexpr int RMAX = 64;
 
 struct Taps {
   int i0, i1;
-  float f;
+  float f;      // EXACT: fractional part; CV2: k = q & 31 as a float (0 .. 31)
 };
+template <int MODE>
 __device__ __forceinline__ Taps taps(float m, int size) {
-  const float fl = floorf(m);
   Taps t;
-  t.f = fsub(m, fl);
-  const float cl = fminf(fmaxf(fl, -1.0f), (float)size);
-  const int i = (int)cl;
+  int i;
+  if (MODE == ATTWARP_CV2) {
+    const float s = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
+    const int q = __float2int_rn(s);      // cvRound
+    i = q >> 5;
+    t.f = (float)(q & 31);
+  } else {
+    const float fl = floorf(m);
+    t.f = fsub(m, fl);
+    i = (int)fminf(fmaxf(fl, -1.0f), (float)size);
+  }
   t.i0 = min(max(i, 0), size - 1);
   t.i1 = min(max(i + 1, 0), size - 1);
   return t;
+}
+// vertical stage: EXACT a + f*(c-a) (three roundings); CV2 (32-k)*a + k*c (exact integers)
+template <int MODE>
+__device__ __forceinline__ float vblend(float a, float c, float f) {
+  if (MODE == ATTWARP_CV2) return __fmaf_rn(f, fsub(c, a), fmul(32.0f, a));
+  return lerp_rn(a, c, f);
+}
+// horizontal stage + rounding, result in the low byte of the returned float's bit pattern
+template <int MODE>
+__device__ __forceinline__ float hblend_biased(float v0, float v1, float f) {
+  if (MODE == ATTWARP_CV2) {
+    const float t = __fmaf_rn(f, fsub(v1, v0), __fmaf_rn(32.0f, v0, 0.5f));   // (32-k)*v0 + k*v1 + 1/2, exact
+    return __fmaf_rn(t, 0.0009765625f, 8388608.0f);
+  }
+  return fadd(lerp_rn(v0, v1, f), 8388608.0f);   // round half to even: the low byte of (x + 2^23) for 0 <= x <= 255
 }
 
 struct Params {
@@ -57,7 +89,7 @@ struct Params {
 // TILED (rows wider than 4096 bytes, one plane): a workgroup owns a column tile of KO*NT output bytes of its rows,
 // stages the source span [min tap, max tap] relative to its dword-aligned start; a span that does not fit KI*NT
 // dwords is read tap by tap from global memory for that tile (same scheme as remap_rows_kernel's TILED).
-template <int KI, int KO, bool HWC, bool TILED = false>
+template <int KI, int KO, bool HWC, bool TILED, int MODE>
 __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KS = (KO + 3) / 4;
@@ -108,7 +140,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
     for (int k = 0; k < KO; ++k) {
       const int e = min(e0 + tid + NT * k, e1 - 1);
       const int x = e / p.CS, c = e - x * p.CS;
-      const Taps tx = taps(p.mx[(long long)bm * p.Wo + x], p.W);
+      const Taps tx = taps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
       f0s[k] = tx.i0 * p.CS + c;
       f1s[k] = tx.i1 * p.CS + c;
       fxr[k] = tx.f;
@@ -172,7 +204,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
         xe = e - pl * p.orow_len;
         ce = 0;
       }
-      const Taps tx = taps(p.mx[(long long)bm * p.Wo + xe], p.W);
+      const Taps tx = taps<MODE>(p.mx[(long long)bm * p.Wo + xe], p.W);
       const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + ce;
       const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + ce;
       pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
@@ -196,22 +228,22 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
   if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
     const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
     for (int q = 0; q < nrows; ++q) {
-      const Taps ty = taps(s_my[q], p.H);
+      const Taps ty = taps<MODE>(s_my[q], p.H);
       const uint8_t* ra = src_b + (long long)ty.i0 * p.row_len;
       const uint8_t* rc = src_b + (long long)ty.i1 * p.row_len;
       uint8_t* orow = dst_b + (long long)(y0 + q) * p.orow_len;
 #pragma unroll
       for (int k = 0; k < KO; ++k) {
         const int e = e0 + tid + NT * k;
-        const float v0 = lerp_rn((float)ra[f0s[k]], (float)rc[f0s[k]], ty.f);
-        const float v1 = lerp_rn((float)ra[f1s[k]], (float)rc[f1s[k]], ty.f);
-        if (e < e1) orow[e] = (uint8_t)__float_as_uint(fadd(lerp_rn(v0, v1, fxr[k]), 8388608.0f));
+        const float v0 = vblend<MODE>((float)ra[f0s[k]], (float)rc[f0s[k]], ty.f);
+        const float v1 = vblend<MODE>((float)ra[f1s[k]], (float)rc[f1s[k]], ty.f);
+        if (e < e1) orow[e] = (uint8_t)__float_as_uint(hblend_biased<MODE>(v0, v1, fxr[k]));
       }
     }
     return;
   }
 
-  Taps tcur = taps(s_my[0], p.H);
+  Taps tcur = taps<MODE>(s_my[0], p.H);
   uint32_t A[KI], C[KI];
 #define ATTWARP_U8_FETCH()                                                                             \
   _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                      \
@@ -232,14 +264,14 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
     const float fy_ = tcur.f;                                                                          \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
       float4 v_;                                                                                       \
-      v_.x = lerp_rn((float)(A[k] & 0xffu), (float)(C[k] & 0xffu), fy_);                               \
-      v_.y = lerp_rn((float)((A[k] >> 8) & 0xffu), (float)((C[k] >> 8) & 0xffu), fy_);                 \
-      v_.z = lerp_rn((float)((A[k] >> 16) & 0xffu), (float)((C[k] >> 16) & 0xffu), fy_);               \
-      v_.w = lerp_rn((float)(A[k] >> 24), (float)(C[k] >> 24), fy_);                                   \
+      v_.x = vblend<MODE>((float)(A[k] & 0xffu), (float)(C[k] & 0xffu), fy_);                          \
+      v_.y = vblend<MODE>((float)((A[k] >> 8) & 0xffu), (float)((C[k] >> 8) & 0xffu), fy_);            \
+      v_.z = vblend<MODE>((float)((A[k] >> 16) & 0xffu), (float)((C[k] >> 16) & 0xffu), fy_);          \
+      v_.w = vblend<MODE>((float)(A[k] >> 24), (float)(C[k] >> 24), fy_);                              \
       *reinterpret_cast<float4*>((rowbuf) + voff[k]) = v_;                                             \
     }                                                                                                  \
     if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
-      tcur = taps(s_my[(q_) + 1], p.H);                                                                \
+      tcur = taps<MODE>(s_my[(q_) + 1], p.H);                                                                \
       ATTWARP_U8_FETCH()                                                                               \
     }                                                                                                  \
     __syncthreads();                                                                                   \
@@ -250,8 +282,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
       asm volatile("" : "+v"(w_));                                                                     \
       const float v0_ = *reinterpret_cast<const float*>(rowb_ + (w_ & 0xffffu));                       \
       const float v1_ = *reinterpret_cast<const float*>(rowb_ + (w_ >> 16));                           \
-      /* round half to even: the low byte of (x + 2^23) for 0 <= x <= 255 */                           \
-      const float r_ = fadd(lerp_rn(v0_, v1_, fxr[k]), 8388608.0f);                                    \
+      const float r_ = hblend_biased<MODE>(v0_, v1_, fxr[k]);                                          \
       (outbuf)[tid + NT * k] = (uint8_t)__float_as_uint(r_);                                           \
     }                                                                                                  \
   }
@@ -269,26 +300,41 @@ __global__ __launch_bounds__(NT) void remap_rows_u8_kernel(const Params p) {
 #undef ATTWARP_U8_FETCH
 }
 
-template <int KI, int KO>
+template <int KI, int KO, int MODE>
 static int launch_kiko(const Params& p, hipStream_t st) {
   const int VLP = (p.VL + 15) & ~15, OVP = NT * KO;
   const size_t lds = (size_t)(RMAX + 2 * VLP) * sizeof(float) + 2 * (size_t)OVP;
   if (p.NP == 1)
-    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, true>), dim3(p.nblocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, true, false, MODE>), dim3(p.nblocks), dim3(NT), lds, st, p);
   else
-    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, false>), dim3(p.nblocks), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((remap_rows_u8_kernel<KI, KO, false, false, MODE>), dim3(p.nblocks), dim3(NT), lds, st, p);
   return check_launch("remap_rows_u8_kernel");
 }
 
-template <int KO>
+template <int KO, int MODE>
 static int launch_ko(const Params& p, hipStream_t st) {
   const int ki = ((p.VL >> 2) + NT - 1) / NT;
   switch (ki) {
-    case 1: return launch_kiko<1, KO>(p, st);
-    case 2: return launch_kiko<2, KO>(p, st);
-    case 3: return launch_kiko<3, KO>(p, st);
-    default: return launch_kiko<4, KO>(p, st);
+    case 1: return launch_kiko<1, KO, MODE>(p, st);
+    case 2: return launch_kiko<2, KO, MODE>(p, st);
+    case 3: return launch_kiko<3, KO, MODE>(p, st);
+    default: return launch_kiko<4, KO, MODE>(p, st);
   }
+}
+
+template <int MODE>
+static int launch_mode(const Params& p, bool tiled, hipStream_t st) {
+  constexpr int TILE_KO = 8, TILE_KI = 3;      // 2048 output bytes per tile against 3072 staged source bytes
+  if (tiled) {
+    const size_t lds = (size_t)(RMAX + 2 * TILE_KI * NT * 4) * sizeof(float) + 2 * (size_t)(NT * TILE_KO);
+    hipLaunchKernelGGL((remap_rows_u8_kernel<TILE_KI, TILE_KO, true, true, MODE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+    return check_launch("remap_rows_u8_kernel");
+  }
+  const int ko = (p.OVL + NT - 1) / NT;
+  if (ko <= 4) return launch_ko<4, MODE>(p, st);
+  if (ko <= 8) return launch_ko<8, MODE>(p, st);
+  if (ko <= 12) return launch_ko<12, MODE>(p, st);
+  return launch_ko<16, MODE>(p, st);
 }
 
 }  // namespace u8k
@@ -297,9 +343,7 @@ static int launch_ko(const Params& p, hipStream_t st) {
 int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                          const float* mx, const float* my, int mode, hipStream_t st, bool* handled) {
   *handled = false;
-  if (mode != ATTWARP_EXACT) return ATTWARP_OK;
-  const char* env = getenv("ATTWARP_REMAP_VARIANT");
-  if (env && env[0] == 'g') return ATTWARP_OK;
+  if (tune(TUNE_REMAP_VARIANT) == 1) return ATTWARP_OK;
   u8k::Params p;
   p.src = src; p.dst = dst; p.mx = mx; p.my = my;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -318,8 +362,7 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   // up to 4096 bytes per staged row (16-bit LDS offsets); wider rows run in column tiles, planar ones plane by plane
   const bool tiled = VL > 4096 || OVL > 4096;
   if (tiled) {
-    const char* te = getenv("ATTWARP_REMAP_TILED");
-    if (te && atoi(te) == 0) return ATTWARP_OK;
+    if (tune(TUNE_REMAP_TILED) == 0) return ATTWARP_OK;
     if ((long long)p.row_len > 2147483647LL / 8 || (long long)p.orow_len > 2147483647LL / 8 ||
         (long long)B * C > 2147483647LL)
       return ATTWARP_OK;
@@ -340,10 +383,10 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.oimg_stride = (long long)Ho * Wo * C;
   if (p.plane_stride * p.NP > 2147483647LL || p.oplane_stride * p.NP > 2147483647LL) return ATTWARP_OK;
   int R = (OVL >= 2048) ? 32 : 16;   // measured: 1024x1024x3 R=32 7 % faster than 16, 336->500 equal
-  constexpr int TILE_KO = 8, TILE_KI = 3;      // 2048 output bytes per tile against 3072 staged source bytes
+  constexpr int TILE_KO = 8;                   // as in launch_mode
   // (2048x2048x3 uint8, B=64: tiled R=32 0.51 ms, R=16 0.55, R=8 0.67; generic gather kernel 2.32 ms)
   if (tiled) { R = 32; p.ntiles = (p.OVL + TILE_KO * u8k::NT - 1) / (TILE_KO * u8k::NT); }
-  if (const char* renv = getenv("ATTWARP_REMAP_ROWS")) { int v = atoi(renv); if (v >= 1 && v <= u8k::RMAX) R = v; }
+  if (const int v = tune(TUNE_REMAP_ROWS); v >= 1 && v <= u8k::RMAX) R = v;
   if (R > Ho) R = Ho;
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
@@ -351,16 +394,8 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   *handled = true;
-  if (tiled) {
-    const size_t lds = (size_t)(u8k::RMAX + 2 * TILE_KI * u8k::NT * 4) * sizeof(float) + 2 * (size_t)(u8k::NT * TILE_KO);
-    hipLaunchKernelGGL((u8k::remap_rows_u8_kernel<TILE_KI, TILE_KO, true, true>), dim3(p.nblocks), dim3(u8k::NT), lds, st, p);
-    return check_launch("remap_rows_u8_kernel");
-  }
-  const int ko = (p.OVL + u8k::NT - 1) / u8k::NT;
-  if (ko <= 4) return u8k::launch_ko<4>(p, st);
-  if (ko <= 8) return u8k::launch_ko<8>(p, st);
-  if (ko <= 12) return u8k::launch_ko<12>(p, st);
-  return u8k::launch_ko<16>(p, st);
+  if (mode == ATTWARP_CV2) return u8k::launch_mode<ATTWARP_CV2>(p, tiled, st);
+  return u8k::launch_mode<ATTWARP_EXACT>(p, tiled, st);
 }
 
 }  // namespace attwarp

@@ -14,20 +14,22 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend: str | None = None, device_index: int | None = None) -> Tuple[int, int, int]:
+def init(backend: str | None = None, device_index: int | None = None, use_gpu: bool = True) -> Tuple[int, int, int]:
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world_size, local_rank).  Single-process runs need no environment.
     ``device_index`` overrides the GPU (default: LOCAL_RANK) -- only used to smoke-test the N>1 code
-    path on a one-GPU box with the gloo backend."""
+    path on a one-GPU box with the gloo backend.  ``use_gpu=False`` (bench.py --dry-run, CPU tests) never touches
+    the GPU and defaults to gloo."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dev_idx = local if device_index is None else device_index
-    if torch.cuda.is_available():
+    have_gpu = use_gpu and torch.cuda.is_available()
+    if have_gpu:
         torch.cuda.set_device(dev_idx)
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if have_gpu else "gloo"
         dist.init_process_group(backend)      # "nccl" is RCCL on ROCm; rendezvous from MASTER_ADDR/PORT
     return rank, world, local
 

@@ -24,6 +24,10 @@ def safe_softmax(logits: torch.Tensor, dim: int = 1, eps: float = 1e-6) -> torch
     dev = require_gpu(logits)
     if logits.dim() < 1:
         raise ValueError("safe_softmax expects at least one dimension")
+    if _lib.needs_grad(logits):           # training: the same formula on differentiable stock ops (same GPU)
+        z = torch.nan_to_num(logits, nan=0.0, posinf=0.0, neginf=0.0)
+        p = torch.nan_to_num(F.softmax(z - z.amax(dim=dim, keepdim=True), dim=dim), nan=0.0, posinf=0.0, neginf=0.0)
+        return p / p.sum(dim=dim, keepdim=True).clamp_min(eps)
     x = logits.detach().to(torch.float32)
     d = dim % x.dim()
     if d != x.dim() - 1:
@@ -43,6 +47,9 @@ def masked_token_mean(txt_tok: torch.Tensor, txt_mask: torch.Tensor) -> torch.Te
     """``(txt_tok * txt_mask).sum(1) / txt_mask.sum(1).clamp_min(1)`` (reference :77-78) in one pass.
     txt_tok [B,Lt,D] float32/float16/bfloat16, txt_mask [B,Lt,1] or [B,Lt] -> [B,D] float32."""
     dev = require_gpu(txt_tok, txt_mask)
+    if _lib.needs_grad(txt_tok, txt_mask):
+        m = txt_mask.float().reshape(txt_tok.shape[0], txt_tok.shape[1], 1)
+        return (txt_tok.float() * m).sum(dim=1) / m.sum(dim=1).clamp_min(1.0)
     tok = txt_tok.detach().contiguous()
     B, Lt, D = tok.shape
     mask = txt_mask.detach().float().reshape(B, Lt).contiguous()
@@ -56,6 +63,10 @@ def film_axis_means(v: torch.Tensor, gamma_beta: torch.Tensor):
     """``v = gamma*v + beta; vx = v.mean(2); vy = v.mean(3)`` (reference :80-88) in one pass over ``v``.
     v [B,Ch,H,W] float32, gamma_beta [B,2*Ch] (``film`` output) -> (vx [B,Ch,W], vy [B,Ch,H])."""
     dev = require_gpu(v, gamma_beta)
+    if _lib.needs_grad(v, gamma_beta):
+        gamma, beta = gamma_beta.float().chunk(2, dim=1)
+        w = gamma[:, :, None, None] * v.float() + beta[:, :, None, None]
+        return w.mean(dim=2), w.mean(dim=3)
     x = v.detach().float().contiguous()
     gb = gamma_beta.detach().float().contiguous()
     B, Ch, H, W = x.shape
@@ -114,6 +125,13 @@ class MarginalNet(nn.Module):
         return self.head_x(vx).squeeze(1), self.head_y(vy).squeeze(1)
 
     def forward(self, fmap_v, H: int, W: int, txt_tok, txt_mask):
+        """Inference (no grad needed): library GEMMs + the fused HIP tail.  When autograd has to see through the call
+        (training, MN/trainer.py:210-260: ``loss.backward()`` must reach the parameters) the same network runs on
+        differentiable stock ops (``forward_logits``) -- the HIP kernels are forward-only."""
+        if _lib.needs_grad(fmap_v, txt_tok, txt_mask, *self.parameters()):
+            require_gpu(fmap_v, txt_tok, txt_mask)
+            lx, ly = self.forward_logits(fmap_v, H, W, txt_tok, txt_mask)
+            return safe_softmax(lx, dim=1, eps=self.eps), safe_softmax(ly, dim=1, eps=self.eps)
         lx, ly = self.forward_logits_fused(fmap_v, H, W, txt_tok, txt_mask)
         return safe_softmax(lx, dim=1, eps=self.eps), safe_softmax(ly, dim=1, eps=self.eps)
 

@@ -73,7 +73,7 @@ def attention_axis_maps(att: torch.Tensor, new_width: int, new_height: int, tran
     return mx, my
 
 
-def remap_hwc(image: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "exact") -> torch.Tensor:
+def remap_hwc(image: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "cv2") -> torch.Tensor:
     """image [B,H,W,C] uint8/float32 (GPU) -> [B,H_out,W_out,C]."""
     from .checkpoint_utils import remap_separable
     return remap_separable(image, map_x, map_y, mode=mode, channels_last=True)
@@ -82,10 +82,11 @@ def remap_hwc(image: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mod
 def warp_image_by_attention(image: np.ndarray, att_map: np.ndarray, new_width: int, new_height: int,
                             transform: Optional[str] = None, exp_scale: Optional[float] = None,
                             exp_divisor: Optional[float] = None, apply_inverse: Optional[bool] = None,
-                            mode: str = "exact") -> np.ndarray:
+                            mode: str = "cv2") -> np.ndarray:
     """Reference :198-283.  image [h,w,3] (or [h,w]) uint8/float32, att_map [h,w] -> warped
     [new_height,new_width,3].  Transform arguments default to the module state set by
-    ``set_transform_function`` (the reference's behaviour)."""
+    ``set_transform_function`` (the reference's behaviour).  ``mode="cv2"`` (default) reproduces the
+    arithmetic of the reference's ``cv2.remap(INTER_LINEAR, BORDER_REPLICATE)`` call (:268-271)."""
     transform = ATTENTION_TRANSFORM if transform is None else transform
     exp_scale = EXP_SCALE if exp_scale is None else exp_scale
     exp_divisor = EXP_DIVISOR if exp_divisor is None else exp_divisor
@@ -124,7 +125,7 @@ def resize_image_to_match_attmap(image: Optional[np.ndarray], att_map: Optional[
         img = img[:, :, None]
     mx = ((torch.arange(tw, dtype=torch.float64) + 0.5) * (cw / tw) - 0.5).clamp(0, cw - 1).float().to(dev)[None]
     my = ((torch.arange(th, dtype=torch.float64) + 0.5) * (ch / th) - 0.5).clamp(0, ch - 1).float().to(dev)[None]
-    out = remap_hwc(torch.from_numpy(np.ascontiguousarray(img)).to(dev).unsqueeze(0), mx, my)[0].cpu().numpy()
+    out = remap_hwc(torch.from_numpy(np.ascontiguousarray(img)).to(dev).unsqueeze(0), mx, my, "exact")[0].cpu().numpy()
     return out[:, :, 0] if squeeze else out
 
 
@@ -149,12 +150,14 @@ def _coerce_att_map(att_map, width, height):
 
 def save_warped_image(image_path, att_map, original_image_save_path, masked_overlay_save_path, output_path,
                       vis_path=None, width=500, height=500, transform="identity", exp_scale=1.0, exp_divisor=1.0,
-                      apply_inverse=False, attention_alpha=0.5):
+                      apply_inverse=False, attention_alpha=0.5, mode="cv2"):
     """Reference :405-506.  Warps ``image_path`` (path or PIL image) by ``att_map`` and writes the
     result to ``output_path``; returns True, or prints the error and returns False (the reference
     swallows every exception, :504-506).  Images are handled in BGR order like the reference;
     files are written with Pillow.  The overlay / visualisation strip outputs are out of scope
-    (visualisation only): ``masked_overlay_save_path`` and ``vis_path`` are accepted and ignored."""
+    (visualisation only): ``masked_overlay_save_path`` and ``vis_path`` are accepted and ignored.
+    ``mode`` (not in the reference) selects the resample arithmetic: "cv2" (default, what the reference's
+    ``cv2.remap`` call computes) or "exact"."""
     try:
         from PIL import Image
         if isinstance(image_path, str):
@@ -175,7 +178,7 @@ def save_warped_image(image_path, att_map, original_image_save_path, masked_over
             raise ValueError("Failed to resize image to match attention map dimensions for warping")
         name = set_transform_function(transform, exp_scale, exp_divisor, apply_inverse)
         warped = warp_image_by_attention(image_for_warping, att_map, width, height, name, exp_scale, exp_divisor,
-                                         apply_inverse)
+                                         apply_inverse, mode)
         if warped is None:
             raise ValueError("Warping failed")
         _imwrite(output_path, warped)

@@ -70,7 +70,7 @@ def axis_maps_from_pdf(px: torch.Tensor, py: torch.Tensor, size_hw: Tuple[int, i
 
 
 def warp_from_pdf(images: torch.Tensor, px: torch.Tensor, py: torch.Tensor, out_size=None, channels_last=False,
-                  mode: str = "exact") -> torch.Tensor:
+                  mode: str = "cv2") -> torch.Tensor:
     """images [B,C,H,W] (or [B,H,W,C]) float32/uint8; px [B,24] over x, py [B,24] over y."""
     if channels_last:
         H, W = images.shape[1], images.shape[2]
@@ -119,7 +119,7 @@ def attention_step_maps(rows: torch.Tensor, starts: torch.Tensor, ntok: int = ae
 
 
 def warp_from_attention_stack(images: torch.Tensor, rows: torch.Tensor, starts: torch.Tensor, out_size=None,
-                              channels_last=False, mode: str = "exact", out: Optional[torch.Tensor] = None,
+                              channels_last=False, mode: str = "cv2", out: Optional[torch.Tensor] = None,
                               starts_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """images: batch on the GPU; rows [T,B,heads,kv] last-query attention rows; starts int32 [B].
     Three launches for float32 attention: A1 (step maps) -> fused A2+A6+A8+A9+A11 (maps) -> A12 (warp)."""
@@ -140,7 +140,7 @@ def warp_from_attention_stack(images: torch.Tensor, rows: torch.Tensor, starts: 
 
 def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500, 500), enhance_coe=10,
                     kernel_size=3, transform="identity", exp_scale=1.0, exp_divisor=1.0, apply_inverse=False,
-                    mode: str = "exact") -> torch.Tensor:
+                    mode: str = "cv2") -> torch.Tensor:
     """The ``main_batched.py:243-287`` chain for a batch of equally sized images.
     images_u8 [B,H,W,3] uint8 (channel order is irrelevant to the warp); attn24 [B,24,24].
     -> [B,H_out,W_out,3] uint8."""
@@ -153,7 +153,7 @@ def warp_from_masks(images_u8: torch.Tensor, attn24: torch.Tensor, out_size=(500
 
 @torch.no_grad()
 def warp_from_marginalnet(net, fmap_v: torch.Tensor, txt_tok: torch.Tensor, txt_mask: torch.Tensor,
-                          images: torch.Tensor, out_size=None, channels_last=False, mode: str = "exact"):
+                          images: torch.Tensor, out_size=None, channels_last=False, mode: str = "cv2"):
     """BASELINE config 5's device-resident chain: MarginalNet(hidden=256) forward (stock PyTorch-ROCm ops +
     the HIP safe_softmax) -> px, py over the 24 x 24 grid -> A8+A9+A11 (one launch) -> A12 warp.
     Mirrors the inference block of the reference trainer (MN/trainer.py:210, :285-289).

@@ -5,31 +5,40 @@ A "step" is one pass of the hot path over one batch of synthetic inputs already 
 
     attention rows [T=20, B, 32 heads, kv=640] float32
       -> A1+A2 aggregation -> 24x24 map -> A6 marginals -> A8+A9+A11 PDF -> CDF -> inverse maps
-      -> A12 bilinear resample of images [B, S, S, 3] float32 (HWC)  -> warped [B, S, S, 3]
+      -> A12 bilinear resample of images [B, S, S, 3] float32  -> warped [B, S, S, 3]
 
-Default workload = BASELINE configs[2] (B=256 per GPU, S=1024: the configuration the 70 %-of-roofline
-target is quoted on; it fits one GPU: 3.2 GB in + 3.2 GB out).  ``--workload 336`` runs configs[1]
-(B=64, S=336); the 336 result is also attached to the default line under "also".  With N GPUs every
-rank processes its own B images (weak scaling, the path shards by image, no data-path collective);
-the only collective is the start-up RCCL broadcast of MarginalNet weights, untimed.
+Workloads (``--workload``):
+  1024     BASELINE configs[2]: B=256 per GPU, S=1024 (default; the configuration the 70 %-of-roofline target is
+           quoted on; 3.2 GB in + 3.2 GB out per GPU)
+  336      BASELINE configs[1]: B=64, S=336
+  336x256  BASELINE configs[3]: B=256 per GPU, S=336 (2048 images over 8 ranks)
+Arithmetic (``--mode``): ``cv2`` (default) = what the reference's cv2.remap(INTER_LINEAR) call computes (1/32-px
+quantised coordinates, 4 table weights); ``exact`` = unquantised bilinear (= F.grid_sample).  Both run on the same
+staged kernel; the default line measures cv2 and attaches the exact-mode, CHW-layout and 336 measurements under
+"also_exact", "also_chw", "also".
+
+``--gpus N`` (N > 1) is self-launching: when RANK is not in the environment the parent -- before it touches the GPU --
+starts N child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), one per GPU,
+relays rank 0's JSON line and exits non-zero if any rank failed.  Launched under ``torch.distributed.run`` (RANK set)
+it simply is one of the ranks.  Every rank processes its own B images (weak scaling, the path shards by image, no
+data-path collective); the only collective is the start-up RCCL broadcast of MarginalNet weights, untimed.
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     dominant kernel (remap_rows_kernel): algorithmic bytes (2*S*S*3*4 per image)
                / its mean launch duration measured live with HIP events inside the timed region,
                against the 8 TB/s HBM peak.
   cpu_baseline the plain-C restatement of the same path (oracle/warp_ref.c, "port") timed on this
-               box's host on a bounded sample, single thread.
+               box's host on a bounded sample: one thread, and one process per host core.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -37,14 +46,116 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 T_STEPS, HEADS, KV, NTOK = 20, 32, 640, 576
-WORKLOADS = {"1024": (256, 1024), "336": (64, 336)}
+WORKLOADS = {"1024": (256, 1024, 2), "336": (64, 336, 1), "336x256": (256, 336, 3)}   # B per GPU, S, BASELINE config
 
 
-def make_inputs(B: int, S: int, dev, seed: int):
-    """Synthetic inputs of SURVEY 8d: uniform [0,1) float32 HWC images; attention rows = softmax of a
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  ->  N ranks.  Runs before torch is imported; never touches the GPU.
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, ATTWARP_BENCH_CHILD="1")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
+    line0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        print(f"[bench] rank exit codes {rcs}: at least one rank failed", file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        return 1
+    lines = [l for l in line0.decode().splitlines() if l.startswith("{")]
+    if not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle/warp_ref.c through oracle/c_oracle.py -- the checker, timed beside the product)
+# ----------------------------------------------------------------------------------------------------------------
+def _cpu_inputs(S: int, n: int, seed: int):
+    """Host-side synthetic inputs of the same distributions as make_inputs()."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    img = rng.random((n, S, S, 3), dtype=np.float32)
+    lg = rng.standard_normal((T_STEPS, n, HEADS, KV)).astype(np.float32)
+    e = np.exp(lg - lg.max(-1, keepdims=True))
+    rows = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    starts = (35 + np.arange(n) % 8).astype(np.int32)
+    return img, rows, starts
+
+
+def _cpu_loop(img, rows, starts, S, mode, budget_s):
+    from oracle import c_oracle, warp_oracle as O
+    inv = O.right_inverse_core(24, S)              # the oracle's own table (not the product's)
+    n_max = img.shape[0]
+    out0 = c_oracle.warp_from_attention_stack(img[0], rows[:, 0], starts[0], inv, inv, mode=mode)   # warm caches
+    t0 = time.perf_counter()
+    n = 0
+    while True:                                    # cycle over the sample until the time budget is spent
+        c_oracle.warp_from_attention_stack(img[n % n_max], rows[:, n % n_max], starts[n % n_max], inv, inv, mode=mode)
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 2:
+            break
+    return n, time.perf_counter() - t0, out0
+
+
+def _cpu_worker(idx, S, mode, budget_s, start_evt, q):
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[idx % len(os.sched_getaffinity(0))]})
+    except Exception:
+        pass
+    img, rows, starts = _cpu_inputs(S, 2, 9000 + idx)
+    start_evt.wait()
+    n, dt, _ = _cpu_loop(img, rows, starts, S, mode, budget_s)
+    q.put((n, dt))
+
+
+def cpu_baseline_all_cores(S: int, mode: str, budget_s: float = 10.0):
+    """One process per host core over disjoint synthetic image shards.  MUST run before this process
+    initialises the GPU: the workers are forked."""
+    import multiprocessing as mp
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ctx = mp.get_context("fork")
+    q, evt = ctx.Queue(), ctx.Event()
+    procs = [ctx.Process(target=_cpu_worker, args=(i, S, mode, budget_s, evt, q)) for i in range(ncores)]
+    for p in procs:
+        p.start()
+    time.sleep(min(20.0, 1.0 + 0.02 * ncores + (3.0 if S >= 1024 else 0.5)))   # let every worker build its inputs
+    t0 = time.perf_counter()
+    evt.set()
+    res = [q.get(timeout=budget_s * 6 + 120) for _ in procs]
+    wall = time.perf_counter() - t0
+    for p in procs:
+        p.join(30)
+    total = sum(n for n, _ in res)
+    rate = sum(n / dt for n, dt in res)
+    return {"value": round(rate, 2), "unit": "images/s", "cores": ncores, "images": total, "wall_s": round(wall, 1)}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GPU side
+# ----------------------------------------------------------------------------------------------------------------
+def make_inputs(B: int, S: int, dev, seed: int, layout: str):
+    """Synthetic inputs of SURVEY 8d: uniform [0,1) float32 images; attention rows = softmax of a
     640-wide random-normal row, image tokens at starts = 35 + (b mod 8)."""
+    import torch
     g = torch.Generator(device=dev).manual_seed(seed)
-    img = torch.rand((B, S, S, 3), device=dev, generator=g)
+    img = torch.rand((B, S, S, 3) if layout == "hwc" else (B, 3, S, S), device=dev, generator=g)
     rows = torch.empty((T_STEPS, B, HEADS, KV), device=dev)
     for t in range(T_STEPS):                       # chunked: keeps the temporary small
         rows[t] = torch.softmax(torch.randn((B, HEADS, KV), device=dev, generator=g), dim=-1)
@@ -55,11 +166,12 @@ def make_inputs(B: int, S: int, dev, seed: int):
 class Step:
     """The hot-path step on static buffers, with HIP events around the dominant kernel."""
 
-    def __init__(self, B, S, dev, seed):
+    def __init__(self, B, S, dev, seed, mode="cv2", layout="hwc"):
+        import torch
         from attwarp_amd import attention_extraction as ae, checkpoint_utils as cu, pipeline
-        self.ae, self.cu, self.pipeline = ae, cu, pipeline
-        self.B, self.S = B, S
-        self.img, self.rows, self.starts = make_inputs(B, S, dev, seed)
+        self.torch, self.ae, self.cu, self.pipeline = torch, ae, cu, pipeline
+        self.B, self.S, self.mode, self.layout = B, S, mode, layout
+        self.img, self.rows, self.starts = make_inputs(B, S, dev, seed, layout)
         self.out = torch.empty_like(self.img)
         self.starts_tiled = self.starts.repeat(T_STEPS)
         self.events = []
@@ -67,6 +179,7 @@ class Step:
     def __call__(self, record: bool = False):
         # same three launches as attwarp_amd.pipeline.warp_from_attention_stack, with HIP events between them
         # (torch's current stream == the stream the kernels are launched on)
+        torch = self.torch
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
         if record:
             ev[0].record()
@@ -76,7 +189,7 @@ class Step:
         mx, my = self.pipeline.axis_maps_from_attention_steps(steps, (self.S, self.S))
         if record:
             ev[2].record()
-        self.cu.remap_separable(self.img, mx, my, channels_last=True, out=self.out)
+        self.cu.remap_separable(self.img, mx, my, mode=self.mode, channels_last=(self.layout == "hwc"), out=self.out)
         if record:
             ev[3].record()
             self.events.append(ev)
@@ -84,68 +197,47 @@ class Step:
 
     def stage_ms(self):
         """Mean duration of the three kernels of a step: (attention reduce, maps, resample)."""
-        return [float(np.mean([e[i].elapsed_time(e[i + 1]) for e in self.events])) for i in range(3)]
+        return [float(sum(e[i].elapsed_time(e[i + 1]) for e in self.events) / len(self.events)) for i in range(3)]
 
     def remap_ms(self):
         return [e[2].elapsed_time(e[3]) for e in self.events]
 
 
-def run_workload(name, steps, warmup, dist_mod, dev, rank):
-    B, S = WORKLOADS[name]
-    step = Step(B, S, dev, seed=1234 + rank)
+def time_steps(step, steps, warmup, D):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    import torch
+    step.events = []
     for _ in range(warmup):
         step()
-    dist_mod.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step(record=True)
     torch.cuda.synchronize()
-    dist_mod.barrier()
+    D.barrier()
     wall = time.perf_counter() - t0
-    wall = dist_mod.max_over_ranks(wall)
-    remap = step.remap_ms()
-    return step, wall, remap
+    return D.max_over_ranks(wall), wall
 
 
-def cpu_baseline(step: "Step", budget_s: float = 12.0):
-    """Time the plain-C port of the same path (oracle/warp_ref.c) on this host: one thread, a bounded
-    sample of the batch (whole images through attention reduce -> ... -> remap)."""
-    from oracle import c_oracle
-    from attwarp_amd import _tables
-    c_oracle.load()
-    S = step.S
-    inv = _tables._right_inverse_inv_host(24, S, 1e-8)
-    n_max = min(step.B, 64)
-    img = step.img[:n_max].cpu().numpy()
-    rows = step.rows[:, :n_max].cpu().numpy()
-    starts = step.starts[:n_max].cpu().numpy()
-    out0 = c_oracle.warp_from_attention_stack(img[0], rows[:, 0], starts[0], inv, inv)     # warm caches
-    t0 = time.perf_counter()
-    n = 0
-    while True:                                   # cycle over the sample until the time budget is spent
-        c_oracle.warp_from_attention_stack(img[n % n_max], rows[:, n % n_max], starts[n % n_max], inv, inv)
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 4:
-            break
-    dt = time.perf_counter() - t0
-    # the sample doubles as a parity check of what was just benchmarked
-    err = float(np.abs(step.out[0].cpu().numpy() - out0).max())
-    return {"value": round(n / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
-            "sample": f"{n} image passes over the first {n_max} of the {step.B} {S}x{S} images through "
-                      f"oracle/warp_ref.c (attention reduce .. remap), 1 thread of {os.cpu_count()} host cores, "
-                      f"{dt:.1f} s",
-            "max_abs_diff_vs_gpu_image0": err}
+def roofline_of(step, traffic=None):
+    rm = step.remap_ms()
+    mean = sum(rm) / len(rm)
+    alg = 2.0 * step.S * step.S * 3 * 4 * step.B
+    ach = alg / (mean * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "remap_rows_kernel", "mode": step.mode, "layout": step.layout.upper(),
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg, "kernel_ms_mean": round(mean, 4),
+            "kernel_ms_min": round(min(rm), 4), "launches_timed": len(rm)}
 
 
-def load_pmc_traffic(workload: str):
+def load_pmc_traffic(workload: str, mode: str):
     """HBM bytes per launch of the remap kernel from the committed rocprofv3 --pmc summary
-    (profiles/round1_pmc.json, collected with this same command).  None if absent."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    (profiles/pmc_traffic.json, collected with this same command).  None if absent."""
     try:
-        with open(p) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
-        return d.get(workload, {}).get("remap_rows_kernel_bytes_per_launch")
+        return d.get(f"{workload}_{mode}", d.get(workload, {})).get("remap_rows_kernel_bytes_per_launch")
     except Exception:
         return None
 
@@ -156,22 +248,63 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1024")
+    ap.add_argument("--mode", choices=["cv2", "exact"], default="cv2", help="resample arithmetic of the main line")
+    ap.add_argument("--layout", choices=["hwc", "chw"], default="hwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary 336x336 measurement")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (exact / CHW / 336)")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="force the GPU index (smoke-testing the N>1 path on a one-GPU box with --dist-backend gloo)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: rendezvous, weight broadcast, counters and the JSON line only (CPU tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no torch import, no GPU call
+
+    B, S, cfg_idx = WORKLOADS[args.workload]
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    rank_env = int(os.environ.get("RANK", "0"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}; start it as "
+                         f"`python bench.py --gpus {args.gpus}` or under torch.distributed.run with --nproc-per-node {args.gpus}")
+
+    # all-core CPU baseline: forked workers, so it runs BEFORE anything initialises the GPU in this process
+    cpu_all = None
+    want_cpu = rank_env == 0 and world_env == 1 and not args.no_cpu_baseline and not args.dry_run
+    if want_cpu:
+        cpu_all = cpu_baseline_all_cores(S, args.mode)
+
+    import numpy as np
+    import torch
     from attwarp_amd import dist as D, _lib
-    rank, world, local = D.init(args.dist_backend, args.device)
+    rank, world, local = D.init(args.dist_backend if not args.dry_run else (args.dist_backend or "gloo"), args.device,
+                                use_gpu=not args.dry_run)
     if args.device is not None:
         local = args.device
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    _lib.load()
+
+    if args.dry_run:
+        from attwarp_amd.model import MarginalNet
+        net = MarginalNet(16, 24, 8)
+        nbytes = D.broadcast_module_weights(net, src=0) if world > 1 else 0
+        D.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (1 + rank))
+        wall_local = time.perf_counter() - t0
+        wall = D.max_over_ranks(wall_local)
+        per = D.all_gather_counters({"images": float(B * args.steps), "wall_s": wall_local})
+        if rank == 0:
+            print(json.dumps({"metric": "warped images/sec", "value": None, "unit": "images/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                              "weights_broadcast": {"bytes": nbytes}, "per_rank_images": per["images"],
+                              "max_wall_s": wall, "config": {"workload": args.workload, "batch_per_gpu": B}}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    _lib.load()
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -187,13 +320,12 @@ def main():
         bcast = {"bytes": nbytes, "ms": round((time.perf_counter() - t0) * 1e3, 3)}
         del net
 
-    step, wall, remap = run_workload(args.workload, args.steps, args.warmup, D, dev, rank)
-    B, S = WORKLOADS[args.workload]
+    step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
+    wall, wall_local = time_steps(step, args.steps, args.warmup, D)
+    per_rank = D.all_gather_counters({"images_per_s": B * args.steps / wall_local})
     ms_per_step = wall / args.steps * 1e3
     value = world * B * args.steps / wall
-    remap_ms = float(np.mean(remap))
-    alg_bytes = 2.0 * S * S * 3 * 4 * B
-    achieved = alg_bytes / (remap_ms * 1e-3) / 1e9
+    roof = roofline_of(step, load_pmc_traffic(args.workload, args.mode))
 
     result = {
         "metric": "warped images/sec",
@@ -208,40 +340,73 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"batch-{B} {S}x{S}x3 float32 HWC images per GPU + attention rows "
+        "config": {"workload": f"batch-{B} {S}x{S}x3 float32 {args.layout.upper()} images per GPU + attention rows "
                                f"[T={T_STEPS},B,{HEADS},{KV}] float32 -> reduce -> 24x24 -> marginals -> CDF -> "
-                               f"inverse maps -> bilinear warp (BASELINE configs[{2 if S == 1024 else 1}])",
-                   "batch_per_gpu": B, "image_size": S, "layout": "HWC", "global_batch": world * B,
+                               f"inverse maps -> bilinear warp, mode={args.mode} "
+                               f"({'cv2.remap arithmetic: 1/32-px coordinates, 4 table weights' if args.mode == 'cv2' else 'unquantised bilinear = grid_sample'}) "
+                               f"(BASELINE configs[{cfg_idx}])",
+                   "mode": args.mode, "batch_per_gpu": B, "image_size": S, "layout": args.layout.upper(),
+                   "global_batch": world * B,
                    "sharding": "contiguous image blocks per rank, no data-path collective"},
-        "roofline": {"bound": "hbm", "kernel": "remap_rows_kernel", "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": load_pmc_traffic(args.workload),
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_mean": round(remap_ms, 4),
-                     "kernel_ms_min": round(float(np.min(remap)), 4), "launches_timed": len(remap)},
+        "roofline": roof,
     }
     st_ms = step.stage_ms()
     result["stages_ms"] = {"attn_reduce_step_kernel": round(st_ms[0], 4), "axis_maps_from_steps_kernel": round(st_ms[1], 4),
                            "remap_rows_kernel": round(st_ms[2], 4)}
+    if world > 1:
+        result["per_rank_images_per_s"] = [round(v, 1) for v in per_rank["images_per_s"]]
     if bcast:
         result["weights_broadcast"] = bcast
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(step)
+    if want_cpu:
+        n_max = min(B, 16 if S >= 1024 else 64)
+        img = step.img[:n_max].cpu().numpy()
+        if args.layout == "chw":
+            img = np.ascontiguousarray(img.transpose(0, 2, 3, 1))
+        n, dt, out0 = _cpu_loop(img, step.rows[:, :n_max].cpu().numpy(), step.starts[:n_max].cpu().numpy(), S, args.mode, 10.0)
+        g0 = step.out[0].cpu().numpy()
+        if args.layout == "chw":
+            g0 = g0.transpose(1, 2, 0)
+        result["cpu_baseline"] = {
+            "value": round(n / dt, 3), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{n} image passes over the first {n_max} of the {B} {S}x{S} images through oracle/warp_ref.c "
+                      f"(attention reduce .. remap, mode={args.mode}; right-inverse table from oracle/), 1 thread, {dt:.1f} s",
+            "max_abs_diff_vs_gpu_image0": float(np.abs(g0 - out0).max()),    # the sample doubles as a parity check
+            "all_cores": dict(cpu_all, kind="port",
+                              sample=f"one process per host core ({cpu_all['cores']}), each cycling over 2 private synthetic "
+                                     f"{S}x{S} images for ~10 s; sum of per-process rates"),
+        }
+
+    if world == 1 and not args.no_also:
+        other = "exact" if args.mode == "cv2" else "cv2"
+        step.mode = other                                     # same buffers, the other arithmetic
+        w2, _ = time_steps(step, args.steps, args.warmup, D)
+        result[f"also_{other}"] = {"workload": f"same batch, mode={other}", "value": round(B * args.steps / w2, 1),
+                                   "unit": "images/s", "ms_per_step": round(w2 / args.steps * 1e3, 4),
+                                   "roofline": roofline_of(step, load_pmc_traffic(args.workload, other))}
+        step.mode = args.mode
+        # the other layout (CHW is what warp_from_cdf_torch receives, MN/checkpoint_utils.py:152)
+        lay2 = "chw" if args.layout == "hwc" else "hwc"
+        step.img = step.img.permute(0, 3, 1, 2).contiguous() if lay2 == "chw" else step.img.permute(0, 2, 3, 1).contiguous()
+        step.out = torch.empty_like(step.img)
+        step.layout = lay2
+        w3, _ = time_steps(step, args.steps, args.warmup, D)
+        result[f"also_{lay2}"] = {"workload": f"same batch as [B,3,S,S] planar float32, mode={args.mode}" if lay2 == "chw"
+                                  else f"same batch as [B,S,S,3], mode={args.mode}",
+                                  "value": round(B * args.steps / w3, 1), "unit": "images/s",
+                                  "ms_per_step": round(w3 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
     del step
     torch.cuda.empty_cache()
 
-    if args.workload == "1024" and not args.no_also:
-        step2, wall2, remap2 = run_workload("336", max(args.steps, 50), args.warmup, D, dev, rank)
-        B2, S2 = WORKLOADS["336"]
+    if world == 1 and args.workload == "1024" and not args.no_also:
+        B2, S2, _ = WORKLOADS["336"]
         n2 = max(args.steps, 50)
-        rm2 = float(np.mean(remap2))
-        ach2 = 2.0 * S2 * S2 * 3 * 4 * B2 / (rm2 * 1e-3) / 1e9
-        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), eager launches (a HIP-graph replay of the "
-                                      f"same 3 kernels measured identical: the step is GPU-bound)",
-                          "value": round(world * B2 * n2 / wall2, 1), "unit": "images/s",
-                          "ms_per_step": round(wall2 / n2 * 1e3, 4),
-                          "roofline": {"achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": round(ach2 / HBM_PEAK_GBS, 4), "kernel_ms_mean": round(rm2, 4)}}
+        step2 = Step(B2, S2, dev, seed=99, mode=args.mode, layout=args.layout)
+        w4, _ = time_steps(step2, n2, args.warmup, D)
+        st2 = step2.stage_ms()
+        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), mode={args.mode}, eager launches",
+                          "value": round(B2 * n2 / w4, 1), "unit": "images/s", "ms_per_step": round(w4 / n2 * 1e3, 4),
+                          "stages_ms": [round(v, 4) for v in st2], "roofline": roofline_of(step2)}
         del step2
 
     if rank == 0:

@@ -18,9 +18,9 @@
  *     allocates: outputs and workspaces are owned by the caller;
  *   - return value: 0 on success, a negative ATTWARP_E_* code on failure (nothing
  *     is enqueued then); attwarp_last_error() gives a thread-local message;
- *   - the library keeps no global mutable state: transform selection etc. are
- *     arguments (the reference keeps them in module globals,
- *     AGW/new_method.py:159-163,378-403).
+ *   - the library keeps no global mutable state on the product path: transform selection etc. are
+ *     arguments (the reference keeps them in module globals, AGW/new_method.py:159-163,378-403) and no
+ *     environment variable is read; the only process-wide setting is the test hook attwarp_debug_set().
  */
 #ifndef ATTWARP_H
 #define ATTWARP_H
@@ -44,8 +44,11 @@ extern "C" {
 enum { ATTWARP_F32 = 0, ATTWARP_F16 = 1, ATTWARP_BF16 = 2, ATTWARP_U8 = 3, ATTWARP_F64 = 4 };
 /* image layouts: HWC = [B,H,W,C] interleaved (OpenCV / numpy), CHW = [B,C,H,W] planar (torch) */
 enum { ATTWARP_HWC = 0, ATTWARP_CHW = 1 };
-/* resample arithmetic: EXACT = bilinear on unquantised coordinates; CV2 = OpenCV's
- * 1/32-pixel coordinate quantisation + table weights (unpinned) */
+/* resample arithmetic: CV2 = what cv2.remap(INTER_LINEAR) computes per OpenCV's published algorithm: coordinates
+ * rounded to 1/32 pixel, 4 table weights for float32, 15-bit fixed point for uint8 (the reference's arithmetic,
+ * the default of the numpy / uint8 drop-ins; unpinned); EXACT = bilinear on the unquantised
+ * coordinates (= F.grid_sample(bilinear, border, align_corners=True), north_star's named op).
+ * Both modes run on the same staged kernels. */
 enum { ATTWARP_EXACT = 0, ATTWARP_CV2 = 1 };
 /* attention transforms, AGW/new_method.py:134-179 */
 enum { ATTWARP_T_IDENTITY = 0, ATTWARP_T_SQUARE = 1, ATTWARP_T_SQRT = 2, ATTWARP_T_EXP = 3, ATTWARP_T_LOG = 4 };
@@ -61,10 +64,18 @@ enum {
 ATTWARP_API int attwarp_version(void);
 ATTWARP_API const char* attwarp_last_error(void);
 
+/* ---- test / measurement hook, NOT part of the drop-in surface.  Kernel variants are chosen automatically from
+ * the shapes; the parity tests and the A/B tools force a particular one to check the variants against each other
+ * (e.g. key "remap_variant" = 1: generic gather kernel only; "remap_rows" = R).  value < 0 restores "automatic",
+ * key "reset" restores every key.  Keys: see kTuneNames in csrc/error.hip.  The setting is process wide (relaxed
+ * atomics); the library never reads environment variables. */
+ATTWARP_API int attwarp_debug_set(const char* key, int value);
+
 /* ---- A1: BatchMaskHookLogger._process_attention, AGW/attention_extraction/llava.py:385-396
  * attn [B,heads,q,kv] with element strides; for sample b uses row q-1, columns
  * starts[b] .. starts[b]+ntok-1; per-head renormalisation (x / (sum + 1e-12)), mean over heads.
- * out [B,ntok] in the same dtype (F32/F16/BF16).  starts: device int32[B]. */
+ * out [B,ntok] in the same dtype (F32/F16/BF16).  starts: device int32[B]; ntok <= kv_len is required and a start
+ * outside [0, kv_len-ntok] is clamped into it on the device (no out-of-row reads). */
 ATTWARP_API int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int heads, int q_len, int kv_len,
                              int64_t stride_b, int64_t stride_h, int64_t stride_q, int64_t stride_kv,
                              const int32_t* starts, int ntok, void* out, void* stream);
@@ -88,7 +99,7 @@ ATTWARP_API int attwarp_attn_reduce_stack(const void* rows, int dtype, int T, in
  *   k  : post-RoPE key cache, [B,kv_heads,kv_len,head_dim], element strides k_stride_b/_h/_t
  *        (head_dim contiguous; heads % kv_heads == 0: grouped-query attention shares a key head)
  *   kv_begin : device int32[B] or NULL - first attended key position (left padding); earlier keys get p = 0
- *   starts   : device int32[B], image-token slice starts; starts[b]+ntok <= kv_len
+ *   starts   : device int32[B], image-token slice starts, clamped into [0, kv_len-ntok] on the device
  *   out      : [B,ntok] in `dtype` = mean over heads of p[st:st+ntok] / (sum + 1e-12), as A1
  *   ws       : attwarp_attn_probe_workspace_bytes(...) bytes, 16-byte aligned
  * Rounding mirrors the eager path's dtype transitions (matmul -> dtype, *scaling -> dtype, softmax in

@@ -64,7 +64,7 @@ def axis_map_from_cdf(F, n_out):
     return m
 
 
-def remap_bilinear(src, mx, my, layout="hwc"):
+def remap_bilinear(src, mx, my, layout="hwc", mode="cv2"):
     src = np.ascontiguousarray(src, np.float32)
     mx = np.ascontiguousarray(mx, np.float32); my = np.ascontiguousarray(my, np.float32)
     if layout == "hwc":
@@ -72,11 +72,11 @@ def remap_bilinear(src, mx, my, layout="hwc"):
     else:
         C, H, W = src.shape; out = np.empty((C, my.shape[0], mx.shape[0]), np.float32); lid = 1
     load().oracle_remap_bilinear_f32(_p(src), _p(out), c_int(lid), c_int(C), c_int(H), c_int(W), c_int(my.shape[0]),
-                                     c_int(mx.shape[0]), _p(mx), _p(my))
+                                     c_int(mx.shape[0]), _p(mx), _p(my), c_int(int(mode == "cv2")))
     return out
 
 
-def warp_from_attention_stack(img, rows, start, inv_x, inv_y, layout="hwc"):
+def warp_from_attention_stack(img, rows, start, inv_x, inv_y, layout="hwc", mode="cv2"):
     """One image through the whole path.  rows [T,heads,kv]."""
     img = np.ascontiguousarray(img, np.float32); rows = np.ascontiguousarray(rows, np.float32)
     if layout == "hwc":
@@ -88,5 +88,5 @@ def warp_from_attention_stack(img, rows, start, inv_x, inv_y, layout="hwc"):
     load().oracle_warp_from_attention_stack_f32(_p(img), _p(out), c_int(lid), c_int(C), c_int(H), c_int(W), _p(rows),
                                                 c_int(T), c_int(heads), c_int(kv), c_int(int(start)),
                                                 _p(np.ascontiguousarray(inv_x, np.float64)),
-                                                _p(np.ascontiguousarray(inv_y, np.float64)))
+                                                _p(np.ascontiguousarray(inv_y, np.float64)), c_int(int(mode == "cv2")))
     return out

@@ -718,7 +718,7 @@ def _lerp(a: np.ndarray, b: np.ndarray, t: np.ndarray) -> np.ndarray:
     return (a + (t * d).astype(F32)).astype(F32)
 
 
-def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: str = "exact") -> np.ndarray:
+def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: str = "cv2") -> np.ndarray:
     """Stand-in for ``cv2.remap(src, meshgrid(map_x, map_y), INTER_LINEAR,
     BORDER_REPLICATE)`` (AGW/new_method.py:268-271, MN/checkpoint_utils.py:195-198).
 
@@ -803,7 +803,7 @@ def _remap_cv2_compat(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> 
 # ---------------------------------------------------------------------------
 
 def warp_from_cdf(img: np.ndarray, Fx: np.ndarray, Fy: np.ndarray,
-                  out_size: Optional[Tuple[int, int]] = None, mode: str = "exact") -> np.ndarray:
+                  out_size: Optional[Tuple[int, int]] = None, mode: str = "cv2") -> np.ndarray:
     """``warp_from_cdf_torch`` (MN/checkpoint_utils.py:133-204) on numpy
     arrays: img [B,C,H,W] (uint8 or float32) -> [B,C,H_out,W_out]."""
     img = np.asarray(img)
@@ -820,7 +820,7 @@ def warp_from_cdf(img: np.ndarray, Fx: np.ndarray, Fy: np.ndarray,
 
 def warp_image_by_attention(image: np.ndarray, att_map: np.ndarray, new_width: int, new_height: int,
                             transform: str = "identity", exp_scale: float = 1.0, exp_divisor: float = 1.0,
-                            apply_inverse: bool = False, mode: str = "exact") -> np.ndarray:
+                            apply_inverse: bool = False, mode: str = "cv2") -> np.ndarray:
     """``warp_image_by_attention`` (AGW/new_method.py:198-283) with the
     module-global transform state passed explicitly."""
     mx, my = maps_from_attention(att_map, new_width, new_height, transform, exp_scale, exp_divisor, apply_inverse)

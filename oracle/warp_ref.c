@@ -162,45 +162,64 @@ API void oracle_axis_map_from_cdf(const float* F, int L, int n_out, float* map) 
 static inline float lerp_rn(float a, float b, float t) { float d = b - a; float m = t * d; return a + m; }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-API void oracle_remap_bilinear_f32(const float* src, float* dst, int layout, int C, int H, int W, int Ho, int Wo,
-                                   const float* mx, const float* my) {
-  int* x0 = (int*)malloc(sizeof(int) * Wo * 2);
-  int* x1 = x0 + Wo;
-  float* fx = (float*)malloc(sizeof(float) * Wo);
-  for (int x = 0; x < Wo; ++x) {
-    const float fl = floorf(mx[x]);
-    fx[x] = mx[x] - fl;
-    float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)W ? (float)W : cl;
-    const int i = (int)cl;
-    x0[x] = clampi(i, 0, W - 1); x1[x] = clampi(i + 1, 0, W - 1);
-  }
-  for (int y = 0; y < Ho; ++y) {
-    const float fl = floorf(my[y]);
-    const float fy = my[y] - fl;
-    float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)H ? (float)H : cl;
-    const int i = (int)cl;
-    const int y0 = clampi(i, 0, H - 1), y1 = clampi(i + 1, 0, H - 1);
-    if (layout == 0) {
-      const float* r0 = src + (size_t)y0 * W * C;
-      const float* r1 = src + (size_t)y1 * W * C;
-      float* o = dst + (size_t)y * Wo * C;
-      for (int x = 0; x < Wo; ++x)
-        for (int c = 0; c < C; ++c) {
-          const float v0 = lerp_rn(r0[x0[x] * C + c], r1[x0[x] * C + c], fy);
-          const float v1 = lerp_rn(r0[x1[x] * C + c], r1[x1[x] * C + c], fy);
-          o[x * C + c] = lerp_rn(v0, v1, fx[x]);
-        }
+/* mode 0 = exact (vertical lerp, then horizontal, unquantised coordinates);
+ * mode 1 = cv2 (OpenCV's published remap algorithm: coordinates rounded to 1/32 pixel with cvRound, float32
+ * sources use the 4 table weights (1-ty|ty)*(1-tx|tx), summed ((p00*w00 + p01*w01) + p10*w10) + p11*w11). */
+static void axis_taps(const float* m, int n, int size, int mode, int* i0, int* i1, float* f) {
+  for (int x = 0; x < n; ++x) {
+    int i;
+    if (mode == 1) {
+      float s = m[x] * 32.0f;
+      s = s < -2.0e9f ? -2.0e9f : (s > 2.0e9f ? 2.0e9f : s);
+      const long q = lrintf(s);                 /* cvRound: round half to even (default rounding mode) */
+      i = (int)(q >> 5);
+      f[x] = (float)(q & 31) * 0.03125f;
     } else {
-      for (int c = 0; c < C; ++c) {
-        const float* r0 = src + ((size_t)c * H + y0) * W;
-        const float* r1 = src + ((size_t)c * H + y1) * W;
-        float* o = dst + ((size_t)c * Ho + y) * Wo;
-        for (int x = 0; x < Wo; ++x) {
-          const float v0 = lerp_rn(r0[x0[x]], r1[x0[x]], fy);
-          const float v1 = lerp_rn(r0[x1[x]], r1[x1[x]], fy);
-          o[x] = lerp_rn(v0, v1, fx[x]);
+      const float fl = floorf(m[x]);
+      f[x] = m[x] - fl;
+      float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)size ? (float)size : cl;
+      i = (int)cl;
+    }
+    i0[x] = clampi(i, 0, size - 1); i1[x] = clampi(i + 1, 0, size - 1);
+  }
+}
+static inline float cv2_sum(float p00, float p01, float p10, float p11, float fx, float fy) {
+  const float ox = 1.0f - fx, oy = 1.0f - fy;
+  const float w00 = oy * ox, w01 = oy * fx, w10 = fy * ox, w11 = fy * fx;
+  const float a = p00 * w00, b = p01 * w01, c = p10 * w10, d = p11 * w11;
+  float s = a + b; s = s + c; s = s + d;
+  return s;
+}
+
+API void oracle_remap_bilinear_f32(const float* src, float* dst, int layout, int C, int H, int W, int Ho, int Wo,
+                                   const float* mx, const float* my, int mode) {
+  int* x0 = (int*)malloc(sizeof(int) * ((size_t)Wo * 2 + (size_t)Ho * 2));
+  int* x1 = x0 + Wo; int* y0s = x1 + Wo; int* y1s = y0s + Ho;
+  float* fx = (float*)malloc(sizeof(float) * ((size_t)Wo + Ho));
+  float* fys = fx + Wo;
+  axis_taps(mx, Wo, W, mode, x0, x1, fx);
+  axis_taps(my, Ho, H, mode, y0s, y1s, fys);
+  for (int y = 0; y < Ho; ++y) {
+    const float fy = fys[y];
+    const int y0 = y0s[y], y1 = y1s[y];
+    for (int c = 0; c < (layout == 0 ? 1 : C); ++c) {
+      const size_t cs = layout == 0 ? (size_t)C : 1;          /* element stride between neighbouring pixels */
+      const int nc = layout == 0 ? C : 1;                     /* interleaved channels handled per pixel */
+      const float* r0 = layout == 0 ? src + (size_t)y0 * W * C : src + ((size_t)c * H + y0) * W;
+      const float* r1 = layout == 0 ? src + (size_t)y1 * W * C : src + ((size_t)c * H + y1) * W;
+      float* o = layout == 0 ? dst + (size_t)y * Wo * C : dst + ((size_t)c * Ho + y) * Wo;
+      for (int x = 0; x < Wo; ++x)
+        for (int k = 0; k < nc; ++k) {
+          const float p00 = r0[x0[x] * cs + k], p01 = r0[x1[x] * cs + k];
+          const float p10 = r1[x0[x] * cs + k], p11 = r1[x1[x] * cs + k];
+          if (mode == 1) {
+            o[x * cs + k] = cv2_sum(p00, p01, p10, p11, fx[x], fy);
+          } else {
+            const float v0 = lerp_rn(p00, p10, fy);
+            const float v1 = lerp_rn(p01, p11, fy);
+            o[x * cs + k] = lerp_rn(v0, v1, fx[x]);
+          }
         }
-      }
     }
   }
   free(x0);
@@ -210,7 +229,7 @@ API void oracle_remap_bilinear_f32(const float* src, float* dst, int layout, int
 /* ---- whole hot path for one image (float32): attention stack -> warped image ------------------- */
 API void oracle_warp_from_attention_stack_f32(const float* img, float* out, int layout, int C, int H, int W,
                                               const float* rows /* [T,1,heads,kv] */, int T, int heads, int kv,
-                                              int start, const double* inv_x, const double* inv_y) {
+                                              int start, const double* inv_x, const double* inv_y, int mode) {
   float att[576], px[24], py[24];
   const int32_t st = start;
   oracle_attn_reduce_stack_f32(rows, T, 1, heads, kv, &st, 576, att);
@@ -223,6 +242,6 @@ API void oracle_warp_from_attention_stack_f32(const float* img, float* out, int 
   oracle_cdf_from_density(dy, H, dy);
   oracle_axis_map_from_cdf(dx, W, W, mx);
   oracle_axis_map_from_cdf(dy, H, H, my);
-  oracle_remap_bilinear_f32(img, out, layout, C, H, W, H, W, mx, my);
+  oracle_remap_bilinear_f32(img, out, layout, C, H, W, H, W, mx, my, mode);
   free(dx);
 }

@@ -57,3 +57,32 @@ def config1_inputs():
     att = np.random.default_rng(1).random((24, 24))
     att = (att / att.sum()).astype(np.float32)
     return img, att
+
+
+def marginalnet_full_state(shapes: dict) -> dict:
+    """Seeded weights of MarginalNet(1024, 4096, hidden=256) (BASELINE configs[4]), same recipe as
+    tests/golden/make_golden.py: keys in sorted order, N(0,1)/sqrt(fan_in) weights, small biases.  11 MB of weights
+    are regenerated from this recipe instead of being committed."""
+    import torch
+    g = torch.Generator().manual_seed(4096)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        w = torch.randn(shp, generator=g)
+        fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else 0
+        sd[k] = w * (2.0 / fan_in ** 0.5) if fan_in else w * 0.1       # gain 2: logits of order 1, peaked px / py
+    return sd
+
+
+def marginalnet_full_inputs(B: int = 4):
+    """Seeded inputs at config-5 shapes: CLIP-L/14@336 token map [B,1024,24,24], 32 text tokens of width 4096 with
+    ragged masks (sample 1: 5 valid tokens, sample 3: none -- the clamp_min(1) branch)."""
+    import torch
+    g = torch.Generator().manual_seed(2048)
+    fmap = torch.randn(B, 1024, 24, 24, generator=g)
+    ttok = torch.randn(B, 32, 4096, generator=g)
+    tmask = torch.ones(B, 32, 1)
+    tmask[1, 5:] = 0
+    if B > 3:
+        tmask[3] = 0
+    return fmap, ttok, tmask

@@ -258,7 +258,42 @@ def make_marginalnet_tail_golden(model):
     np.savez_compressed(os.path.join(OUT, "marginalnet_tail.npz"), **out)
 
 
+def make_marginalnet_full_golden(model):
+    """BASELINE configs[4] at its stated size: the reference MarginalNet(1024, 4096, hidden=256)
+    (MN/model.py:25-53, config.py:26) forward at B=4 on seeded weights / inputs (recipes in tests/conftest.py, so the
+    11 MB of weights are not committed).  Stored: (px, py), the logits' inputs vx / vy as a strided sub-grid, and
+    float64 checksums of every hooked tensor and of the state_dict."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    from conftest import marginalnet_full_state, marginalnet_full_inputs
+    net = model.MarginalNet(d_vis_in=1024, d_txt_in=4096, hidden=256).eval()
+    sd = marginalnet_full_state({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    fmap, ttok, tmask = marginalnet_full_inputs(4)
+    cap = {}
+    hs = [net.txt_pool.register_forward_pre_hook(lambda m, a: cap.__setitem__("tmean", a[0].detach().clone())),
+          net.film.register_forward_hook(lambda m, a, o: cap.__setitem__("gamma_beta", o.detach().clone())),
+          net.head_x.register_forward_pre_hook(lambda m, a: cap.__setitem__("vx", a[0].detach().clone())),
+          net.head_y.register_forward_pre_hook(lambda m, a: cap.__setitem__("vy", a[0].detach().clone()))]
+    with torch.no_grad():
+        px, py = net(fmap, 24, 24, ttok, tmask)
+    for h in hs:
+        h.remove()
+    out = {"px": px.numpy(), "py": py.numpy(), "vx_sub": cap["vx"][:, ::16, ::3].numpy(),
+           "vy_sub": cap["vy"][:, ::16, ::3].numpy(), "tmean_sub": cap["tmean"][:, ::64].numpy(),
+           "gamma_beta_sub": cap["gamma_beta"][:, ::32].numpy(),
+           "sum_vx": np.array(cap["vx"].double().sum().item()), "sum_vy": np.array(cap["vy"].double().sum().item()),
+           "sum_tmean": np.array(cap["tmean"].double().sum().item()),
+           "sd_checksum": np.array(sum(v.double().sum().item() for v in sd.values())),
+           "n_params": np.array(sum(v.numel() for v in sd.values()))}
+    np.savez_compressed(os.path.join(OUT, "marginalnet_full.npz"), **out)
+
+
 def main():
+    if "--only-mnfull" in sys.argv:
+        _install_stubs()
+        torch.set_num_threads(1)
+        make_marginalnet_full_golden(_load("ref_model", os.path.join(MN, "model.py")))
+        return
     if not any(a.startswith("--only-") for a in sys.argv):
         make_clip_goldens()
     from transformers.models.llama.modeling_llama import eager_attention_forward
@@ -278,6 +313,7 @@ def main():
     make_marginalnet_tail_golden(model)
     if "--only-mntail" in sys.argv:
         return
+    make_marginalnet_full_golden(model)
     if "--only-mntail" not in sys.argv:
         make_probe_golden(eager_attention_forward, llava)
     if "--only-probe" in sys.argv:

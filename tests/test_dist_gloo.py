@@ -54,3 +54,33 @@ def test_two_rank_gloo():
     assert s0 == (0, 6) and s1 == (6, 11)
     assert g0 == g1 == {"images": [6.0, 5.0], "ms": [1.5, 2.5]}
     assert m0 == m1 == 20.0
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` must itself bring up 2 ranks: the parent spawns the children
+    before touching any GPU, rank 0's JSON line reports n_gpus = 2, the weight broadcast and per-rank counters ran.
+    --dry-run skips the timed GPU step (there is no GPU here); on a GPU box the same launcher path runs the real step."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--dry-run", "--steps", "3", "--workload", "336x256"], env=env, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True
+    assert d["weights_broadcast"]["bytes"] > 0
+    assert d["per_rank_images"] == [256.0 * 3, 256.0 * 3]
+    assert d["config"]["batch_per_gpu"] == 256
+
+
+def test_bench_refuses_world_size_mismatch():
+    """A stale WORLD_SIZE must not silently produce a 1-GPU number labelled as N."""
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 import torch
 
+from attwarp_amd import _lib
 from oracle import warp_oracle as O
 from conftest import pool_input, clip_input, clip_digest, config1_inputs
 
@@ -246,6 +247,25 @@ def test_attn_strided_prefill_and_empty(dev):
         hl3._process_attention(a)
 
 
+def test_attn_out_of_range_starts_are_clamped(dev):
+    """A slice start outside [0, kv - ntok] must not read outside the attention row: it is clamped on the
+    device; ntok > kv is rejected on the host."""
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(12)
+    B, heads, kv = 4, 8, 600
+    rows = softmax_rows(rng, (2, B, heads, kv))
+    bad = np.array([-5, 0, 24, 10 ** 6], np.int32)
+    ok = np.clip(bad, 0, kv - 576).astype(np.int32)
+    a = N(ae.attn_reduce_stack(T(rows, dev), T(bad, dev)))
+    b = N(ae.attn_reduce_stack(T(rows, dev), T(ok, dev)))
+    assert np.array_equal(a, b)
+    assert np.array_equal(b, O.attn_reduce_stack(rows, ok))
+    s1 = N(ae.attn_reduce_step(T(rows[0][:, :, None, :], dev), T(bad, dev), 576))
+    assert np.array_equal(s1, N(ae.attn_reduce_step(T(rows[0][:, :, None, :], dev), T(ok, dev), 576)))
+    with pytest.raises(_lib.AttWarpError, match="ntok"):
+        ae.attn_reduce_stack(T(rows[..., :500], dev), T(ok, dev))
+
+
 def test_attn_stack_fused_and_single_logger(dev):
     from attwarp_amd import attention_extraction as ae
     rng = np.random.default_rng(22)
@@ -279,19 +299,15 @@ def test_revise_mask(dev, golden):
         ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
 
 
-@pytest.mark.parametrize("variant", [None, "g"])       # fused single launch (small sources) / two-kernel form
+@pytest.mark.parametrize("variant", [-1, 1])       # fused single launch (small sources) / two-kernel form
 @pytest.mark.parametrize("wh", [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24), (24, 24)])
 def test_mask_upsample_lanczos_bit_exact(dev, golden, wh, variant):
     from attwarp_amd import attention_extraction as ae
     g = golden("mask_postproc")
     w, h = wh
-    if variant:
-        os.environ["ATTWARP_LANCZOS_VARIANT"] = variant
-    try:
+    with _lib.debug_override(lanczos_variant=variant):
         got_f = N(ae.upsample_mask_lanczos(T(g["revised"][:2], dev), (w, h)))      # float mask: x255 truncation inside
         got_u = N(ae.upsample_mask_lanczos(T(g["u8"][:2], dev), (w, h)))
-    finally:
-        os.environ.pop("ATTWARP_LANCZOS_VARIANT", None)
     if wh == (24, 24):
         assert np.array_equal(got_f, g["u8"][:2]) and np.array_equal(got_u, g["u8"][:2])
     else:
@@ -396,6 +412,110 @@ def test_marginalnet_forward_gpu(dev, golden):
     np.testing.assert_allclose(N(px), g["px"], rtol=1e-4, atol=1e-6)      # convs run on MIOpen/rocBLAS
     np.testing.assert_allclose(N(py), g["py"], rtol=1e-4, atol=1e-6)
     assert np.allclose(N(px).sum(1), 1, atol=1e-5)
+
+
+def test_marginalnet_hidden256_config5_and_real_checkpoint(dev, golden, tmp_path):
+    """BASELINE configs[4] at its stated size: MarginalNet(1024, 4096, hidden=256) on seeded weights / inputs against
+    the reference's own forward (tests/golden/marginalnet_full.npz, generated by importing MN/model.py), loaded through
+    a REAL ``torch.save({"epoch", "model", "opt", "cfg"})`` file in the trainer's format (MN/trainer.py:660-683),
+    then through the device-resident chain ``warp_from_marginalnet`` (maps bit-exact vs the oracle given px, py)."""
+    from conftest import marginalnet_full_state, marginalnet_full_inputs
+    from attwarp_amd import model, pipeline
+    g = golden("marginalnet_full")
+    net = model.MarginalNet(1024, 4096, hidden=256).eval()
+    sd = marginalnet_full_state({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"]) == 2755074
+    assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["sd_checksum"])) < 1e-6
+    opt = torch.optim.AdamW(model.MarginalNet(1024, 4096, hidden=256).parameters(), lr=3e-4, weight_decay=1e-4)
+    path = str(tmp_path / "marginal_net_epoch_1.pt")
+    torch.save({"epoch": 1, "model": sd, "opt": opt.state_dict(),
+                "cfg": {"seed": 13, "epochs": 50, "batch_size": 128, "lr": 3e-4, "wd": 1e-4, "grad_clip": 1.0, "workers": 4,
+                        "image_size": 512, "num_per_ds": 12000, "hidden": 256, "w_cdf": 10.0, "axis_len": 256,
+                        "llava_model": "liuhaotian/llava-v1.5-7b"}}, path)
+    model.load_reference_checkpoint(net, path)
+    net = net.to(dev)
+    fmap, ttok, tmask = (t.to(dev) for t in marginalnet_full_inputs(4))
+    cap = {}
+    hs = [net.head_x.register_forward_pre_hook(lambda m, a: cap.__setitem__("vx", a[0].detach())),
+          net.head_y.register_forward_pre_hook(lambda m, a: cap.__setitem__("vy", a[0].detach())),
+          net.txt_pool.register_forward_pre_hook(lambda m, a: cap.__setitem__("tmean", a[0].detach()))]
+    img = torch.rand(4, 3, 336, 336, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    out, px, py = pipeline.warp_from_marginalnet(net, fmap, ttok, tmask, img)
+    for h in hs:
+        h.remove()
+    # masked token mean has no GEMM in front of it: tight; everything behind MIOpen / rocBLAS: GEMM-order tolerance
+    np.testing.assert_allclose(N(cap["tmean"][:, ::64]), g["tmean_sub"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(N(cap["vx"][:, ::16, ::3]), g["vx_sub"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(N(cap["vy"][:, ::16, ::3]), g["vy_sub"], rtol=2e-4, atol=2e-5)
+    assert abs(float(cap["vx"].double().sum()) - float(g["sum_vx"])) < 2e-3
+    np.testing.assert_allclose(N(px), g["px"], rtol=5e-4, atol=1e-7)
+    np.testing.assert_allclose(N(py), g["py"], rtol=5e-4, atol=1e-7)
+    assert np.allclose(N(px).sum(1), 1, atol=1e-5) and np.allclose(N(py).sum(1), 1, atol=1e-5)
+    # the rest of the chain is exact given (px, py)
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(px), 336), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(N(py), 336), 0))
+    assert np.array_equal(N(out), O.warp_from_cdf(N(img), Fx, Fy))
+    # and end to end against the reference's (px, py): the warp moves by less than north_star's tolerance per pixel
+    Fxr = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(g["px"], 336), 0))
+    Fyr = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(g["py"], 336), 0))
+    mxr, myr = O.maps_from_cdf(Fxr, Fyr)
+    mxg, myg = O.maps_from_cdf(Fx, Fy)
+    assert np.abs(mxr - mxg).max() < 0.05 and np.abs(myr - myg).max() < 0.05       # source coordinates, pixels
+
+
+def test_training_path_is_differentiable(dev, golden):
+    """the drop-ins sit on the autograd path of the reference's training loss (MN/trainer.py:210-260:
+    ``px_s, py_s = net(...)``, ``upsample_pdf_right_inverse(px_s, W)``, loss.backward()).  With grad needed the
+    same maths runs on differentiable ops (or an autograd.Function around the kernel): gradients reach every
+    parameter, values equal the inference (HIP) path, and the right-inverse gradient equals the explicit matrix."""
+    from attwarp_amd import model, checkpoint_utils as cu
+    g = golden("marginalnet")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd|")}
+    net = model.MarginalNet(32, 48, hidden=16)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    args = (T(g["fmap"], dev), 24, 24, T(g["ttok"], dev), T(g["tmask"], dev))
+    px, py = net(*args)                                        # grad mode on, parameters require grad
+    assert px.requires_grad and py.requires_grad
+    with torch.no_grad():
+        px0, py0 = net(*args)                                  # HIP tail + HIP safe_softmax
+    np.testing.assert_allclose(N(px), N(px0), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(N(py), N(py0), rtol=2e-5, atol=1e-7)
+    W = 336
+    px_img = cu.upsample_pdf_right_inverse(px, W).clamp_min(0)
+    Fx = cu.cdf_from_density(px_img)
+    target = torch.linspace(0, 1, W, device=dev)[None].expand_as(Fx)
+    loss = ((Fx - target) ** 2).mean() + (cu.upsample_pdf_right_inverse(py, W) ** 2).mean()
+    loss.backward()
+    missing = [n for n, p in net.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
+    assert any(float(p.grad.abs().max()) > 0 for p in net.parameters())
+    # right-inverse: forward == kernel, backward == explicit M^T with M = inv @ A
+    y = torch.rand(3, 24, device=dev, requires_grad=True)
+    out = cu.upsample_pdf_right_inverse(y, 500)
+    with torch.no_grad():
+        assert torch.equal(out, cu.upsample_pdf_right_inverse(y.detach(), 500))
+    w = torch.randn(3, 500, device=dev)
+    (out * w).sum().backward()
+    A = torch.zeros(24, 500, dtype=torch.float64)
+    for k in range(24):
+        s0, e0 = (k * 500) // 24, -((-(k + 1) * 500) // 24)
+        A[k, s0:e0] = 1.0 / (e0 - s0)
+    M = torch.from_numpy(O.right_inverse_core(24, 500)) @ A          # [24, 500]
+    np.testing.assert_allclose(N(y.grad), (w.double().cpu() @ M.T).numpy(), rtol=1e-5, atol=1e-7)
+    # the other CDF helpers: differentiable route equals the kernels' values
+    p = torch.rand(2, 64, device=dev, requires_grad=True)
+    np.testing.assert_allclose(N(cu.cdf_from_density(p)), N(cu.cdf_from_density(p.detach())), rtol=0, atol=2e-7)
+    Fd = cu.resample_cdf(cu.cdf_from_density(p), 100)
+    np.testing.assert_allclose(N(Fd), N(cu.resample_cdf(cu.cdf_from_density(p.detach()), 100)), rtol=0, atol=5e-7)
+    Fd.sum().backward()
+    assert p.grad is not None and torch.isfinite(p.grad).all()
+    Aq = torch.rand(2, 1, 12, 9, device=dev, requires_grad=True)
+    mx, my = cu.gt_marginals(Aq)
+    mx0, my0 = cu.gt_marginals(Aq.detach())
+    np.testing.assert_allclose(N(mx), N(mx0), rtol=1e-6, atol=1e-8)
+    lg = torch.randn(4, 24, device=dev, requires_grad=True)
+    np.testing.assert_allclose(N(model.safe_softmax(lg)), N(model.safe_softmax(lg.detach())), rtol=2e-6, atol=1e-8)
 
 
 # =============================== A8 / A9 / A10 / A11 ==========================
@@ -565,7 +685,10 @@ def make_maps(rng, B, H, W, Ho, Wo, kind="cdf"):
 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("kind", ["cdf", "wild"])
-def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_remap_all_modes_layouts_dtypes(dev, shape, kind, mode):
+    """Both arithmetic modes x both kernels (staged rows kernel, generic gather kernel) x both layouts x both dtypes:
+    bit-exact against the oracle (cv2: oracle._remap_cv2_compat)."""
     from attwarp_amd import checkpoint_utils as cu
     H, W, Ho, Wo, C = shape
     rng = np.random.default_rng(hash((shape, kind)) % 2**32)
@@ -575,21 +698,42 @@ def test_remap_exact_all_layouts_dtypes(dev, shape, kind):
         img = rng.random((B, H, W, C), dtype=np.float32)
         if dt == np.uint8:
             img = (img * 255).astype(np.uint8)
-        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
         for variant in ("rows", "gather"):
-            os.environ["ATTWARP_REMAP_VARIANT"] = variant[0]
-            try:
-                hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
-                chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev)))
-            finally:
-                os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+            with _lib.debug_override(remap_variant=int(variant == "gather")):
+                hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
+                chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode=mode))
             assert np.array_equal(hwc, ref), (dt.__name__, variant, "hwc")
             assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (dt.__name__, variant, "chw")
 
 
+@pytest.mark.parametrize("C", [1, 2, 3, 4])
+@pytest.mark.parametrize("kind", ["cdf", "wild", "identity"])
+def test_remap_cv2_staged_channels_and_edges(dev, C, kind):
+    """cv2 arithmetic on the staged kernels for every channel count, with coordinates on the 1/64-pixel rounding
+    ties of cvRound (half to even), exactly on pixel centres, and far outside the image."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(900 + C)
+    B, H, W, Ho, Wo = 2, 48, 64, 52, 72
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    mx[:, :8] = np.array([0.015625, 0.046875, 3.0, 62.984375, 63.0, 63.5, -7.25, 1e9], np.float32)   # ties, edges, far
+    my[:, :6] = np.array([0.015625, 47.0, 46.984375, 47.515625, -1e9, 5.5], np.float32)
+    for dt in (np.float32, np.uint8):
+        img = rng.random((B, H, W, C), dtype=np.float32)
+        if dt == np.uint8:
+            img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+            img[0, :4, :4] = 255; img[0, 4:8, :4] = 0                       # saturated corners
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], "cv2") for b in range(B)])
+        hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode="cv2", channels_last=True))
+        chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode="cv2"))
+        assert np.array_equal(hwc, ref), (dt.__name__, "hwc")
+        assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (dt.__name__, "chw")
+
+
 @pytest.mark.parametrize("kind", ["cdf", "wild"])
-@pytest.mark.parametrize("split", [None, "0", "1"])
-def test_remap_planar_plane_split(dev, kind, split):
+@pytest.mark.parametrize("split", [-1, 0, 1])
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_remap_planar_plane_split(dev, kind, split, mode):
     """Planar float32 images with wide rows are dispatched plane by plane (maps of image b serve planes b*C..):
     default heuristic, forced on and forced off must all equal the oracle bit-for-bit."""
     from attwarp_amd import checkpoint_utils as cu
@@ -597,14 +741,10 @@ def test_remap_planar_plane_split(dev, kind, split):
     B, C, H, W, Ho, Wo = 3, 3, 40, 1024, 37, 768
     img = rng.random((B, C, H, W), dtype=np.float32)
     mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
-    ref = np.stack([O.remap_bilinear(img[b].transpose(1, 2, 0), mx[b], my[b]) for b in range(B)]).transpose(0, 3, 1, 2)
-    if split is not None:
-        os.environ["ATTWARP_REMAP_CHW_SPLIT"] = split
-    try:
-        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev)))
-        two = N(cu.remap_separable(T(img[:, :2], dev), T(mx, dev), T(my, dev)))      # C = 2
-    finally:
-        os.environ.pop("ATTWARP_REMAP_CHW_SPLIT", None)
+    ref = np.stack([O.remap_bilinear(img[b].transpose(1, 2, 0), mx[b], my[b], mode) for b in range(B)]).transpose(0, 3, 1, 2)
+    with _lib.debug_override(remap_chw_split=split):
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode))
+        two = N(cu.remap_separable(T(img[:, :2], dev), T(mx, dev), T(my, dev), mode=mode))      # C = 2
     assert np.array_equal(got, ref)
     assert np.array_equal(two, ref[:, :2])
 
@@ -617,7 +757,8 @@ def test_remap_planar_plane_split(dev, kind, split):
     (2, 26, 1100, 26, 1100, 4, "hwc"),     # 4 channels, 4400 floats
 ])
 @pytest.mark.parametrize("kind", ["cdf", "wild", "identity"])
-def test_remap_wide_rows_column_tiles(dev, shape, kind):
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_remap_wide_rows_column_tiles(dev, shape, kind, mode):
     """Rows wider than the 4096-float LDS row run in column tiles ("cdf": every tile staged; "wild": spans that do not
     fit take the per-tile direct path); both must equal the oracle and the generic kernel bit-for-bit."""
     from attwarp_amd import checkpoint_utils as cu
@@ -625,30 +766,32 @@ def test_remap_wide_rows_column_tiles(dev, shape, kind):
     rng = np.random.default_rng(hash((shape, kind)) % 2**32)
     img = rng.random((B, H, W, C), dtype=np.float32)
     mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
-    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
     x = T(img if layout == "hwc" else img.transpose(0, 3, 1, 2), dev)
-    got = N(cu.remap_separable(x, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
-    os.environ["ATTWARP_REMAP_TILED"] = "0"          # generic gather kernel
-    try:
-        gen = N(cu.remap_separable(x, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
-    finally:
-        os.environ.pop("ATTWARP_REMAP_TILED", None)
+    got = N(cu.remap_separable(x, T(mx, dev), T(my, dev), mode=mode, channels_last=(layout == "hwc")))
+    with _lib.debug_override(remap_tiled=0):          # generic gather kernel
+        gen = N(cu.remap_separable(x, T(mx, dev), T(my, dev), mode=mode, channels_last=(layout == "hwc")))
+    if mode == "exact":
+        with _lib.debug_override(remap_tile_ko=12):   # the wider tile variant
+            t12 = N(cu.remap_separable(x, T(mx, dev), T(my, dev), mode=mode, channels_last=(layout == "hwc")))
+        assert np.array_equal(t12, got)
     if layout == "chw":
         got, gen = got.transpose(0, 2, 3, 1), gen.transpose(0, 2, 3, 1)
     assert np.array_equal(got, ref) and np.array_equal(gen, ref)
     # the uint8 kernel tiles rows wider than 4096 BYTES: same shapes, 4x the width in bytes is not needed --
     # these rows (4200 .. 5000 bytes) already exceed it
     img8 = (img * 255).astype(np.uint8)
-    ref8 = np.stack([O.remap_bilinear(img8[b], mx[b], my[b]) for b in range(B)])
+    ref8 = np.stack([O.remap_bilinear(img8[b], mx[b], my[b], mode) for b in range(B)])
     x8 = T(img8 if layout == "hwc" else img8.transpose(0, 3, 1, 2), dev)
-    got8 = N(cu.remap_separable(x8, T(mx, dev), T(my, dev), channels_last=(layout == "hwc")))
+    got8 = N(cu.remap_separable(x8, T(mx, dev), T(my, dev), mode=mode, channels_last=(layout == "hwc")))
     if layout == "chw":
         got8 = got8.transpose(0, 2, 3, 1)
     assert np.array_equal(got8, ref8)
 
 
-@pytest.mark.parametrize("R", ["1", "5", "64"])
-def test_remap_rows_block_boundaries(dev, R):
+@pytest.mark.parametrize("R", [1, 5, 64])
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_remap_rows_block_boundaries(dev, R, mode):
     """Row-block size must not change a single bit (halo / slide logic at block seams)."""
     from attwarp_amd import checkpoint_utils as cu
     rng = np.random.default_rng(41)
@@ -657,13 +800,14 @@ def test_remap_rows_block_boundaries(dev, R):
     px = softmax_rows(rng, (2, 24)) ** 3; px /= px.sum(1, keepdims=True)      # strongly peaked: slopes >> 2 and << 1
     Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px.astype(np.float32), W), 0))
     mx, my = O.maps_from_cdf(Fx, Fx[::-1].copy(), (H, W))
-    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(2)])
-    os.environ["ATTWARP_REMAP_ROWS"] = R
-    try:
-        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
-        assert np.array_equal(got, ref)
-    finally:
-        os.environ.pop("ATTWARP_REMAP_ROWS", None)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(2)])
+    img8 = (img * 255).astype(np.uint8)
+    ref8 = np.stack([O.remap_bilinear(img8[b], mx[b], my[b], mode) for b in range(2)])
+    with _lib.debug_override(remap_rows=R):
+        got = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
+        got8 = N(cu.remap_separable(T(img8, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got8, ref8)
 
 
 @pytest.mark.parametrize("dt", [np.float32, np.uint8])
@@ -914,39 +1058,92 @@ def test_two_host_threads_two_streams(dev):
 
 # =============================== full-size properties =========================
 @pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
-def test_full_size_properties(dev, cfg):
-    """BASELINE configs 2 and 3 at full size, checked on the GPU through properties:
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_full_size_properties(dev, cfg, mode):
+    """BASELINE configs 2 and 3 at full size, both arithmetic modes, checked on the GPU through properties:
     (1) identity maps reproduce the input bit-for-bit; (2) the streaming kernel and the independent
-    gather kernel agree bit-for-bit on attention-driven maps; (3) a constant image stays constant
-    (partition of unity); (4) every output lies within the input's range."""
+    gather kernel agree bit-for-bit on attention-driven maps (HWC and CHW, float32 and uint8); (3) a constant image
+    stays constant (partition of unity; in cv2 mode the four table weights sum to 1 exactly); (4) every output lies
+    within the input's range; (5) first and last image equal the CPU oracle bit-for-bit."""
     from attwarp_amd import checkpoint_utils as cu, pipeline
     B, S = cfg
     gen = torch.Generator(device=dev).manual_seed(0)
     img = torch.rand((B, S, S, 3), device=dev, generator=gen)
     ar = torch.arange(S, device=dev, dtype=torch.float32).repeat(B, 1)
-    out = cu.remap_separable(img, ar, ar, channels_last=True)
+    out = cu.remap_separable(img, ar, ar, mode=mode, channels_last=True)
     assert torch.equal(out, img)
     px = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 2, 1)
     py = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 2, 1)
     mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
     assert bool((mx[:, 1:] >= mx[:, :-1]).all()) and float(mx.min()) >= 0 and float(mx.max()) <= S
     del out
-    a = cu.remap_separable(img, mx, my, channels_last=True)
-    os.environ["ATTWARP_REMAP_VARIANT"] = "g"      # the independent gather kernel
-    try:
-        b = cu.remap_separable(img, mx, my, channels_last=True)
-    finally:
-        os.environ.pop("ATTWARP_REMAP_VARIANT", None)
+    a = cu.remap_separable(img, mx, my, mode=mode, channels_last=True)
+    with _lib.debug_override(remap_variant=1):     # the independent gather kernel
+        b = cu.remap_separable(img, mx, my, mode=mode, channels_last=True)
     assert torch.equal(a, b)
     assert float(a.min()) >= float(img.min()) and float(a.max()) <= float(img.max())
     del b
     const = torch.full_like(img, 0.3125)
-    c = cu.remap_separable(const, mx, my, channels_last=True)
+    c = cu.remap_separable(const, mx, my, mode=mode, channels_last=True)
     assert torch.equal(c, const)
+    del c, const
     # spot-check a few images against the CPU oracle
     for bi in (0, B - 1):
-        ref = O.remap_bilinear(N(img[bi]), N(mx[bi]), N(my[bi]))
+        ref = O.remap_bilinear(N(img[bi]), N(mx[bi]), N(my[bi]), mode)
         assert np.array_equal(N(a[bi]), ref)
+    # planar layout: same pixels
+    chw = cu.remap_separable(img.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
+    assert torch.equal(chw.permute(0, 2, 3, 1), a)
+    del chw, a
+    # uint8 (the main_batched dtype): rows kernel == gather kernel == oracle
+    img8 = (img * 255).to(torch.uint8)
+    a8 = cu.remap_separable(img8, mx, my, mode=mode, channels_last=True)
+    with _lib.debug_override(remap_variant=1):
+        b8 = cu.remap_separable(img8, mx, my, mode=mode, channels_last=True)
+    assert torch.equal(a8, b8)
+    for bi in (0, B - 1):
+        assert np.array_equal(N(a8[bi]), O.remap_bilinear(N(img8[bi]), N(mx[bi]), N(my[bi]), mode))
+    c8 = cu.remap_separable(img8.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
+    assert torch.equal(c8.permute(0, 2, 3, 1), a8)
+
+
+@pytest.mark.parametrize("cfg", [(64, 336), (8, 1024)])
+@pytest.mark.parametrize("layout", ["hwc", "chw"])
+@pytest.mark.parametrize("kind", ["peaked", "wild"])
+def test_remap_exact_vs_torch_grid_sample(dev, cfg, layout, kind):
+    """Independent check of the EXACT mode on the GPU box: torch's own F.grid_sample(bilinear, border,
+    align_corners=True) -- north_star's named op -- on the same separable maps, at BASELINE image sizes.
+    float32 grid_sample: tolerance 1e-4 (north_star) at 336; its own [-1,1] coordinate round trip costs up to
+    ~S * 2^-23 pixels (SURVEY 8c measured 2e-5 @336, 2.9e-5 @1024 on average maps; 1.1e-4 on peaked ones), so at
+    1024 the float32 comparison allows 2e-4 and the float64 grid_sample below is the tight check (2e-6)."""
+    import torch.nn.functional as F
+    from attwarp_amd import checkpoint_utils as cu, pipeline
+    B, S = cfg
+    gen = torch.Generator(device=dev).manual_seed(5)
+    img = torch.rand((B, 3, S, S), device=dev, generator=gen)
+    if kind == "peaked":
+        px = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 3, 1)
+        py = torch.softmax(torch.randn(B, 24, device=dev, generator=gen) * 3, 1)
+        mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
+    else:
+        mx = torch.rand((B, S), device=dev, generator=gen) * (S + 6) - 3
+        my = torch.rand((B, S), device=dev, generator=gen) * (S + 6) - 3
+    if layout == "hwc":
+        got = cu.remap_separable(img.permute(0, 2, 3, 1).contiguous(), mx, my, mode="exact",
+                                 channels_last=True).permute(0, 3, 1, 2)
+    else:
+        got = cu.remap_separable(img, mx, my, mode="exact")
+    gx = (2.0 * mx.double() / (S - 1) - 1.0)[:, None, :].expand(B, S, S)
+    gy = (2.0 * my.double() / (S - 1) - 1.0)[:, :, None].expand(B, S, S)
+    grid = torch.stack([gx, gy], -1).float()
+    ref = F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+    err = float((got - ref).abs().max())
+    assert err <= TOL_PIXEL * (1 if S <= 512 else 2), err
+    # and in float64 (no coordinate round-trip error left): the kernel's three-rounding lerps stay within 2e-7
+    ref64 = F.grid_sample(img.double(), torch.stack([gx, gy], -1), mode="bilinear", padding_mode="border",
+                          align_corners=True)
+    # grid_sample recomputes the pixel coordinate from the normalised one: allow its float64 round trip
+    assert float((got.double() - ref64).abs().max()) <= 2e-6
 
 
 def test_integration_md_stub_runs(dev):
@@ -1014,6 +1211,179 @@ def test_hook_plumbing_with_dummy_decoder(dev):
     hl.remove_hook_and_unpatch()
     model.model.layers[1].self_attn(h)
     assert model.model.layers[1].self_attn.calls[-1] is False and len(hl.step_attentions) == 2
+
+
+def test_single_sample_hook_logger_with_dummy_decoder(dev):
+    """hook_logger / MaskHookLogger.register_hook / remove_hook / _attention_hook (reference llava.py:74-92,141-187,
+    the surface main.py:38,307 and new_method.py:45 import): config.output_attentions is switched on for the whole
+    model, the forward hook of layers[i].self_attn consumes output[1], malformed outputs are ignored, the default
+    range [1, 577) is used until set_image_token_range, finalize() equals the oracle."""
+    import types
+    from attwarp_amd import attention_extraction as ae
+
+    class Attn(torch.nn.Module):
+        def __init__(self, cfg):
+            super().__init__()
+            self.cfg, self.mode = cfg, "weights"
+
+        def forward(self, hidden):
+            B, q = hidden.shape[0], hidden.shape[1]
+            g = torch.Generator(device=hidden.device).manual_seed(q)
+            w = torch.softmax(torch.randn(B, 4, q, 640, device=hidden.device, generator=g), dim=-1)
+            if self.mode == "weights":
+                return hidden, (w if self.cfg.output_attentions else None), None
+            if self.mode == "3d":
+                return hidden, w[0], None
+            return hidden                                          # not a tuple
+
+    cfg = types.SimpleNamespace(output_attentions=False)
+    layers = torch.nn.ModuleList([torch.nn.Module() for _ in range(3)])
+    for l in layers:
+        l.self_attn = Attn(cfg)
+    model = types.SimpleNamespace(model=types.SimpleNamespace(layers=layers), config=cfg)
+    hl = ae.hook_logger(model, dev, layer_index=2)
+    assert isinstance(hl, ae.MaskHookLogger) and model.hooklogger is hl
+    assert cfg.output_attentions is True and model._original_output_attentions is False
+    assert hl._find_image_token_range(torch.zeros(1, 700, dtype=torch.long)) == (1, 577)
+    h = torch.zeros(1, 6, 8, device=dev)
+    seen = []
+    for q in (6, 1, 1):                                            # prefill + two decode steps
+        for i, l in enumerate(layers):
+            l.self_attn(h[:, :q])
+        g = torch.Generator(device=dev).manual_seed(q)
+        seen.append(torch.softmax(torch.randn(1, 4, q, 640, device=dev, generator=g), dim=-1))
+    assert len(hl.attns) == 3 and hl.attns[0].shape == (1, 576)
+    got = N(hl.finalize())
+    ref = np.mean([O.attn_reduce_step(N(w), [1], [577])[0] for w in seen], axis=0)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=1e-9)
+    hl.reinit()
+    hl.set_image_token_range(40, 616)
+    layers[2].self_attn(h)
+    np.testing.assert_allclose(N(hl.finalize()), O.attn_reduce_step(N(seen[0]), [40], [616])[0], rtol=2e-6, atol=1e-9)
+    for mode in ("3d", "plain"):                                   # silently ignored, like the reference
+        layers[2].self_attn.mode = mode
+        layers[2].self_attn(h)
+    assert len(hl.attns) == 1
+    layers[2].self_attn.mode = "weights"
+    hl.register_hook()                                             # re-registering replaces the handle (no double count)
+    layers[2].self_attn(h)
+    assert len(hl.attns) == 2
+    hl.remove_hook()
+    layers[2].self_attn(h)
+    assert len(hl.attns) == 2 and hl.hook_handle is None
+    assert float(ae.MaskHookLogger(model, dev).finalize().sum()) == pytest.approx(1.0)     # empty -> uniform [576]
+
+
+def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev):
+    """INTEGRATION.md section 2, the recipe for the reference's pinned transformers 4.37.2 (no AttentionInterface):
+    ``register_probe_legacy`` = forward hook that re-applies q_proj + rotary to the last token and reads the layer's
+    key cache.  Checked on a stand-in module with 4.37.2's LlamaAttention interface (q_proj / k_proj /
+    rotary_emb(x, seq_len) / layer_idx / past_key_value.update) against that module's own eager attention weights
+    fed through the reference-style hook (``register_hook_and_patch`` + ``_process_attention``): fp16, left padding,
+    prefill + two decode steps."""
+    import math
+    import types
+    from attwarp_amd import attention_extraction as ae
+    heads, D, hid = 8, 64, 512                       # head_dim a power of 4: /sqrt(D) == *D**-0.5 exactly
+
+    class Rotary(torch.nn.Module):                   # 4.37.2: forward(x, seq_len) -> (cos[:seq_len], sin[:seq_len])
+        def forward(self, x, seq_len=None):
+            inv = 1.0 / (10000 ** (torch.arange(0, D, 2, device=x.device).float() / D))
+            fr = torch.outer(torch.arange(seq_len, device=x.device).float(), inv)
+            emb = torch.cat((fr, fr), dim=-1)
+            return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+
+    class Cache:                                     # DynamicCache of 4.36+: key_cache[layer] grows along the kv axis
+        def __init__(self, n):
+            self.key_cache = [None] * n
+
+        def update(self, k, layer):
+            self.key_cache[layer] = k if self.key_cache[layer] is None else torch.cat([self.key_cache[layer], k], dim=2)
+            return self.key_cache[layer]
+
+    class Attn(torch.nn.Module):
+        def __init__(self, layer_idx):
+            super().__init__()
+            self.layer_idx, self.num_heads = layer_idx, heads
+            self.q_proj = torch.nn.Linear(hid, heads * D, bias=False)
+            self.k_proj = torch.nn.Linear(hid, heads * D, bias=False)
+            self.rotary_emb = Rotary()
+
+        def forward(self, hidden_states=None, attention_mask=None, position_ids=None, past_key_value=None,
+                    output_attentions=False, use_cache=True):
+            B, q_len, _ = hidden_states.shape
+            q = self.q_proj(hidden_states).view(B, q_len, heads, D).transpose(1, 2)
+            k = self.k_proj(hidden_states).view(B, q_len, heads, D).transpose(1, 2)
+            kv = q_len + (0 if past_key_value.key_cache[self.layer_idx] is None else past_key_value.key_cache[self.layer_idx].shape[2])
+            cos, sin = self.rotary_emb(k, seq_len=kv)
+            cos, sin = cos[position_ids].unsqueeze(1), sin[position_ids].unsqueeze(1)
+            rh = lambda x: torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1)
+            q, k = (q * cos) + (rh(q) * sin), (k * cos) + (rh(k) * sin)
+            k = past_key_value.update(k, self.layer_idx)
+            w = None
+            if output_attentions:                    # the eager path of 4.37.2
+                w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(D) + attention_mask
+                w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+            return hidden_states, w, past_key_value
+
+    torch.manual_seed(9)
+    layers = torch.nn.ModuleList([torch.nn.Module() for _ in range(2)])
+    for i, l in enumerate(layers):
+        l.self_attn = Attn(i).to(dev).half()
+    model = types.SimpleNamespace(model=types.SimpleNamespace(layers=layers), config=types.SimpleNamespace(output_attentions=False))
+    B, prompt, pads = 2, 620, [0, 9]
+    starts = [5 + p for p in pads]
+    ends = [s0 + 576 for s0 in starts]
+    hidden = torch.randn(B, prompt + 2, hid, device=dev).half() * 0.5
+
+    def run(register):
+        hl = ae.BatchMaskHookLogger(model, dev, layer_index=1)
+        register(hl)
+        hl.set_batch_image_token_ranges(starts, ends)
+        cache = Cache(2)
+        done = 0
+        for q_len in (prompt, 1, 1):
+            kv = done + q_len
+            pos = torch.stack([torch.arange(done, kv, device=dev) - p for p in pads]).clamp_min(0)
+            mask = torch.zeros(B, 1, q_len, kv, device=dev, dtype=torch.float16)
+            causal = torch.arange(kv, device=dev)[None, :] > (done + torch.arange(q_len, device=dev))[:, None]
+            mask.masked_fill_(causal[None, None], torch.finfo(torch.float16).min)
+            for b, p in enumerate(pads):
+                mask[b, :, :, :p] = torch.finfo(torch.float16).min
+            layers[1].self_attn(hidden_states=hidden[:, done:kv], attention_mask=mask, position_ids=pos,
+                                past_key_value=cache, use_cache=True)
+            done = kv
+        maps = torch.stack(hl.finalize_batch())
+        hl.remove_hook_and_unpatch()
+        return maps, len(hl.step_attentions)
+
+    ref, n_ref = run(lambda hl: hl.register_hook_and_patch())            # eager weights -> reference-style hook
+    got, n_got = run(lambda hl: hl.register_probe_legacy())              # q_proj + rotary on one token + key cache
+    assert n_ref == n_got == 3
+    # the probe forms exact fp16 dot products where the eager matmul accumulates in its own order: same tolerance as
+    # test_probe_equals_hooked_eager_on_hf_llama (layer 0)
+    np.testing.assert_allclose(N(got.float()), N(ref.float()), rtol=4e-3, atol=2e-6)
+    assert abs(float(got[0].float().sum()) - 1.0) < 2e-3
+
+
+def test_bench_gpus2_self_launch_on_one_gpu(dev):
+    """`python bench.py --gpus 2` brings up two ranks by itself (parent spawns before touching the GPU); on this one-GPU
+    box both ranks share device 0 over gloo.  The JSON line must say n_gpus = 2 and carry both ranks' rates."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                        "--workload", "336", "--steps", "5", "--warmup", "2"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak"
+    assert len(d["per_rank_images_per_s"]) == 2 and d["weights_broadcast"]["bytes"] == 2755074 * 4
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
 
 
 def test_wide_rows_sorted_random_maps(dev):
@@ -1102,11 +1472,8 @@ def test_clip_preprocess_staged_equals_generic(dev, shape):
     x = T(img, dev)
     for dt in (torch.float32, torch.float16):
         a = pipeline.clip_preprocess(x, size, dt, mean, std)
-        os.environ["ATTWARP_CLIP_VARIANT"] = "g"
-        try:
+        with _lib.debug_override(clip_variant=1):
             b = pipeline.clip_preprocess(x, size, dt, mean, std)
-        finally:
-            os.environ.pop("ATTWARP_CLIP_VARIANT", None)
         assert a.shape == (B, C, size, size) and torch.equal(a, b), (shape, dt)
     if C == 3 and H * W <= 600 * 600:
         got = N(pipeline.clip_preprocess(x, size, torch.float32))
@@ -1205,7 +1572,7 @@ def test_remap_fuzz_shapes(dev):
     (float rows kernel, uint8 rows kernel, gather fallback for unaligned shapes): bit-exact vs the oracle."""
     from attwarp_amd import checkpoint_utils as cu
     rng = np.random.default_rng(2026)
-    for case in range(40):
+    for case in range(60):
         H, W = int(rng.integers(24, 160)), int(rng.integers(24, 200))
         Ho, Wo = int(rng.integers(1, 180)), int(rng.integers(1, 220))
         C = int(rng.integers(1, 5))
@@ -1218,9 +1585,10 @@ def test_remap_fuzz_shapes(dev):
         img = rng.random((B, H, W, C), dtype=np.float32)
         if dt == np.uint8:
             img = (img * 255).astype(np.uint8)
-        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b]) for b in range(B)])
-        hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), channels_last=True))
-        chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev)))
-        tag = (case, H, W, Ho, Wo, C, kind, dt.__name__)
+        mode = ("exact", "cv2")[(case // 2) % 2]
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
+        hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
+        chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode=mode))
+        tag = (case, H, W, Ho, Wo, C, kind, dt.__name__, mode)
         assert np.array_equal(hwc, ref), tag
         assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), tag

@@ -253,3 +253,37 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_reference_checkpoint_file_roundtrip(tmp_path):
+    """load_reference_checkpoint on a real file in the trainer's format (MN/trainer.py:660-683:
+    ``{"epoch", "model", "opt", "cfg"}``), on a bare state_dict file and on an in-memory dict; a checkpoint of the wrong
+    architecture fails loudly.  (CPU: only the loader, no compute.)"""
+    import torch
+    from attwarp_amd import model
+    torch.manual_seed(5)
+    src = model.MarginalNet(12, 20, hidden=8)
+    opt = torch.optim.AdamW(src.parameters(), lr=3e-4, weight_decay=1e-4)
+    full = tmp_path / "marginal_net_epoch_3.pt"
+    torch.save({"epoch": 3, "model": src.state_dict(), "opt": opt.state_dict(), "cfg": {"hidden": 8, "seed": 13}}, full)
+    bare = tmp_path / "bare.pt"
+    torch.save(src.state_dict(), bare)
+    for source in (str(full), str(bare), {"model": src.state_dict()}, src.state_dict()):
+        dst = model.MarginalNet(12, 20, hidden=8)
+        model.load_reference_checkpoint(dst, source)
+        for (ka, va), (kb, vb) in zip(src.state_dict().items(), dst.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb)
+    with pytest.raises(RuntimeError):
+        model.load_reference_checkpoint(model.MarginalNet(12, 20, hidden=16), str(full))
+
+
+def test_golden_marginalnet_full_recipe():
+    """The seeded weight recipe the GPU test regenerates must be the one the golden was made with."""
+    import numpy as np
+    from conftest import marginalnet_full_state
+    from attwarp_amd import model
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "marginalnet_full.npz"))
+    net = model.MarginalNet(1024, 4096, hidden=256)
+    sd = marginalnet_full_state({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["sd_checksum"])) < 1e-6
+    assert sum(v.numel() for v in sd.values()) == int(g["n_params"])

@@ -55,30 +55,33 @@ def test_c_marginals(C):
 
 
 @pytest.mark.parametrize("layout", ["hwc", "chw"])
-def test_c_remap(C, layout):
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_c_remap(C, layout, mode):
     rng = np.random.default_rng(4)
     img = rng.random((45, 61, 3), dtype=np.float32)
     mx = np.sort(rng.random(70).astype(np.float32) * 63 - 1)
     my = np.sort(rng.random(50).astype(np.float32) * 47 - 1)
-    ref = O.remap_bilinear(img, mx, my)
+    mx[:4] = [-3.0, 0.015625, 0.046875, 2.5]          # outside, cvRound ties
+    ref = O.remap_bilinear(img, mx, my, mode)
     src = img if layout == "hwc" else np.ascontiguousarray(img.transpose(2, 0, 1))
-    out = C.remap_bilinear(src, mx, my, layout)
+    out = C.remap_bilinear(src, mx, my, layout, mode)
     if layout == "chw":
         out = out.transpose(1, 2, 0)
     assert np.array_equal(out, ref)
 
 
-def test_c_whole_path(C):
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_c_whole_path(C, mode):
     rng = np.random.default_rng(5)
     T, heads, kv, S = 3, 32, 640, 48
     lg = rng.standard_normal((T, 1, heads, kv)).astype(np.float32)
     rows = np.exp(lg - lg.max(-1, keepdims=True)); rows = (rows / rows.sum(-1, keepdims=True)).astype(np.float32)
     img = rng.random((S, S, 3), dtype=np.float32)
     inv = O.right_inverse_core(24, S)
-    out = C.warp_from_attention_stack(img, rows[:, 0], 37, inv, inv)
+    out = C.warp_from_attention_stack(img, rows[:, 0], 37, inv, inv, mode=mode)
     att = O.attn_reduce_stack(rows, [37]).reshape(1, 1, 24, 24)
     px, py = O.gt_marginals(att)
     Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, S), 0))
     Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, S), 0))
     mx, my = O.maps_from_cdf(Fx, Fy)
-    assert np.array_equal(out, O.remap_bilinear(img, mx[0], my[0]))
+    assert np.array_equal(out, O.remap_bilinear(img, mx[0], my[0], mode))

@@ -241,13 +241,50 @@ def test_remap_matches_torch_grid_sample():
     img = rng.random((H, W, 3), dtype=np.float32)
     mx = np.sort(rng.random(64).astype(np.float32) * (W + 2) - 1)
     my = np.sort(rng.random(40).astype(np.float32) * (H + 2) - 1)
-    out = O.remap_bilinear(img, mx, my)
+    out = O.remap_bilinear(img, mx, my, "exact")
     gx = 2 * torch.from_numpy(mx) / (W - 1) - 1
     gy = 2 * torch.from_numpy(my) / (H - 1) - 1
     grid = torch.stack(torch.meshgrid(gy, gx, indexing="ij")[::-1], dim=-1)[None]
     ref = torch.nn.functional.grid_sample(torch.from_numpy(img).permute(2, 0, 1)[None], grid, mode="bilinear",
                                           padding_mode="border", align_corners=True)[0].permute(1, 2, 0).numpy()
     assert np.abs(out - ref).max() < 5e-5
+
+
+@pytest.mark.parametrize("size", [(37, 53, 40, 64), (336, 336, 336, 336)])
+@pytest.mark.parametrize("kind", ["sorted", "wild"])
+def test_remap_matches_scipy_map_coordinates_float64(size, kind):
+    """Independent float64 check of both arithmetic modes: scipy.ndimage.map_coordinates
+    (order=1, mode="nearest" = replicate border) on the dense meshgrid the reference hands to cv2.remap.
+    exact: the unquantised coordinates; cv2: the coordinates rounded to 1/32 pixel (what OpenCV's table weights
+    interpolate at).  float32 outputs agree to a few ulps, the uint8 fixed-point path to one grey level."""
+    from scipy.ndimage import map_coordinates
+    H, W, Ho, Wo = size
+    rng = np.random.default_rng(H + Wo)
+    img = rng.random((H, W, 3), dtype=np.float32)
+    if kind == "sorted":
+        mx = np.sort(rng.random(Wo).astype(np.float32) * (W - 1))
+        my = np.sort(rng.random(Ho).astype(np.float32) * (H - 1))
+    else:
+        mx = (rng.random(Wo) * (W + 6) - 3).astype(np.float32)
+        my = (rng.random(Ho) * (H + 6) - 3).astype(np.float32)
+
+    def dense(mxq, myq, src):
+        yy, xx = np.meshgrid(myq.astype(np.float64), mxq.astype(np.float64), indexing="ij")
+        # scipy's "nearest" extends the edge value: clamp the coordinate first so both taps sit on the border pixel
+        yy = np.clip(yy, 0, H - 1); xx = np.clip(xx, 0, W - 1)
+        return np.stack([map_coordinates(src[:, :, c].astype(np.float64), [yy, xx], order=1, mode="nearest")
+                         for c in range(3)], -1)
+
+    ref = dense(mx, my, img)
+    assert np.abs(O.remap_bilinear(img, mx, my, "exact") - ref).max() < 4e-7
+    q = lambda m: (np.rint(m.astype(np.float64) * 32) / 32)
+    refq = dense(q(mx), q(my), img)
+    assert np.abs(O.remap_bilinear(img, mx, my, "cv2") - refq).max() < 4e-7
+    u8 = (img * 255).astype(np.uint8)
+    ref8 = dense(mx, my, u8)
+    assert np.abs(O.remap_bilinear(u8, mx, my, "exact").astype(np.float64) - ref8).max() <= 0.5 + 1e-4
+    ref8q = dense(q(mx), q(my), u8)
+    assert np.abs(O.remap_bilinear(u8, mx, my, "cv2").astype(np.float64) - ref8q).max() <= 0.5 + 1e-9
 
 
 def test_cv2_compat_mode_close_to_exact():
