@@ -109,6 +109,9 @@ def lanczos_tables(n_in: int, n_out: int, device: torch.device, filt: str = "lan
     t = _DEV_CACHE.get(key)
     if t is None:
         bounds, kk, ksize = _lanczos_tables_host(n_in, n_out, filt)
+        if ksize < 8:           # rows of exactly 8 zero-padded coefficients enable the register-window kernels (attwarp.h)
+            kk = np.concatenate([kk, np.zeros((kk.shape[0], 8 - ksize), dtype=np.int32)], axis=1)
+            ksize = 8
         t = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
         _DEV_CACHE[key] = t
     return t

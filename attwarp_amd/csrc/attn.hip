@@ -239,6 +239,15 @@ __global__ __launch_bounds__(NT) void mask_postproc_kernel(const float* __restri
 constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
 
 __device__ __forceinline__ uint8_t pil_clip8(int v) { return (uint8_t)min(max(v >> PIL_PRECISION_BITS, 0), 255); }
+// four clip8 results packed into a dword: gfx950's v_ashr_pk_u8_i32 shifts, saturates to [0,255] and packs two
+// values into the low 16 bits.  Used through the builtin with an explicit 16-bit mask: when the compiler forms the
+// instruction by itself from `clip8(a) | clip8(b) << 8 | clip8(c) << 16 | ...` it omits that mask (ROCm 7.2) and the
+// stale upper half of the destination register corrupts bytes 2 and 3.
+__device__ __forceinline__ uint32_t pil_clip8x4(int s0, int s1, int s2, int s3) {
+  const uint32_t lo = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(s0, s1, PIL_PRECISION_BITS);
+  const uint32_t hi = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(s2, s3, PIL_PRECISION_BITS);
+  return lo | (hi << 16);
+}
 
 // ToPILImage on a float tensor: pic.mul(255).byte()  (truncating cast)
 __device__ __forceinline__ uint8_t to_pil_u8(float v) {
@@ -325,8 +334,10 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
   const int ye = bounds_y[2 * (yy1 - 1)] + bounds_y[2 * (yy1 - 1) + 1];
   const size_t ib = (size_t)b * h * w;
   for (int i = ys * w + tid; i < ye * w; i += NT) src[i] = mf ? to_pil_u8(mf[ib + i]) : mu[ib + i];
-  for (int i = tid; i < nrows * ksize_y; i += NT) s_ky[i] = kk_y[(size_t)yy0 * ksize_y + i];
-  if (tid < 2 * nrows) s_by[tid] = bounds_y[2 * yy0 + tid];
+  if (ksize_y != 8) {      // only the generic vertical pass reads these (R <= 64 there)
+    for (int i = tid; i < nrows * ksize_y; i += NT) s_ky[i] = kk_y[(size_t)yy0 * ksize_y + i];
+    if (tid < 2 * nrows) s_by[tid] = bounds_y[2 * yy0 + tid];
+  }
   __syncthreads();
   for (int xx = tid; xx < out_w; xx += NT) {
     const int xmin = bounds_x[2 * xx], cnt = bounds_x[2 * xx + 1];
@@ -340,13 +351,81 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
       const uint8_t* row = src + r * w;
       int ss = 1 << (PIL_PRECISION_BITS - 1);
 #pragma unroll
-      for (int x = 0; x < KS; ++x) ss += (int)row[toff[x]] * kreg[x];
+      for (int x = 0; x < KS; ++x) ss += __mul24((int)row[toff[x]], kreg[x]);
       tile[r * out_w + xx] = pil_clip8(ss);
     }
   }
   __syncthreads();
-  // vertical pass: a thread owns dword q of an output row; rows are spread over the threads left
+  // vertical pass.  Everything that depends on the output row only (bounds, the <= 8 coefficients) is wave uniform
+  // and comes from scalar loads; a lane owns one dword column (4 pixels) and keeps the 8 tile rows of the current tap
+  // window UNPACKED in registers, so an output dword costs 32 v_mad_i32_i24 (pixels are 8 bit, coefficients < 2^23)
+  // + clip / pack / one store.  The window slides by one tile row every out_h / h output rows (42 for 24 -> 1024).
+  // Work items = (64-dword column chunk, chunk of the block's rows), dealt to the 4 waves.
   const int nq = out_w >> 2;
+  if (ksize_y == 8) {       // rows of exactly 8 zero-padded coefficients (attwarp.h): unconditional 32-byte scalar loads
+    const int lane = tid & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int QW = (nq + WAVE - 1) / WAVE;
+    const int RC = QW >= 3 ? 1 : (NT / WAVE) / QW;               // QW = 1 -> 4 row chunks, 2 -> 2
+    const int rows_per = (nrows + RC - 1) / RC;
+    for (int item = wid; item < QW * RC; item += NT / WAVE) {
+      const int rc = item / QW, qc = item - rc * QW;
+      const int q = qc * WAVE + lane;
+      const int qq = min(q, nq - 1);
+      const int r_beg = rc * rows_per, r_end = min(r_beg + rows_per, nrows);
+      int win[8][4];
+      int base = -0x40000000;
+#pragma unroll
+      for (int y = 0; y < 8; ++y) win[y][0] = win[y][1] = win[y][2] = win[y][3] = 0;
+      auto load_row = [&](int r, int (&dst)[4]) {
+        const uint32_t wv = reinterpret_cast<const uint32_t*>(tile + min(r, h - 1) * out_w)[qq];
+        dst[0] = (int)(wv & 0xffu); dst[1] = (int)((wv >> 8) & 0xffu); dst[2] = (int)((wv >> 16) & 0xffu); dst[3] = (int)(wv >> 24);
+      };
+      // the NEXT row's bounds and coefficients are fetched while the current row is computed
+      int kc[8], ymin_c = 0;
+      if (r_beg < r_end) {
+        ymin_c = bounds_y[2 * (yy0 + r_beg)];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)(yy0 + r_beg) * 8 + y];
+      }
+      for (int ry = r_beg; ry < r_end; ++ry) {
+        const int yy = yy0 + ry;
+        const int ymin = ymin_c;
+        int kv[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) kv[y] = kc[y];
+        const int yn = min(yy + 1, out_h - 1);
+        ymin_c = bounds_y[2 * yn];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)yn * 8 + y];
+        if (ymin != base) {                                      // wave uniform
+          if (ymin == base + 1) {
+#pragma unroll
+            for (int y = 0; y < 7; ++y) { win[y][0] = win[y + 1][0]; win[y][1] = win[y + 1][1]; win[y][2] = win[y + 1][2]; win[y][3] = win[y + 1][3]; }
+            load_row(ymin + 7, win[7]);
+          } else {
+#pragma unroll
+            for (int y = 0; y < 8; ++y) load_row(ymin + y, win[y]);
+          }
+          base = ymin;
+        }
+        int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+          // one v_mad_i32_i24 per tap and pixel (left to itself the compiler pairs v_mul_i32_i24 with v_add3_u32:
+          // 1.5 instructions per tap); the coefficient is wave uniform and sits in an SGPR
+          asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s0) : "v"(win[y][0]), "s"(kv[y]));
+          asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s1) : "v"(win[y][1]), "s"(kv[y]));
+          asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s2) : "v"(win[y][2]), "s"(kv[y]));
+          asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s3) : "v"(win[y][3]), "s"(kv[y]));
+        }
+        if (q < nq) reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + yy) * out_w)[q] = pil_clip8x4(s0, s1, s2, s3);
+      }
+    }
+    return;
+  }
+  // generic form (more than 8 vertical taps: down-sampling): a thread owns dword q of an output row; rows are spread
+  // over the threads left
   const int rstep = nq >= NT ? 1 : NT / nq;          // rows in flight per sweep
   const int q0 = nq >= NT ? tid : tid % nq, r0 = nq >= NT ? 0 : tid / nq;
   if (r0 < rstep) {
@@ -364,11 +443,118 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
           s2 += (int)((wv >> 16) & 0xffu) * kv;
           s3 += (int)(wv >> 24) * kv;
         }
-        const uint32_t o = (uint32_t)pil_clip8(s0) | ((uint32_t)pil_clip8(s1) << 8) | ((uint32_t)pil_clip8(s2) << 16) |
-                           ((uint32_t)pil_clip8(s3) << 24);
-        reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + yy) * out_w)[q] = o;
+        reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + yy) * out_w)[q] = pil_clip8x4(s0, s1, s2, s3);
       }
     }
+  }
+}
+
+// Up-sampling form of the fused kernel (<= 8 taps on both axes: the 24 x 24 token grid blown up to the image size).
+// The cost is the vertical pass -- out_h * out_w outputs of <= 8 taps each -- so the decomposition is chosen for it:
+//   * a workgroup owns a COLUMN STRIP of 256 pixels (64 dwords, one per lane) and a chunk of the output rows; its
+//     horizontal pass therefore produces each tile value it needs exactly once (h x 256 bytes of LDS) -- in the
+//     row-block form every block of R rows recomputed ~8 of the 24 tile rows at full width, a third of all VALU work
+//     (SQ_INSTS_VALU, profiles/round2_chain_pmc.txt);
+//   * the four waves split the chunk's rows; everything that depends on the output row only (bounds, the 8
+//     zero-padded coefficients) is wave uniform and comes from scalar loads issued one row ahead; a lane keeps the 8
+//     tile rows of the current tap window unpacked in registers (the window slides by one tile row every
+//     out_h / h rows), so an output dword costs 28-32 v_mad_i32_i24 (8-bit pixels, coefficients < 2^23), two
+//     v_ashr_pk_u8_i32 and one store.
+// Same integer arithmetic as the other forms (bit-identical to Pillow).  grid = (nstrips * nchunks, B).
+// LDS: src[h*w] | tile[h][256].   kk_y rows hold exactly 8 coefficients (zero padded).
+template <int KS>
+__global__ __launch_bounds__(NT) void lanczos_strip_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
+                                                           int h, int w, int out_h, int out_w,
+                                                           const int32_t* __restrict__ bounds_x,
+                                                           const int32_t* __restrict__ kk_x, int ksize_x,
+                                                           const int32_t* __restrict__ bounds_y,
+                                                           const int32_t* __restrict__ kk_y, int nchunks, int rows_per_chunk,
+                                                           uint8_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lz[];
+  constexpr int SW = NT;                               // strip width in pixels
+  const int srcp = (h * w + 3) & ~3;
+  uint8_t* src = lz;
+  uint8_t* tile = lz + srcp;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int strip = blockIdx.x / nchunks, chunk = blockIdx.x - strip * nchunks;
+  const int yy0 = chunk * rows_per_chunk, yy1 = min(yy0 + rows_per_chunk, out_h);
+  const int ys = bounds_y[2 * yy0];                                          // first / one-past-last source row
+  const int ye = bounds_y[2 * (yy1 - 1)] + bounds_y[2 * (yy1 - 1) + 1];
+  const size_t ib = (size_t)b * h * w;
+  for (int i = ys * w + tid; i < ye * w; i += NT) src[i] = mf ? to_pil_u8(mf[ib + i]) : mu[ib + i];
+  __syncthreads();
+  {   // horizontal pass: one column per thread
+    const int xx = min(strip * SW + tid, out_w - 1);
+    const int xmin = bounds_x[2 * xx], cnt = bounds_x[2 * xx + 1];
+    int kreg[KS], toff[KS];
+#pragma unroll
+    for (int x = 0; x < KS; ++x) {
+      kreg[x] = (x < cnt) ? kk_x[(size_t)xx * ksize_x + min(x, ksize_x - 1)] : 0;
+      toff[x] = xmin + min(x, cnt - 1);
+    }
+    for (int r = ys; r < ye; ++r) {
+      const uint8_t* row = src + r * w;
+      int ss = 1 << (PIL_PRECISION_BITS - 1);
+#pragma unroll
+      for (int x = 0; x < KS; ++x) ss += __mul24((int)row[toff[x]], kreg[x]);
+      tile[r * SW + tid] = pil_clip8(ss);
+    }
+  }
+  __syncthreads();
+  const int lane = tid & (WAVE - 1);
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = out_w >> 2;
+  const int q = strip * (SW / 4) + lane;               // global dword column
+  const int nrows = yy1 - yy0;
+  const int rows_per_wave = (nrows + NT / WAVE - 1) / (NT / WAVE);
+  const int r_beg = yy0 + wid * rows_per_wave, r_end = min(r_beg + rows_per_wave, yy1);
+  if (r_beg >= r_end) return;
+  int win[8][4];
+  int base = -0x40000000;
+#pragma unroll
+  for (int y = 0; y < 8; ++y) win[y][0] = win[y][1] = win[y][2] = win[y][3] = 0;
+  auto load_row = [&](int r, int (&dst)[4]) {
+    const uint32_t wv = reinterpret_cast<const uint32_t*>(tile + min(r, h - 1) * SW)[lane];
+    dst[0] = (int)(wv & 0xffu); dst[1] = (int)((wv >> 8) & 0xffu); dst[2] = (int)((wv >> 16) & 0xffu); dst[3] = (int)(wv >> 24);
+  };
+  // the NEXT row's bounds and coefficients are fetched while the current row is computed
+  int kc[8], ymin_c = bounds_y[2 * r_beg];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)r_beg * 8 + y];
+  uint32_t* orow = reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + r_beg) * out_w) + min(q, nq - 1);
+  for (int yy = r_beg; yy < r_end; ++yy) {
+    const int ymin = ymin_c;
+    int kv[8];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) kv[y] = kc[y];
+    const int yn = min(yy + 1, out_h - 1);
+    ymin_c = bounds_y[2 * yn];
+#pragma unroll
+    for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)yn * 8 + y];
+    if (ymin != base) {                                      // wave uniform
+      if (ymin == base + 1) {
+#pragma unroll
+        for (int y = 0; y < 7; ++y) { win[y][0] = win[y + 1][0]; win[y][1] = win[y + 1][1]; win[y][2] = win[y + 1][2]; win[y][3] = win[y + 1][3]; }
+        load_row(ymin + 7, win[7]);
+      } else {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) load_row(ymin + y, win[y]);
+      }
+      base = ymin;
+    }
+    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+      if (y == 7 && kv[7] == 0) break;                       // 24 -> 1024 has 7 taps: the padded 8th is skipped (uniform)
+      // one v_mad_i32_i24 per tap and pixel (left to itself the compiler pairs v_mul_i32_i24 with v_add3_u32:
+      // 1.5 instructions per tap); the coefficient is wave uniform and sits in an SGPR
+      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s0) : "v"(win[y][0]), "s"(kv[y]));
+      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s1) : "v"(win[y][1]), "s"(kv[y]));
+      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s2) : "v"(win[y][2]), "s"(kv[y]));
+      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s3) : "v"(win[y][3]), "s"(kv[y]));
+    }
+    if (q < nq) *orow = pil_clip8x4(s0, s1, s2, s3);
+    orow += nq;
   }
 }
 
@@ -551,15 +737,33 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     hipLaunchKernelGGL(quantise_copy_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, mask_f32, mask_u8, n, out);
     return check_launch("quantise_copy_kernel");
   }
-  // small source (the 24 x 24 token grid) and both passes needed: one fused launch
+  // up-sampling of a small source with <= 8 taps per axis (the 24 x 24 token grid): column-strip kernel
+  if (need_h && need_v && tune(TUNE_LANCZOS_VARIANT) <= 0 && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
+      ksize_y == 8 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0 && (size_t)((h * w + 3) & ~3) + (size_t)h * NT <= 48 * 1024) {
+    const int nstrips = (out_w + NT - 1) / NT;
+    // enough workgroups to fill the chip (~4096: measured 1024x1024 B=256, rows per chunk 512 / 256 / 128 / 64:
+    // 108 / 105 / 111 / 127 us), at least 16 rows per wave
+    long long nchunks = (4096 + (long long)B * nstrips - 1) / ((long long)B * nstrips);
+    const int max_chunks = (out_h + 63) / 64;
+    if (nchunks > max_chunks) nchunks = max_chunks;
+    if (nchunks < 1) nchunks = 1;
+    int rows_per_chunk = (int)((out_h + nchunks - 1) / nchunks);
+    if (const int v = tune(TUNE_LANCZOS_ROWS); v >= 1) rows_per_chunk = v < out_h ? v : out_h;
+    nchunks = (out_h + rows_per_chunk - 1) / rows_per_chunk;
+    const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * NT;
+    hipLaunchKernelGGL((lanczos_strip_kernel<8>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, mask_f32, mask_u8, h, w,
+                       out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, (int)nchunks, rows_per_chunk, out);
+    return check_launch("lanczos_strip_kernel");
+  }
+  // small source and both passes needed, any tap count: one fused launch (row-block form)
   {
-    const bool two_kernel = tune(TUNE_LANCZOS_VARIANT) == 1;
+    const bool two_kernel = tune(TUNE_LANCZOS_VARIANT) == 1;      // 2: the row-block fused kernel
     const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * out_w;
     if (need_h && need_v && !two_kernel && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
         ksize_y <= 32 &&
         lds <= 48 * 1024 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0) {
       int R = out_h >= 448 ? 64 : 32;   // measured: 24->336 R=32 27 us (two-kernel form 34), 24->1024 B=256 R=64 258 us (287)
-      if (const int v = tune(TUNE_LANCZOS_ROWS); v >= 1 && v <= 64) R = v;
+      if (const int v = tune(TUNE_LANCZOS_ROWS); v >= 1 && v <= (ksize_y == 8 ? 1024 : 64)) R = v;
       hipLaunchKernelGGL((lanczos_fused_kernel<8>), dim3((out_h + R - 1) / R, B), dim3(NT), lds, st, mask_f32, mask_u8,
                          h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, ksize_y, R, out);
       return check_launch("lanczos_fused_kernel");

@@ -118,7 +118,7 @@ enum TuneKey {
   TUNE_REMAP_ALT,           // 0: every row block sweeps top-down
   TUNE_REMAP_NOSWZ,         // 1: no XCD-aware block order
   TUNE_REMAP_LDSPAD,        // extra dynamic LDS bytes (occupancy experiments)
-  TUNE_LANCZOS_VARIANT,     // 1: two-kernel form
+  TUNE_LANCZOS_VARIANT,     // 1: two-kernel form, 2: row-block fused kernel (default: column-strip kernel when it applies)
   TUNE_LANCZOS_ROWS,
   TUNE_CLIP_VARIANT,        // 1: generic kernels
   TUNE_PROFILES_VARIANT,    // 1: generic (non byte-packed) profile kernel for uint8 attention

@@ -264,6 +264,151 @@ __global__ __launch_bounds__(NT) void profiles_kernel(const T* __restrict__ A, i
   if (tid < len) col[(size_t)b * W + off + tid] = cacc;
 }
 
+// ---- uint8 attention (the main_batched chain: the up-sampled mask, AGW/new_method.py:206-215) -------------------
+// Same outputs as profiles_kernel<uint8_t, XfAttention<TR>> (col[b][c], ls[b][row][leaf]) in the same summation
+// orders, restructured around what bounds that kernel on uint8 input (profiles/round2_chain_pmc.txt: half of the
+// wave cycles parked on LDS, 26 % of the LDS cycles bank conflicts -- every byte became an 8-byte double in LDS that
+// was read back twice):
+//   * LDS holds the RAW BYTES of a band of 64 rows x one strip of <= 256 columns (whole pairwise leaves), double
+//     buffered through registers; the transform runs in registers where the value is consumed;
+//   * row sums: a thread owns (row, leaf, half h): it walks numpy's stride-8 accumulators k = 4h .. 4h+3 of that leaf
+//     with ONE dword read per 8 columns -- four independent float64 chains per thread, no cross-lane step until the
+//     final ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), one xor-1 shuffle; lane h = 0 adds the leaf's tail;
+//   * column sums: a thread owns one column and adds the band's rows in ascending order (np.sum(axis=0)'s order);
+//   * identity / square: (double)byte (+ exact float square) + 1e-9 in registers; sqrt / exp / log: a 256-entry
+//     table of XfAttention<TR>(byte) built once per workgroup with the SAME device functions as the generic kernel
+//     (bit-identical results, no per-element sqrt / exp / log).
+// The row stride of the byte tile is 256 + 8: consecutive rows start 2 banks apart, so the 64 dword reads of a wave
+// (16 rows x 2 leaves x 2 halves) hit 64 different banks.
+// grid = (nstrips, B).  Requires W % 4 == 0, a 4-byte aligned base, every leaf >= 8 long.
+constexpr int U8_RB = 64;              // rows per band
+constexpr int U8_SC = 256;             // max columns per strip
+constexpr int U8_STR = U8_SC + 8;      // tile row stride in bytes
+constexpr int U8_MAXL = 16;            // max leaves per strip
+struct StripTable {
+  int nstrips;
+  unsigned char first[PW_MAX_LEAVES];  // first leaf of strip s
+  unsigned char count[PW_MAX_LEAVES];  // leaves in strip s
+};
+
+template <int TR>
+__global__ __launch_bounds__(NT) void profiles_u8_kernel(const uint8_t* __restrict__ A, int H, int W,
+                                                         XfAttention<TR> xf, const PairwisePlan P, const StripTable S,
+                                                         double* __restrict__ col, double* __restrict__ ls) {
+  constexpr bool ARITH = (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE);
+  __shared__ __attribute__((aligned(16))) uint8_t tile[2][U8_RB * U8_STR];
+  __shared__ double lut[ARITH ? 1 : 256];
+  __shared__ int s_off[U8_MAXL], s_len[U8_MAXL];
+  const int tid = threadIdx.x, b = blockIdx.y, strip = blockIdx.x;
+  const int leaf0 = S.first[strip], nl = S.count[strip], nleaves = P.nleaves;
+  const int coff = P.off[leaf0];                                   // first column of the strip
+  const int ncols = P.off[leaf0 + nl - 1] + P.len[leaf0 + nl - 1] - coff;
+  if (tid < nl) { s_off[tid] = P.off[leaf0 + tid] - coff; s_len[tid] = P.len[leaf0 + tid]; }
+  if (!ARITH) lut[tid] = xf((double)tid);
+  const uint8_t* base = A + (size_t)b * H * W + coff;
+  // element transform of a byte held as float (exact)
+  auto tf = [&](float f) -> double {
+    if (TR == ATTWARP_T_SQUARE) return (double)fmul(f, f) + 1e-9;   // <= 65025: exact in float32
+    return (double)f + 1e-9;
+  };
+  // global -> registers: thread owns dword (tid & 63) of rows (tid >> 6) + 4 * pass
+  const int gd = tid & 63, gr = tid >> 6;
+  const int nd = ncols >> 2;                                       // dwords per strip row (ncols % 4 == 0)
+  constexpr int NPASS = U8_RB / 4;
+  uint32_t raw[NPASS];
+#define ATTWARP_U8P_FETCH(row0_)                                                                 \
+  _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                          \
+    const int r_ = (row0_) + gr + 4 * ps;                                                        \
+    raw[ps] = (r_ < H && gd < nd) ? reinterpret_cast<const uint32_t*>(base + (size_t)r_ * W)[gd] : 0u; \
+  }
+#define ATTWARP_U8P_STAGE(buf_)                                                                  \
+  _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps)                                            \
+      reinterpret_cast<uint32_t*>(tile[buf_] + (gr + 4 * ps) * U8_STR)[gd] = raw[ps];
+  ATTWARP_U8P_FETCH(0)
+  double cacc = 0.0;
+  int buf = 0;
+  for (int row0 = 0; row0 < H; row0 += U8_RB) {
+    const int nb = min(U8_RB, H - row0);
+    ATTWARP_U8P_STAGE(buf)
+    __syncthreads();                                               // (also publishes s_off / s_len / lut the first time)
+    if (row0 + U8_RB < H) ATTWARP_U8P_FETCH(row0 + U8_RB)
+    const uint8_t* tb = tile[buf];
+    // ---- rows: tasks (row, leaf, half) ----
+    for (int t = tid; t < U8_RB * nl * 2; t += NT) {
+      const int r = t / (2 * nl), rem = t - r * 2 * nl, j = rem >> 1, hh = rem & 1;
+      const int off = s_off[j], len = s_len[j], m = len >> 3;
+      const uint8_t* rp = tb + r * U8_STR + off + 4 * hh;
+      double a0, a1, a2, a3;
+      {
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(rp);
+        if (ARITH) {
+          a0 = tf((float)(wv & 0xffu)); a1 = tf((float)((wv >> 8) & 0xffu));
+          a2 = tf((float)((wv >> 16) & 0xffu)); a3 = tf((float)(wv >> 24));
+        } else {
+          a0 = lut[wv & 0xffu]; a1 = lut[(wv >> 8) & 0xffu]; a2 = lut[(wv >> 16) & 0xffu]; a3 = lut[wv >> 24];
+        }
+      }
+      for (int i = 1; i < m; ++i) {
+        const uint32_t wv = *reinterpret_cast<const uint32_t*>(rp + 8 * i);
+        if (ARITH) {
+          a0 += tf((float)(wv & 0xffu)); a1 += tf((float)((wv >> 8) & 0xffu));
+          a2 += tf((float)((wv >> 16) & 0xffu)); a3 += tf((float)(wv >> 24));
+        } else {
+          a0 += lut[wv & 0xffu]; a1 += lut[(wv >> 8) & 0xffu]; a2 += lut[(wv >> 16) & 0xffu]; a3 += lut[wv >> 24];
+        }
+      }
+      double u = (a0 + a1) + (a2 + a3);
+      u = u + __shfl_xor(u, 1, WAVE);                              // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+      if (hh == 0 && r < nb) {
+        const uint8_t* tp = tb + r * U8_STR + off;
+        for (int i = 8 * m; i < len; ++i) u += ARITH ? tf((float)tp[i]) : lut[tp[i]];
+        ls[((size_t)b * H + row0 + r) * nleaves + leaf0 + j] = u;
+      }
+    }
+    // ---- columns: ascending rows ----
+    if (tid < ncols) {
+      const uint8_t* cp = tb + tid;
+      for (int r = 0; r < nb; ++r) cacc = cacc + (ARITH ? tf((float)cp[r * U8_STR]) : lut[cp[r * U8_STR]]);
+    }
+    buf ^= 1;                                                      // the other buffer is free: its readers passed the barrier above
+  }
+#undef ATTWARP_U8P_FETCH
+#undef ATTWARP_U8P_STAGE
+  if (tid < ncols) col[(size_t)b * W + coff + tid] = cacc;
+}
+
+// strips of whole leaves, <= 256 columns and <= 16 leaves each; false if the fast kernel does not apply
+static bool build_strips(const PairwisePlan& P, StripTable& S) {
+  S.nstrips = 0;
+  int j = 0;
+  while (j < P.nleaves) {
+    int cols = 0, n = 0;
+    while (j + n < P.nleaves && n < U8_MAXL && cols + P.len[j + n] <= U8_SC) {
+      if (P.len[j + n] < 8 || P.len[j + n] % 4 != 0) return false;
+      cols += P.len[j + n];
+      ++n;
+    }
+    if (n == 0) return false;
+    S.first[S.nstrips] = (unsigned char)j;
+    S.count[S.nstrips] = (unsigned char)n;
+    ++S.nstrips;
+    j += n;
+  }
+  return true;
+}
+
+template <int TR>
+static int launch_profiles_u8(const void* A, int B, int H, int W, XfAttention<TR> xf, const PairwisePlan& P,
+                              double* col, double* ls, hipStream_t st, bool* handled) {
+  *handled = false;
+  StripTable S;
+  if (tune(TUNE_PROFILES_VARIANT) == 1 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 3u) != 0 || !build_strips(P, S))
+    return ATTWARP_OK;
+  *handled = true;
+  hipLaunchKernelGGL((profiles_u8_kernel<TR>), dim3(S.nstrips, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, S, col, ls);
+  return check_launch("profiles_u8_kernel");
+}
+
 // ---- A6 finalize: normalise a marginal.  grid = (B, 2) ----------------------------------
 __global__ __launch_bounds__(NT) void marginals_finalize_kernel(const double* __restrict__ col,
                                                                 const double* __restrict__ ls, int nleaves, int H,
@@ -495,7 +640,11 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
 #define ATTWARP_PROFILES(TR)                                                                                      \
   case TR: {                                                                                                      \
     XfAttention<TR> xf{exp_scale, exp_divisor};                                                                   \
-    if (dtype == ATTWARP_U8) rc = launch_profiles<uint8_t, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);   \
+    if (dtype == ATTWARP_U8) {                                                                                    \
+      bool handled = false;                                                                                       \
+      rc = launch_profiles_u8<TR>(att, B, h, w, xf, Pw, col, ls, st, &handled);                                   \
+      if (!handled) rc = launch_profiles<uint8_t, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);            \
+    }                                                                                                             \
     else if (dtype == ATTWARP_F32) rc = launch_profiles<float, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st); \
     else rc = launch_profiles<double, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);                        \
   } break;

@@ -119,7 +119,9 @@ ATTWARP_API int attwarp_mask_postproc(const float* mask, int B, int n, int kerne
 /* ---- A4: ToPILImage (x*255, truncating cast) + PIL Image.resize(LANCZOS), llava.py:192-196,243,253
  * mask_f32 [B,h,w] float32 in [0,1]  (or mask_u8 [B,h,w] if mask_f32 is NULL)
  * -> out [B,out_h,out_w] uint8.  Coefficients: host-computed Pillow tables uploaded by the
- * caller: bounds_* int32[out,2] = (first tap, tap count), kk_* int32[out,ksize] (22-bit fixed point).
+ * caller: bounds_* int32[out,2] = (first tap, tap count), kk_* int32[out,ksize] (22-bit fixed point; entries at
+ * index >= tap count must be 0, as Pillow leaves them; a row stride of exactly 8 -- zero-pad narrower tables --
+ * selects the fastest vertical pass).
  * tmp: uint8 [B,h,out_w] workspace (horizontal pass output). */
 ATTWARP_API int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_t* mask_u8, int B, int h, int w,
                                   int out_h, int out_w,

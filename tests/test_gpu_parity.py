@@ -299,7 +299,7 @@ def test_revise_mask(dev, golden):
         ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
 
 
-@pytest.mark.parametrize("variant", [-1, 1])       # fused single launch (small sources) / two-kernel form
+@pytest.mark.parametrize("variant", [-1, 1, 2])    # column-strip kernel (up-sampling) / two-kernel form / row-block fused kernel
 @pytest.mark.parametrize("wh", [(336, 336), (500, 375), (1024, 1024), (24, 48), (17, 24), (24, 24)])
 def test_mask_upsample_lanczos_bit_exact(dev, golden, wh, variant):
     from attwarp_amd import attention_extraction as ae
@@ -652,6 +652,35 @@ def test_maps_from_attention_bit_exact_vs_numpy_order(dev, hw):
         for b in range(2):
             rx, ry = O.maps_from_attention(a[b], 500, 400, tr)
             assert np.array_equal(N(mx)[b], rx) and np.array_equal(N(my)[b], ry), (hw, tr)
+
+
+@pytest.mark.parametrize("hw", [(1024, 1024), (336, 336), (500, 500), (333, 500), (100, 1000), (64, 260), (70, 132),
+                                (40, 2048)])
+def test_maps_from_uint8_attention_fast_kernel(dev, hw):
+    """uint8 attention (the up-sampled mask of the main_batched chain) through profiles_u8_kernel -- raw bytes in LDS,
+    per-thread stride-8 accumulator chains, table look-up for sqrt / exp / log -- against the oracle (numpy's own
+    summation orders) for identity / square, and bit-for-bit against the generic kernel for every transform
+    (the device libm is the same in both), with and without the inverse, on regular and irregular pairwise trees
+    (leaves of 128, 80/88, 120/128/64/68 with tails, one leaf, 16 leaves)."""
+    from attwarp_amd import new_method as nm
+    h, w = hw
+    rng = np.random.default_rng(h * 13 + w)
+    att = rng.integers(0, 256, (3, h, w), dtype=np.uint8)
+    att[1] = np.clip(rng.normal(128, 3, (h, w)), 0, 255).astype(np.uint8)          # smooth: table look-ups collide
+    att[2, : h // 2] = 0                                                           # half empty
+    a = T(att, dev)
+    for tr in ("identity", "square", "sqrt", "exp", "log"):
+        for inv in (False, True):
+            kw = dict(transform=tr, exp_scale=1.0, exp_divisor=50.0, apply_inverse=inv)
+            mx, my = nm.attention_axis_maps(a, 500, 400, **kw)
+            with _lib.debug_override(profiles_variant=1):
+                gx, gy = nm.attention_axis_maps(a, 500, 400, **kw)
+            # (log + inverse overflows to NaN maps in the reference too: NaNs must match position by position)
+            assert np.array_equal(N(mx), N(gx), equal_nan=True) and np.array_equal(N(my), N(gy), equal_nan=True), (hw, tr, inv)
+            if tr in ("identity", "square") and not inv:
+                for b in range(3):
+                    rx, ry = O.maps_from_attention(att[b], 500, 400, tr)
+                    assert np.array_equal(N(mx)[b], rx) and np.array_equal(N(my)[b], ry), (hw, tr, b)
 
 
 def test_uniform_attention_gives_identity_warp(dev):
