@@ -269,41 +269,32 @@ __global__ __launch_bounds__(NT) void profiles_kernel(const T* __restrict__ A, i
 // orders, restructured around what bounds that kernel on uint8 input (profiles/round2_chain_pmc.txt: half of the
 // wave cycles parked on LDS, 26 % of the LDS cycles bank conflicts -- every byte became an 8-byte double in LDS that
 // was read back twice):
-//   * LDS holds the RAW BYTES of a band of 64 rows x one strip of <= 256 columns (whole pairwise leaves), double
-//     buffered through registers; the transform runs in registers where the value is consumed;
-//   * row sums: a thread owns (row, leaf, half h): it walks numpy's stride-8 accumulators k = 4h .. 4h+3 of that leaf
-//     with ONE dword read per 8 columns -- four independent float64 chains per thread, no cross-lane step until the
-//     final ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), one xor-1 shuffle; lane h = 0 adds the leaf's tail;
+//   * grid = (leaf, image) as before, but LDS holds the RAW BYTES of a band of 64 rows x the leaf's <= 128 columns,
+//     double buffered through registers; the transform runs in registers where the value is consumed;
+//   * the two reductions run CONCURRENTLY on different waves of the workgroup: waves 0-1 own the row sums, waves 2-3
+//     the column sums (about the same number of float64 operations each);
+//   * row sums: a thread owns (row, half h) and walks numpy's stride-8 accumulators k = 4h .. 4h+3 with ONE dword
+//     read per 8 columns -- four independent float64 chains per thread, no cross-lane step until the final
+//     ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)), one xor-1 shuffle; lane h = 0 adds the leaf's tail;
 //   * column sums: a thread owns one column and adds the band's rows in ascending order (np.sum(axis=0)'s order);
 //   * identity / square: (double)byte (+ exact float square) + 1e-9 in registers; sqrt / exp / log: a 256-entry
 //     table of XfAttention<TR>(byte) built once per workgroup with the SAME device functions as the generic kernel
 //     (bit-identical results, no per-element sqrt / exp / log).
-// The row stride of the byte tile is 256 + 8: consecutive rows start 2 banks apart, so the 64 dword reads of a wave
-// (16 rows x 2 leaves x 2 halves) hit 64 different banks.
-// grid = (nstrips, B).  Requires W % 4 == 0, a 4-byte aligned base, every leaf >= 8 long.
+// The row stride of the byte tile is 128 + 8 bytes = 34 dwords: the 64 dword reads of a row-sum wave (32 rows x 2
+// halves) hit 64 different banks.  Requires W % 4 == 0, a 4-byte aligned base, every leaf >= 8 long and a multiple of 4.
 constexpr int U8_RB = 64;              // rows per band
-constexpr int U8_SC = 256;             // max columns per strip
-constexpr int U8_STR = U8_SC + 8;      // tile row stride in bytes
-constexpr int U8_MAXL = 16;            // max leaves per strip
-struct StripTable {
-  int nstrips;
-  unsigned char first[PW_MAX_LEAVES];  // first leaf of strip s
-  unsigned char count[PW_MAX_LEAVES];  // leaves in strip s
-};
+constexpr int U8_STR = 128 + 8;        // tile row stride in bytes
 
 template <int TR>
 __global__ __launch_bounds__(NT) void profiles_u8_kernel(const uint8_t* __restrict__ A, int H, int W,
-                                                         XfAttention<TR> xf, const PairwisePlan P, const StripTable S,
+                                                         XfAttention<TR> xf, const PairwisePlan P,
                                                          double* __restrict__ col, double* __restrict__ ls) {
   constexpr bool ARITH = (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE);
   __shared__ __attribute__((aligned(16))) uint8_t tile[2][U8_RB * U8_STR];
   __shared__ double lut[ARITH ? 1 : 256];
-  __shared__ int s_off[U8_MAXL], s_len[U8_MAXL];
-  const int tid = threadIdx.x, b = blockIdx.y, strip = blockIdx.x;
-  const int leaf0 = S.first[strip], nl = S.count[strip], nleaves = P.nleaves;
-  const int coff = P.off[leaf0];                                   // first column of the strip
-  const int ncols = P.off[leaf0 + nl - 1] + P.len[leaf0 + nl - 1] - coff;
-  if (tid < nl) { s_off[tid] = P.off[leaf0 + tid] - coff; s_len[tid] = P.len[leaf0 + tid]; }
+  const int tid = threadIdx.x, b = blockIdx.y, leaf = blockIdx.x;
+  const int coff = P.off[leaf], len = P.len[leaf], nleaves = P.nleaves;
+  const int m = len >> 3;                                          // steps of the stride-8 accumulators
   if (!ARITH) lut[tid] = xf((double)tid);
   const uint8_t* base = A + (size_t)b * H * W + coff;
   // element transform of a byte held as float (exact)
@@ -311,101 +302,93 @@ __global__ __launch_bounds__(NT) void profiles_u8_kernel(const uint8_t* __restri
     if (TR == ATTWARP_T_SQUARE) return (double)fmul(f, f) + 1e-9;   // <= 65025: exact in float32
     return (double)f + 1e-9;
   };
-  // global -> registers: thread owns dword (tid & 63) of rows (tid >> 6) + 4 * pass
-  const int gd = tid & 63, gr = tid >> 6;
-  const int nd = ncols >> 2;                                       // dwords per strip row (ncols % 4 == 0)
-  constexpr int NPASS = U8_RB / 4;
+  // global -> registers: thread owns dword (tid & 31) of rows (tid >> 5) + 8 * pass
+  const int gd = tid & 31, gr = tid >> 5;
+  const int nd = len >> 2;                                         // dwords per leaf row (len % 4 == 0)
+  constexpr int NPASS = U8_RB / 8;
   uint32_t raw[NPASS];
 #define ATTWARP_U8P_FETCH(row0_)                                                                 \
   _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                          \
-    const int r_ = (row0_) + gr + 4 * ps;                                                        \
+    const int r_ = (row0_) + gr + 8 * ps;                                                        \
     raw[ps] = (r_ < H && gd < nd) ? reinterpret_cast<const uint32_t*>(base + (size_t)r_ * W)[gd] : 0u; \
   }
 #define ATTWARP_U8P_STAGE(buf_)                                                                  \
   _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps)                                            \
-      reinterpret_cast<uint32_t*>(tile[buf_] + (gr + 4 * ps) * U8_STR)[gd] = raw[ps];
+      reinterpret_cast<uint32_t*>(tile[buf_] + (gr + 8 * ps) * U8_STR)[gd] = raw[ps];
   ATTWARP_U8P_FETCH(0)
   double cacc = 0.0;
   int buf = 0;
   for (int row0 = 0; row0 < H; row0 += U8_RB) {
     const int nb = min(U8_RB, H - row0);
     ATTWARP_U8P_STAGE(buf)
-    __syncthreads();                                               // (also publishes s_off / s_len / lut the first time)
+    __syncthreads();                                               // (also publishes lut the first time)
     if (row0 + U8_RB < H) ATTWARP_U8P_FETCH(row0 + U8_RB)
     const uint8_t* tb = tile[buf];
-    // ---- rows: tasks (row, leaf, half) ----
-    for (int t = tid; t < U8_RB * nl * 2; t += NT) {
-      const int r = t / (2 * nl), rem = t - r * 2 * nl, j = rem >> 1, hh = rem & 1;
-      const int off = s_off[j], len = s_len[j], m = len >> 3;
-      const uint8_t* rp = tb + r * U8_STR + off + 4 * hh;
+    if (tid < 2 * U8_RB) {
+      // ---- rows (waves 0-1): thread = (row, half) ----
+      const int r = tid >> 1, hh = tid & 1;
+      const uint8_t* rp = tb + r * U8_STR + 4 * hh;
+      // all <= 16 dwords of the chain are requested before the first add (in-row reads past the leaf are harmless:
+      // the tile row is 136 bytes); steps i >= m are skipped
+      uint32_t wv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i] = *reinterpret_cast<const uint32_t*>(rp + 8 * i);
       double a0, a1, a2, a3;
-      {
-        const uint32_t wv = *reinterpret_cast<const uint32_t*>(rp);
-        if (ARITH) {
-          a0 = tf((float)(wv & 0xffu)); a1 = tf((float)((wv >> 8) & 0xffu));
-          a2 = tf((float)((wv >> 16) & 0xffu)); a3 = tf((float)(wv >> 24));
-        } else {
-          a0 = lut[wv & 0xffu]; a1 = lut[(wv >> 8) & 0xffu]; a2 = lut[(wv >> 16) & 0xffu]; a3 = lut[wv >> 24];
-        }
+      if (ARITH) {
+        a0 = tf((float)(wv[0] & 0xffu)); a1 = tf((float)((wv[0] >> 8) & 0xffu));
+        a2 = tf((float)((wv[0] >> 16) & 0xffu)); a3 = tf((float)(wv[0] >> 24));
+      } else {
+        a0 = lut[wv[0] & 0xffu]; a1 = lut[(wv[0] >> 8) & 0xffu]; a2 = lut[(wv[0] >> 16) & 0xffu]; a3 = lut[wv[0] >> 24];
       }
-      for (int i = 1; i < m; ++i) {
-        const uint32_t wv = *reinterpret_cast<const uint32_t*>(rp + 8 * i);
-        if (ARITH) {
-          a0 += tf((float)(wv & 0xffu)); a1 += tf((float)((wv >> 8) & 0xffu));
-          a2 += tf((float)((wv >> 16) & 0xffu)); a3 += tf((float)(wv >> 24));
-        } else {
-          a0 += lut[wv & 0xffu]; a1 += lut[(wv >> 8) & 0xffu]; a2 += lut[(wv >> 16) & 0xffu]; a3 += lut[wv >> 24];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) {
+        if (i < m) {                                               // block uniform
+          if (ARITH) {
+            a0 += tf((float)(wv[i] & 0xffu)); a1 += tf((float)((wv[i] >> 8) & 0xffu));
+            a2 += tf((float)((wv[i] >> 16) & 0xffu)); a3 += tf((float)(wv[i] >> 24));
+          } else {
+            a0 += lut[wv[i] & 0xffu]; a1 += lut[(wv[i] >> 8) & 0xffu]; a2 += lut[(wv[i] >> 16) & 0xffu]; a3 += lut[wv[i] >> 24];
+          }
         }
       }
       double u = (a0 + a1) + (a2 + a3);
       u = u + __shfl_xor(u, 1, WAVE);                              // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
       if (hh == 0 && r < nb) {
-        const uint8_t* tp = tb + r * U8_STR + off;
+        const uint8_t* tp = tb + r * U8_STR;
         for (int i = 8 * m; i < len; ++i) u += ARITH ? tf((float)tp[i]) : lut[tp[i]];
-        ls[((size_t)b * H + row0 + r) * nleaves + leaf0 + j] = u;
+        ls[((size_t)b * H + row0 + r) * nleaves + leaf] = u;
       }
-    }
-    // ---- columns: ascending rows ----
-    if (tid < ncols) {
-      const uint8_t* cp = tb + tid;
-      for (int r = 0; r < nb; ++r) cacc = cacc + (ARITH ? tf((float)cp[r * U8_STR]) : lut[cp[r * U8_STR]]);
+    } else if (tid - 2 * U8_RB < len) {
+      // ---- columns (waves 2-3): ascending rows ----
+      const uint8_t* cp = tb + (tid - 2 * U8_RB);
+      for (int r0 = 0; r0 < nb; r0 += 16) {                          // 16 byte reads in flight, then the 16 ordered adds
+        uint8_t v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = cp[(r0 + i) * U8_STR];  // rows >= nb of a partial band: stale, unused
+        if (r0 + 16 <= nb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cacc = cacc + (ARITH ? tf((float)v[i]) : lut[v[i]]);
+        } else {
+          for (int i = 0; i < nb - r0; ++i) cacc = cacc + (ARITH ? tf((float)cp[(r0 + i) * U8_STR]) : lut[cp[(r0 + i) * U8_STR]]);
+        }
+      }
     }
     buf ^= 1;                                                      // the other buffer is free: its readers passed the barrier above
   }
 #undef ATTWARP_U8P_FETCH
 #undef ATTWARP_U8P_STAGE
-  if (tid < ncols) col[(size_t)b * W + coff + tid] = cacc;
-}
-
-// strips of whole leaves, <= 256 columns and <= 16 leaves each; false if the fast kernel does not apply
-static bool build_strips(const PairwisePlan& P, StripTable& S) {
-  S.nstrips = 0;
-  int j = 0;
-  while (j < P.nleaves) {
-    int cols = 0, n = 0;
-    while (j + n < P.nleaves && n < U8_MAXL && cols + P.len[j + n] <= U8_SC) {
-      if (P.len[j + n] < 8 || P.len[j + n] % 4 != 0) return false;
-      cols += P.len[j + n];
-      ++n;
-    }
-    if (n == 0) return false;
-    S.first[S.nstrips] = (unsigned char)j;
-    S.count[S.nstrips] = (unsigned char)n;
-    ++S.nstrips;
-    j += n;
-  }
-  return true;
+  if (tid >= 2 * U8_RB && tid - 2 * U8_RB < len) col[(size_t)b * W + coff + tid - 2 * U8_RB] = cacc;
 }
 
 template <int TR>
 static int launch_profiles_u8(const void* A, int B, int H, int W, XfAttention<TR> xf, const PairwisePlan& P,
                               double* col, double* ls, hipStream_t st, bool* handled) {
   *handled = false;
-  StripTable S;
-  if (tune(TUNE_PROFILES_VARIANT) == 1 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 3u) != 0 || !build_strips(P, S))
-    return ATTWARP_OK;
+  if (tune(TUNE_PROFILES_VARIANT) == 1 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 3u) != 0) return ATTWARP_OK;
+  for (int j = 0; j < P.nleaves; ++j)
+    if (P.len[j] < 8 || P.len[j] % 4 != 0) return ATTWARP_OK;
   *handled = true;
-  hipLaunchKernelGGL((profiles_u8_kernel<TR>), dim3(S.nstrips, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, S, col, ls);
+  hipLaunchKernelGGL((profiles_u8_kernel<TR>), dim3(P.nleaves, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, col, ls);
   return check_launch("profiles_u8_kernel");
 }
 
@@ -486,7 +469,8 @@ __device__ __forceinline__ double inverse_transform(double x, int transform, dou
   }
 }
 
-__global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const double* __restrict__ col,
+__global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const PairwisePlan Pw_arg, const PairwisePlan Ph_arg,
+                                                                     const double* __restrict__ col,
                                                                      const double* __restrict__ ls, int h, int w,
                                                                      int new_w, int new_h, int transform,
                                                                      double exp_scale, double exp_divisor,
@@ -498,8 +482,14 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
   __shared__ double leafbuf[PW_MAX_LEAVES];
   __shared__ PlanLds Pw, Ph;             // numpy's pairwise plans of a row (w terms) and of a column profile (h terms)
   const int b = blockIdx.x, axis = blockIdx.y;
-  if (threadIdx.x == 0) pw_build_lds(w, &Pw);
-  if (threadIdx.x == WAVE) pw_build_lds(h, &Ph);
+  // the two plans come from the host through the kernel arguments and are copied to LDS by all threads (one lane
+  // building them with its explicit stack in LDS cost ~10 us of dependent LDS round trips per workgroup)
+  {
+    const int t = threadIdx.x;
+    if (t < PW_MAX_LEAVES) { Pw.off[t] = Pw_arg.off[t]; Pw.len[t] = Pw_arg.len[t]; Ph.off[t] = Ph_arg.off[t]; Ph.len[t] = Ph_arg.len[t]; }
+    Pw.prog[t] = Pw_arg.prog[t]; Ph.prog[t] = Ph_arg.prog[t];
+    if (t == 0) { Pw.nleaves = Pw_arg.nleaves; Pw.nprog = Pw_arg.nprog; Ph.nleaves = Ph_arg.nleaves; Ph.nprog = Ph_arg.nprog; }
+  }
   __syncthreads();
   const int n = axis ? h : w;            // profile length
   const int other = axis ? w : h;        // number of terms summed into each profile entry
@@ -544,16 +534,19 @@ __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const doubl
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    // np.cumsum: sequential running sum (adds only; the division below is elementwise and parallel)
+    // np.cumsum: sequential running sum (adds only; the division below is elementwise and parallel).  32 values are
+    // requested from LDS before the first add of a batch: one LDS round trip per 32 dependent adds instead of per 4
+    // (the lane spent most of its time waiting: 1024 knots 16 us -> 5 us).
     double c = 0.0;
     int k = 1;
-    for (; k + 4 <= n + 1; k += 4) {
-      double v0 = xn[k], v1 = xn[k + 1], v2 = xn[k + 2], v3 = xn[k + 3];
-      c = c + v0; v0 = c;
-      c = c + v1; v1 = c;
-      c = c + v2; v2 = c;
-      c = c + v3; v3 = c;
-      xn[k] = v0; xn[k + 1] = v1; xn[k + 2] = v2; xn[k + 3] = v3;
+    for (; k + 32 <= n + 1; k += 32) {
+      double v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = xn[k + i];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { c = c + v[i]; v[i] = c; }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) xn[k + i] = v[i];
     }
     for (; k <= n; ++k) { c = c + xn[k]; xn[k] = c; }
   }
@@ -660,7 +653,7 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
   }
 #undef ATTWARP_PROFILES
   if (rc) return rc;
-  hipLaunchKernelGGL(attention_maps_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)(n + 2) * sizeof(double), st, col,
-                     ls, h, w, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
+  hipLaunchKernelGGL(attention_maps_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)(n + 2) * sizeof(double), st, Pw, Ph,
+                     col, ls, h, w, new_w, new_h, transform, exp_scale, exp_divisor, apply_inverse, map_x, map_y);
   return check_launch("attention_maps_finalize_kernel");
 }
