@@ -18,12 +18,16 @@ from ._lib import call, ptr, require_gpu, stream_ptr
 NUM_IMAGE_TOKENS = 576  # 24 x 24 patches for LLaVA-1.5 (reference :350)
 
 
-def attn_reduce_step(attn_weights: torch.Tensor, starts: torch.Tensor, ntok: int) -> torch.Tensor:
+def attn_reduce_step(attn_weights: torch.Tensor, starts: torch.Tensor, ntok: int,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One step of attention aggregation: [B,heads,q,kv] -> [B,ntok] (same dtype).
-    ``starts``: int32 device tensor [B] of per-sample image-token offsets."""
+    ``starts``: int32 device tensor [B] of per-sample image-token offsets.  ``out``: optional caller-owned result."""
     dev = require_gpu(attn_weights, starts)
     B, heads, q, kv = attn_weights.shape
-    out = torch.empty(B, ntok, device=dev, dtype=attn_weights.dtype)
+    if out is None:
+        out = torch.empty(B, ntok, device=dev, dtype=attn_weights.dtype)
+    elif tuple(out.shape) != (B, ntok) or out.dtype != attn_weights.dtype or not out.is_contiguous() or out.device != dev:
+        raise ValueError(f"attn_reduce_step: out must be a contiguous {attn_weights.dtype} [B={B}, ntok={ntok}] tensor on {dev}")
     sb, sh, sq, skv = attn_weights.stride()
     with torch.cuda.device(dev):
         call("attwarp_attn_reduce_step", ptr(attn_weights), _lib.dtype_id(attn_weights), B, heads, q, kv, sb, sh, sq,

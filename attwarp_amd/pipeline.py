@@ -82,7 +82,7 @@ def warp_from_pdf(images: torch.Tensor, px: torch.Tensor, py: torch.Tensor, out_
 
 def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int],
                                    out_size: Optional[Tuple[int, int]] = None, eps: float = 1e-8,
-                                   return_attention: bool = False):
+                                   return_attention: bool = False, maps_out=None):
     """Per-step aggregated maps [T,B,g*g] float32 (output of the A1 kernel) -> (map_x, map_y) in ONE
     launch: mean over steps, marginals of the g x g map, PDF up-sample, CDF, inverse maps.
     Bit-identical to attn_finalize -> gt_marginals -> axis_maps_from_pdf."""
@@ -98,8 +98,13 @@ def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int]
     H_out, W_out = (H, W) if out_size is None else (int(out_size[0]), int(out_size[1]))
     inv_x = _tables.right_inverse_inv(g, W, eps, dev)
     inv_y = _tables.right_inverse_inv(g, H, eps, dev)
-    mx = torch.empty(B, W_out, device=dev, dtype=torch.float32)
-    my = torch.empty(B, H_out, device=dev, dtype=torch.float32)
+    if maps_out is None:
+        mx = torch.empty(B, W_out, device=dev, dtype=torch.float32)
+        my = torch.empty(B, H_out, device=dev, dtype=torch.float32)
+    else:                       # caller-owned static buffers (graph replay)
+        mx, my = maps_out
+        if tuple(mx.shape) != (B, W_out) or tuple(my.shape) != (B, H_out) or mx.dtype != torch.float32 or my.dtype != torch.float32:
+            raise ValueError("axis_maps_from_attention_steps: maps_out must be float32 [B,W_out], [B,H_out]")
     att = torch.empty(B, ntok, device=dev, dtype=torch.float32) if return_attention else None
     with torch.cuda.device(dev):
         call("attwarp_axis_maps_from_steps", ptr(s), T, B, g, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y), ptr(mx),
@@ -213,3 +218,121 @@ def capture_step(fn, *args, warmup: int = 2):
     with torch.cuda.graph(g):
         out = fn(*args)
     return g, out
+
+
+class OverlappedWarp:
+    """Steady-state form of ``warp_from_attention_stack`` for a stream of equally shaped batches: one HIP graph whose
+    THREE branches run side by side --
+        R: the resample of batch k                      (HBM-bound, maps[c])
+        M: the map construction of batch k+1            (latency-bound, steps[c] -> maps[1-c])
+        A: the attention reduce of batch k+2            (a second bandwidth stream, rows -> steps[1-c])
+    -- instead of reduce -> maps -> resample back to back for every batch.  Buffers are static (graph replay); the
+    per-step maps and the per-step attention maps are double buffered.
+
+        ow = OverlappedWarp(images, rows, starts)      # captures; images / rows are the static input buffers
+        rows <- attention of batch 0;  ow.prime()      # reduce + maps of batch 0 (serial)
+        rows <- attention of batch 1;  ow.prime2()     # reduce of batch 1 (serial)
+        for k in 0 .. n-1:
+            images <- batch k;  rows <- attention of batch k+2 (if any)
+            out = ow.step()                            # R(k) || M(k+1) || A(k+2)
+    i.e. the attention buffer runs two batches ahead of the image buffer (``ow.flush()`` = R alone, for a tail).
+    With static inputs every step is bit-identical to ``warp_from_attention_stack`` (same kernels, same arguments)."""
+
+    def __init__(self, images: torch.Tensor, rows: torch.Tensor, starts: torch.Tensor, out_size=None,
+                 channels_last: bool = False, mode: str = "cv2"):
+        dev = require_gpu(images, rows, starts)
+        if rows.dtype != torch.float32:
+            raise TypeError("OverlappedWarp: float32 attention rows expected")
+        self.images, self.rows, self.starts = images, rows, starts
+        self.channels_last, self.mode = channels_last, mode
+        H, W = (images.shape[1], images.shape[2]) if channels_last else (images.shape[2], images.shape[3])
+        self.size_hw = (H, W)
+        self.out_size = out_size
+        T = rows.shape[0]
+        self.starts_tiled = starts.repeat(T)
+        B = images.shape[0]
+        Ho, Wo = (H, W) if out_size is None else out_size
+        shape = (B, Ho, Wo, images.shape[3]) if channels_last else (B, images.shape[1], Ho, Wo)
+        self.out = torch.empty(shape, device=dev, dtype=images.dtype)
+        self.cur = 0
+        self._sideM = torch.cuda.Stream(device=dev)
+        self._sideA = torch.cuda.Stream(device=dev)
+        self._graphs = [None, None]
+        self._many = {}
+        # both buffer sets, filled once outside capture (allocations, lazily built tables)
+        self.steps = [attention_step_maps(self.rows, self.starts, ae.NUM_IMAGE_TOKENS, self.starts_tiled) for _ in (0, 1)]
+        self.maps = [axis_maps_from_attention_steps(self.steps[i], self.size_hw, self.out_size) for i in (0, 1)]
+        cu.remap_separable(self.images, *self.maps[0], mode=self.mode, channels_last=self.channels_last, out=self.out)
+        torch.cuda.synchronize(dev)
+        for i in (0, 1):
+            self._graphs[i] = self._capture(i)
+
+    def _reduce(self, i):
+        """A: rows -> steps[i]"""
+        T, B, heads, kv = self.rows.shape
+        ae.attn_reduce_step(self.rows.view(T * B, heads, 1, kv), self.starts_tiled, ae.NUM_IMAGE_TOKENS,
+                            out=self.steps[i].view(T * B, ae.NUM_IMAGE_TOKENS))
+
+    def _maps(self, i_steps, i_maps):
+        """M: steps[i_steps] -> maps[i_maps]"""
+        axis_maps_from_attention_steps(self.steps[i_steps], self.size_hw, self.out_size, maps_out=self.maps[i_maps])
+
+    def _resample(self, i):
+        cu.remap_separable(self.images, *self.maps[i], mode=self.mode, channels_last=self.channels_last, out=self.out)
+
+    def _capture(self, i, unroll: int = 1):
+        """graph: ``unroll`` consecutive steps starting with buffer set c = i; step u is
+        R: resample with maps[c]  ||  M: steps[c] -> maps[1-c]  ||  A: rows -> steps[1-c],   joined before step u+1."""
+        g = torch.cuda.CUDAGraph()
+        main = torch.cuda.Stream(device=self.out.device)
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            with torch.cuda.graph(g, stream=main):
+                c = i
+                for _ in range(unroll):
+                    self._sideM.wait_stream(main)                    # fork
+                    self._sideA.wait_stream(main)
+                    with torch.cuda.stream(self._sideA):
+                        self._reduce(1 - c)
+                    with torch.cuda.stream(self._sideM):
+                        self._maps(c, 1 - c)
+                    self._resample(c)
+                    main.wait_stream(self._sideM)                    # join
+                    main.wait_stream(self._sideA)
+                    c ^= 1
+        torch.cuda.current_stream().wait_stream(main)
+        return g
+
+    def run(self, n: int, unroll: int = 8) -> torch.Tensor:
+        """n steps on the buffers as they are (steady-state measurement / identical consecutive batches): graphs of
+        ``unroll`` steps (one host call per ``unroll`` steps), then single steps for the remainder."""
+        unroll -= unroll % 2                                         # an even number of steps returns to the same buffer set
+        if unroll >= 2 and n >= unroll:
+            key = (self.cur, unroll)
+            if key not in self._many:
+                self._many[key] = self._capture(self.cur, unroll)
+            while n >= unroll:
+                self._many[key].replay()
+                n -= unroll
+        for _ in range(n):
+            self.step()
+        return self.out
+
+    def prime(self):
+        """Reduce + maps of batch 0 into the current buffer set (serial, outside the graph)."""
+        self._reduce(self.cur)
+        self._maps(self.cur, self.cur)
+
+    def prime2(self):
+        """Reduce of batch 1 into the current steps buffer (its maps are built by the first step)."""
+        self._reduce(self.cur)
+
+    def step(self) -> torch.Tensor:
+        self._graphs[self.cur].replay()
+        self.cur ^= 1
+        return self.out
+
+    def flush(self) -> torch.Tensor:
+        """Resample with the current maps alone."""
+        self._resample(self.cur)
+        return self.out

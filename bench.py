@@ -407,7 +407,26 @@ def main():
         result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), mode={args.mode}, eager launches",
                           "value": round(B2 * n2 / w4, 1), "unit": "images/s", "ms_per_step": round(w4 / n2 * 1e3, 4),
                           "stages_ms": [round(v, 4) for v in st2], "roofline": roofline_of(step2)}
-        del step2
+        # the same workload with the resample of batch k overlapped with reduce + maps of batch k+1 (one HIP graph with
+        # two branches, attwarp_amd.pipeline.OverlappedWarp): exactly n2 of each kernel inside the timed region
+        from attwarp_amd import pipeline as _pl
+        ow = _pl.OverlappedWarp(step2.img, step2.rows, step2.starts, channels_last=(args.layout == "hwc"), mode=args.mode)
+        for _ in range(args.warmup):
+            ow.prime(); ow.prime2(); ow.run(8); ow.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ow.prime()                               # reduce + maps of batch 0
+        ow.prime2()                              # reduce of batch 1
+        ow.run(n2 - 2)                           # R(k) || M(k+1) || A(k+2): graphs of 8 steps + single steps
+        ow._maps(ow.cur, 1 - ow.cur); ow.flush(); ow.cur ^= 1; ow.flush()     # tail: R(n-2), M(n-1), R(n-1)
+        torch.cuda.synchronize()
+        w5 = time.perf_counter() - t0
+        same = bool(torch.equal(ow.out, step2.out))
+        result["also_overlapped"] = {"workload": f"batch-{B2} {S2}x{S2}, resample(k) || maps(k+1) || reduce(k+2) as three branches of "
+                                                 f"one HIP graph (pipeline.OverlappedWarp), exactly {n2} of each kernel timed", "value": round(B2 * n2 / w5, 1),
+                                     "unit": "images/s", "ms_per_step": round(w5 / n2 * 1e3, 4),
+                                     "bit_identical_to_serial": same}
+        del step2, ow
 
     if rank == 0:
         print(json.dumps(result), flush=True)

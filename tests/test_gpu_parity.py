@@ -1621,3 +1621,30 @@ def test_remap_fuzz_shapes(dev):
         tag = (case, H, W, Ho, Wo, C, kind, dt.__name__, mode)
         assert np.array_equal(hwc, ref), tag
         assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), tag
+
+
+def test_overlapped_warp_equals_serial(dev):
+    """pipeline.OverlappedWarp (resample of batch k || maps of batch k+1 || attention reduce of batch k+2 as three
+    branches of one HIP graph): every step is bit-identical to warp_from_attention_stack on the batch it belongs to,
+    with the inputs refilled between steps per the documented protocol (attention runs two batches ahead)."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(21)
+    B, T, S, NB = 6, 4, 96, 5
+    imgs = [torch.rand((B, S, S, 3), device=dev, generator=g) for _ in range(NB)]
+    rws = [torch.softmax(torch.randn((T, B, 32, 640), device=dev, generator=g) * (1 + k), dim=-1) for k in range(NB)]
+    starts = (35 + torch.arange(B, device=dev) % 8).to(torch.int32)
+    refs = [pipeline.warp_from_attention_stack(imgs[k], rws[k], starts, channels_last=True) for k in range(NB)]
+    img, rows = imgs[0].clone(), rws[0].clone()
+    ow = pipeline.OverlappedWarp(img, rows, starts, channels_last=True)
+    rows.copy_(rws[0]); ow.prime()
+    rows.copy_(rws[1]); ow.prime2()
+    for k in range(NB):
+        img.copy_(imgs[k])
+        if k + 2 < NB:
+            rows.copy_(rws[k + 2])
+        out = ow.step()
+        assert torch.equal(out, refs[k]), k
+    # steady state on static buffers (what bench.py times): unrolled graphs == serial
+    ow2 = pipeline.OverlappedWarp(imgs[1], rws[1], starts, channels_last=True)
+    ow2.prime(); ow2.prime2()
+    assert torch.equal(ow2.run(19), refs[1])

@@ -1,5 +1,5 @@
-"""Dev tool: A/B two builds of libattwarp_hip.so on the float32 resample kernel (alternating subprocesses).
-usage: ab_remap.py libA.so libB.so"""
+"""Dev tool: A/B two builds of libattwarp_hip.so on the float32 resample kernel (alternating subprocesses on the
+same box).   usage: ab_remap.py libA.so libB.so"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if "--child" in sys.argv:
@@ -7,10 +7,12 @@ if "--child" in sys.argv:
     from attwarp_amd import _lib
     _lib.LIB_PATH = os.environ["AB_LIB"]
     import remap_bench as rb
-    print(os.path.basename(os.environ["AB_LIB"]), flush=True)
-    rb.bench(256, 1024, "hwc", "uniform")
-    rb.bench(256, 1024, "chw", "uniform")
-    rb.bench(64, 336, "hwc", "uniform", 50)
+    tag = os.path.basename(os.environ["AB_LIB"])
+    for mode in ("exact", "cv2"):
+        rb.bench(256, 1024, "hwc", "uniform", mode, tag=tag)
+        rb.bench(256, 1024, "chw", "uniform", mode, tag=tag)
+    rb.bench(256, 1024, "hwc", "peaked", "cv2", tag=tag)
+    rb.bench(64, 336, "hwc", "uniform", "cv2", 100, tag=tag)
 else:
     libs = [os.path.abspath(p) for p in sys.argv[1:3]]
     for rep in range(3):

@@ -1,52 +1,59 @@
-"""Turn gpurun_out/r1/ (written by tools/refresh_profiles.sh on the GPU box) into the committed summaries
-under profiles/: kernel-stats table, HBM traffic of the resample kernel from the PMC passes, bench lines."""
+"""Turn gpurun_out/<tag>/ (written by tools/refresh_profiles.sh on the GPU box) into the committed summaries
+under profiles/: kernel-stats table, HBM traffic of the resample kernel from the PMC passes (both arithmetic modes),
+bench lines, stage / chain benches.   usage: make_profiles.py [src_tag] [name]   (default r2 round2)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r1")
+src_tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
+SRC = os.path.join(ROOT, "gpurun_out", src_tag)
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
 
 def one(pattern):
     files = glob.glob(os.path.join(SRC, pattern), recursive=True)
     assert len(files) == 1, (pattern, files)
     return files[0]
 
-stats = one("trace/**/*kernel_stats.csv")
+stats = one("keep/trace/*kernel_stats.csv")
 shutil.copy(stats, os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
-prof_line = [l for l in open(os.path.join(SRC, "bench_profiled.json")) if l.startswith("{")][-1]
-prof = json.loads(prof_line)
+prof = json.loads([l for l in open(os.path.join(SRC, "bench_profiled.json")) if l.startswith("{")][-1])
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({tag}, final code)\n\n")
-    f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1/trace -- "
-            "python bench.py --no-cpu-baseline` (tools/refresh_profiles.sh)\n\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({tag})\n\n")
+    f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
+            "--no-cpu-baseline` (tools/refresh_profiles.sh).  The run measures, in this order: mode=cv2 HWC (main line), "
+            "mode=exact HWC, mode=cv2 CHW at B=256 1024x1024, then mode=cv2 at B=64 336x336; `remap_rows_kernel` rows are "
+            "per template instance (last template arguments: MODE 1 = cv2 / 0 = exact, SINGLE).\n\n")
     f.write("| kernel | calls | avg us | min us | max us | total ms | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
     for r in rows:
-        f.write(f"| `{r['Name'][:120]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
+        f.write(f"| `{r['Name'][:140]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                 f"{float(r['MaxNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |\n")
     f.write(f"\nbench.py's own HIP-event measurement in the same (profiled) process: ms_per_step {prof['ms_per_step']}, "
-            f"roofline {json.dumps(prof['roofline'])}, stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
+            f"roofline {json.dumps(prof['roofline'])}, also_exact {json.dumps(prof.get('also_exact', {}).get('roofline'))}, "
+            f"also_chw {json.dumps(prof.get('also_chw', {}).get('roofline'))}, stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
 
 def pmc(dirname, counter):
     vals = []
-    for r in csv.DictReader(open(one(f"{dirname}/**/*counter_collection.csv"))):
+    for r in csv.DictReader(open(one(f"keep/{dirname}/*counter_collection.csv"))):
         if "remap_rows_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
     return vals
-fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 B, S = 256, 1024
 alg = 2 * B * S * S * 3 * 4
-f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
-total = (2 * f_kb + w_kb) * 1024
-json.dump({"1024": {"remap_rows_kernel_bytes_per_launch": total, "ratio_to_algorithmic": total / alg,
-                    "FETCH_SIZE_KB_raw": f_kb, "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": min(len(fetch), len(write)),
-                    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py "
-                            "--no-cpu-baseline --no-also --steps 5`, mean over the launches of remap_rows_kernel; FETCH_SIZE "
-                            "doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}},
-          open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+traffic = {}
+for mode in ("cv2", "exact"):
+    fetch, write = pmc(f"pmc_fetch_{mode}", "FETCH_SIZE"), pmc(f"pmc_write_{mode}", "WRITE_SIZE")
+    f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+    total = (2 * f_kb + w_kb) * 1024
+    traffic[f"1024_{mode}"] = {
+        "remap_rows_kernel_bytes_per_launch": total, "ratio_to_algorithmic": total / alg, "FETCH_SIZE_KB_raw": f_kb,
+        "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": min(len(fetch), len(write)),
+        "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline "
+                f"--no-also --steps 5 --mode {mode}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
+                f"MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}
+    print(mode, "traffic ratio", total / alg)
+json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 bench_line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, f"{tag}_bench.json"), "w").write(bench_line)
-shutil.copy(os.path.join(SRC, "stage_bench.txt"), os.path.join(DST, f"{tag}_stage_bench.txt"))
-shutil.copy(os.path.join(SRC, "probe_bench.txt"), os.path.join(DST, f"{tag}_probe_bench.txt"))
+for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats"):
+    shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)
-print("traffic ratio", total / alg)

@@ -1,15 +1,30 @@
 #!/bin/bash
-# Run ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh): regenerates the raw material of profiles/
-# under gpurun_out/r1/.  tools/make_profiles.py turns it into the committed summaries.
+# Run ON THE GPU BOX (gpurun -- bash tools/refresh_profiles.sh [tag]): regenerates the raw material of profiles/
+# under gpurun_out/<tag>/.  tools/make_profiles.py turns it into the committed summaries.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/r1
+TAG=${1:-r2}
+OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 > /dev/null 2>&1
+for MODE in cv2 exact; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
+done
 python3 $ROOT/tools/stage_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/stage_bench.txt
+python3 $ROOT/tools/chain_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
 python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.txt
+python3 $ROOT/tools/remap_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_bench.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_trace -- python3 $ROOT/tools/chain_once.py 256 1024 500 > /dev/null 2>&1
+python3 $ROOT/tools/kstats.py $(find $OUT/chain_trace -name "*kernel_stats.csv" | head -1) > $OUT/chain_kernel_stats.txt
+# keep only the summaries (traces are large)
+for d in trace pmc_fetch_cv2 pmc_write_cv2 pmc_fetch_exact pmc_write_exact; do
+  mkdir -p $OUT/keep/$d
+  find $OUT/$d -name "*kernel_stats.csv" -exec cp {} $OUT/keep/$d/ \;
+  find $OUT/$d -name "*counter_collection.csv" -exec cp {} $OUT/keep/$d/ \;
+  rm -rf $OUT/$d
+done
+rm -rf $OUT/chain_trace
 cat $OUT/bench.json
