@@ -80,6 +80,16 @@ __device__ __forceinline__ float cv2_sum(float p00, float p01, float p10, float 
                                          float w11) {
   return fadd(fadd(fadd(fmul(p00, w00), fmul(p01, w01)), fmul(p10, w10)), fmul(p11, w11));
 }
+// The same sum with the (top, bottom) pairs as the two halves of packed float32 operations (v_pk_mul_f32 rounds each
+// half like v_mul_f32): weights (oy, fy) * ox and (oy, fy) * fx, products (p00, p10) * (w00, w10) and
+// (p01, p11) * (w01, w11), then the three ordered adds -- 7 VALU instructions instead of 11 per output.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cv2_sum_pk(v2f p0 /* p00, p10 */, v2f p1 /* p01, p11 */, v2f wy /* oy, fy */, float ox,
+                                            float fx) {
+  const v2f w0 = wy * ox, w1 = wy * fx;          // (w00, w10), (w01, w11)
+  const v2f s0 = p0 * w0, s1 = p1 * w1;          // (s00, s10), (s01, s11)
+  return fadd(fadd(fadd(s0.x, s1.x), s0.y), s1.y);
+}
 
 struct RowsParams {
   const float* src;
@@ -322,9 +332,11 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     const char* rowb = reinterpret_cast<const char*>(rowbuf);                                       \
     char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + yi_) * p.orow_len);               \
     const float fy_ = ty.f, oy_ = fsub(1.0f, ty.f);                                                 \
-    /* gather in two halves: the LDS reads of a half in flight, then their arithmetic + stores */   \
-    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                        \
-      constexpr int KH = (KO + 1) / 2;                                                              \
+    /* gather in parts (EXACT: 2, CV2: 3 -- four values per output live there): the LDS reads of  \
+       a part in flight, then their arithmetic + stores */                                          \
+    constexpr int NPART = CV ? 3 : 2;                                                               \
+    _Pragma("unroll") for (int half = 0; half < NPART; ++half) {                                    \
+      constexpr int KH = (KO + NPART - 1) / NPART;                                                  \
       float v0[KH], v1[KH], u0[CV ? KH : 1], u1[CV ? KH : 1];                                       \
       _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
         const int k = half * KH + kk;                                                               \
@@ -346,8 +358,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
           float o_;                                                                                 \
           if (CV) {                                                                                 \
             const float fx_ = fxr[k], ox_ = fsub(1.0f, fx_);                                        \
-            o_ = cv2_sum(v0[kk], v1[kk], u0[kk], u1[kk], fmul(oy_, ox_), fmul(oy_, fx_),            \
-                         fmul(fy_, ox_), fmul(fy_, fx_));                                           \
+            o_ = cv2_sum_pk(v2f{v0[kk], u0[kk]}, v2f{v1[kk], u1[kk]}, v2f{oy_, fy_}, ox_, fx_);     \
           } else {                                                                                  \
             o_ = ATTWARP_EXP_FLAG(4) ? v0[kk] : lerp_rn(v0[kk], v1[kk], fxr[k]);                    \
           }                                                                                         \

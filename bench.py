@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 T_STEPS, HEADS, KV, NTOK = 20, 32, 640, 576
 WORKLOADS = {"1024": (256, 1024, 2), "336": (64, 336, 1), "336x256": (256, 336, 3)}   # B per GPU, S, BASELINE config
+PREWARM_STEPS = 25             # untimed device pre-conditioning before the W warm-up steps (see main())
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -321,6 +322,12 @@ def main():
         del net
 
     step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
+    # device pre-conditioning, untimed and outside the contract's W warm-up steps: the first ~20 launches after start-up
+    # run 1-2 % slower (clock ramp; rocprofv3 shows their maxima 15 % above the mean), which would only penalise whichever
+    # measurement comes first.  The timed region below is still W warm-up steps + exactly K timed steps.
+    for _ in range(PREWARM_STEPS):
+        step()
+    torch.cuda.synchronize()
     wall, wall_local = time_steps(step, args.steps, args.warmup, D)
     per_rank = D.all_gather_counters({"images_per_s": B * args.steps / wall_local})
     ms_per_step = wall / args.steps * 1e3
@@ -340,6 +347,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "prewarm_steps": PREWARM_STEPS,
         "config": {"workload": f"batch-{B} {S}x{S}x3 float32 {args.layout.upper()} images per GPU + attention rows "
                                f"[T={T_STEPS},B,{HEADS},{KV}] float32 -> reduce -> 24x24 -> marginals -> CDF -> "
                                f"inverse maps -> bilinear warp, mode={args.mode} "
