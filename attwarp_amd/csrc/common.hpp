@@ -116,8 +116,9 @@ enum TuneKey {
   TUNE_REMAP_TILED,         // 0: rows wider than the LDS row take the generic kernel
   TUNE_REMAP_TILE_KO,       // 8 / 12
   TUNE_REMAP_ALT,           // 0: every row block sweeps top-down
-  TUNE_REMAP_NOSWZ,         // 1: no XCD-aware block order
+  TUNE_REMAP_NOSWZ,         // 0: contiguous range of row blocks per XCD, 1: plain order, g >= 2: XCDs interleaved in groups of g
   TUNE_REMAP_LDSPAD,        // extra dynamic LDS bytes (occupancy experiments)
+  TUNE_REMAP_NT,            // 0 / 1: nontemporal loads for block-private source rows
   TUNE_LANCZOS_VARIANT,     // 1: two-kernel form, 2: row-block fused kernel (default: column-strip kernel when it applies)
   TUNE_LANCZOS_ROWS,
   TUNE_CLIP_VARIANT,        // 1: generic kernels

@@ -65,6 +65,12 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   int R = (int)((24 * 1024 + row_bytes / 2) / row_bytes);
   R = R < 4 ? 4 : (R > 16 ? 16 : R);
   if (tiled) R = 8;
+  // Block order: a contiguous range of row blocks per XCD (group = 0).  Alternatives kept behind the test hook
+  // ("remap_noswz" = 1: plain order, g >= 2: XCDs interleaved in groups of g blocks; "remap_rows"; "remap_nt") were
+  // measured in round 2 and none is a win across boxes and shapes -- on boxes in the slow state R=3 with groups of 4
+  // gains 2-3.5 % at 1024x1024x3 but loses 5 % on peaked maps and 15 % at 768x768x3; nontemporal loads of block-private
+  // rows gain 3 % on boxes in the fast state and lose 1-2 % in the slow state.
+  int group = 0;
   if (const int v = tune(TUNE_REMAP_ROWS); v >= 1 && v <= RMAX) R = v;
   if (R > Ho) R = Ho;
   p.R = R;
@@ -73,9 +79,11 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   p.alt_dir = tune(TUNE_REMAP_ALT) != 0;
-  p.no_swz = tune(TUNE_REMAP_NOSWZ) == 1;
+  p.no_swz = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : group;
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
+  // nontemporal loads for block-private rows: measurement option only (see remap_rows_kernel.hpp)
+  p.nt_loads = tune(TUNE_REMAP_NT) == 1;
   *handled = true;
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)

@@ -32,14 +32,27 @@
 // contents), bit 1 = stores only for values that never occur.  Splits the kernel time into its read and write sides.
 #ifdef ATTWARP_EXPERIMENT
 #define ATTWARP_EXP_LOAD(X, rp_)                                                                                   \
-  if (!(p.lds_pad & 1)) { _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
+  if (!(p.lds_pad & 1)) { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
 #define ATTWARP_EXP_STORE(ptr_, v_)                                                                                \
   if (!(p.lds_pad & 2) || (v_) == -12345.678f) *reinterpret_cast<float*>(ptr_) = (v_)
 #define ATTWARP_EXP_FLAG(b) (p.lds_pad & (b))
 #else
 #define ATTWARP_EXP_FLAG(b) false
-#define ATTWARP_EXP_LOAD(X, rp_) \
-  _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);
+// Measurement option (p.nt_loads, test hook "remap_nt"): source rows a block shares with a neighbour (its first and
+// last needed row: the neighbour's halo) are read with plain loads, rows only this block reads NONTEMPORAL.  Same-box
+// alternating runs, 1024x1024x3 float32 B=256: on boxes in the fast state EXACT 1.073 -> 1.040 ms, CV2 1.088 -> 1.060,
+// CV2 CHW 1.102 -> 1.051; on boxes in the slow state +1-2 % slower at every batch size, and -15 % on a batch that fits
+// the Infinity Cache (B=64 336x336).  Nontemporal loads for ALL rows (the halo then misses): never a gain.  Off by default.
+typedef float rows_v4f __attribute__((ext_vector_type(4)));
+#define ATTWARP_EXP_LOAD(X, rp_)                                                                                    \
+  if (p.nt_loads && srow_ != row_lo && srow_ != row_hi) {                                                           \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                                 \
+      const rows_v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k]));             \
+      X[k] = make_float4(t_.x, t_.y, t_.z, t_.w);                                                                   \
+    }                                                                                                               \
+  } else {                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);           \
+  }
 #define ATTWARP_EXP_STORE(ptr_, v_) *reinterpret_cast<float*>(ptr_) = (v_)
 #endif
 
@@ -107,10 +120,11 @@ struct RowsParams {
   int nblk;          // blocks per image
   int nblocks;       // total
   int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
-  int no_swz;        // 1: disable the XCD-aware block order (experiments)
+  int no_swz;        // block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g blocks
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
+  int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads (large streaming batches)
 };
 
 constexpr int RMAX = 64;
@@ -153,7 +167,15 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   int bid = blockIdx.x;
   {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    if (!p.no_swz) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    if (p.no_swz == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    else if (p.no_swz >= 2) {
+      // XCD x owns every 8th GROUP of g consecutive row blocks (g = no_swz): neighbouring blocks of a group still share
+      // an L2 (halo hits for g-1 of g seams), while the eight XCDs work in one compact window of memory
+      const int g = p.no_swz, per = 8 * g;
+      const int grp = idx / g, within = idx - grp * g;
+      const int cand = grp * per + xcd * g + within;
+      bid = cand < (n / per) * per ? cand : bid;          // the ragged tail keeps the plain order
+    }
   }
   int b, rb, tile = 0;
   if (TILED) {          // (image, tile, row block): row blocks of one tile stay neighbours (halo rows meet in L2)
@@ -269,10 +291,14 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
 
   float4 X0[KI], X1[KI];
   int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
+  // the two rows this block shares with its neighbours (valid for the monotone maps of the path; for arbitrary maps
+  // they are just two rows that stay cacheable)
+  const int row_lo = rtaps<MODE>(s_my[0], p.H).i0, row_hi = rtaps<MODE>(s_my[nrows - 1], p.H).i1;
   // (macros, not lambdas: the register sets must stay scalar-replaced, never addressed through a pointer)
 #define ATTWARP_LOAD_ROW(X, srow)                                                                   \
   do {                                                                                              \
-    const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)(srow) * p.row_len);         \
+    const int srow_ = (srow);                                                                       \
+    const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)srow_ * p.row_len);          \
     ATTWARP_EXP_LOAD(X, rp_)                                                                        \
   } while (0)
   // EXACT: the vertical lerp of (XA, XC) into the row buffer; CV2: XA, then XC one row further

@@ -8,14 +8,13 @@ if "--child" in sys.argv:
     _lib.LIB_PATH = os.environ["AB_LIB"]
     import remap_bench as rb
     tag = os.path.basename(os.environ["AB_LIB"])
-    import time
-    for mode in ("cv2",):
-        for rep in range(3):
+    for rep in range(2):
+        for mode in ("cv2", "exact"):
             rb.bench(256, 1024, "hwc", "uniform", mode, tag=tag)
     rb.bench(256, 1024, "chw", "uniform", "cv2", tag=tag)
     rb.bench(256, 1024, "hwc", "peaked", "cv2", tag=tag)
-    rb.bench(64, 336, "hwc", "uniform", "cv2", 100, tag=tag)
-    time.sleep(3)
+    rb.bench(64, 1024, "hwc", "uniform", "cv2", tag=tag)
+    rb.bench(256, 768, "hwc", "uniform", "cv2", tag=tag)
 else:
     libs = [os.path.abspath(p) for p in sys.argv[1:3]]
     for rep in range(4):

@@ -11,6 +11,8 @@ px = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * sc, 1)
 py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * sc, 1)
 mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
 img = torch.rand((B, S, S, 3), device=dev); out = torch.empty_like(img)
-for _ in range(5):
-    cu.remap_separable(img, mx, my, channels_last=True, out=out)
+from attwarp_amd import _lib
+with _lib.debug_override(remap_noswz=int("noswz" in sys.argv)):
+    for _ in range(5):
+        cu.remap_separable(img, mx, my, channels_last=True, out=out)
 torch.cuda.synchronize()
