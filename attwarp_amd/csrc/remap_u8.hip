@@ -322,6 +322,175 @@ static int launch_ko(const Params& p, hipStream_t st) {
   }
 }
 
+// ---- CV2 mode, integer form (rows of <= 4096 bytes) ----------------------------------------------------------------
+// OpenCV's uint8 path is exact integer arithmetic (see the header of this file), so it does not need the float
+// pipeline above.  This kernel keeps the same decomposition (workgroup = R output rows of one image, vertical pass
+// into LDS, horizontal gather) but
+//   * vertical: a thread owns dwords of the two source rows; bytes (0,2) and (1,3) of a dword are two packed 16-bit
+//     pairs, v = (32-ky)*top + ky*bottom <= 8160 is one v_pk_mul_lo_u16 + one v_pk_mad_u16 per pair -- 10 VALU
+//     instructions per 4 source bytes (the float form: 4 + 4 conversions and 12 lerp operations) -- and the LDS row holds
+//     16-bit values (half the LDS bytes), in the order [e0, e2, e1, e3] per group of 4 (no re-interleaving: the tap
+//     offsets know the order);
+//   * horizontal: a lane produces 4 CONSECUTIVE output bytes: 8 ds_read_u16, per byte
+//     ((v0 << 5) + 512 + kx*(v1 - v0)) >> 10, packed and stored as one dword -- no LDS output row, no flush pass;
+//     tap 1 is always "tap 0's pixel + 1" with kx forced to 0 where OpenCV clamps both taps to the same pixel (integer
+//     arithmetic: a zero weight is exact), so the clamped cases need no second offset logic.
+// Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
+template <int KI, int KD, bool HWC>
+__global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* s_my = smem;                                               // RMAX
+  const int VLP = ((p.VL + 7) & ~7) + 8;                            // u16 elements per LDS row (+ one pixel of slack)
+  uint16_t* vrow0 = reinterpret_cast<uint16_t*>(smem + RMAX);
+  uint16_t* vrow1 = vrow0 + VLP;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  {
+    const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+  }
+  const int b = bid / p.nblk, rb = bid - b * p.nblk;
+  const int y0 = rb * p.R;
+  const int nrows = min(y0 + p.R, p.Ho) - y0;
+  const uint8_t* src_b = p.src + (long long)b * p.img_stride;
+  uint8_t* dst_b = p.dst + (long long)b * p.oimg_stride;
+  if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
+
+  // source dwords this thread owns (clamped: padding lanes repeat the last dword)
+  int goff[KI], voff[KI];           // byte offset inside the image (row 0) / u16 index in the LDS row
+  {
+    const int dpr = p.row_len >> 2, nd = p.VL >> 2;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) {
+      const int d = min(tid + NT * k, nd - 1);
+      const int pl = HWC ? 0 : d / dpr;
+      goff[k] = (int)(pl * p.plane_stride) + 4 * (d - pl * dpr);
+      voff[k] = 4 * d;
+    }
+  }
+  // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
+  // order) and kx
+  unsigned t0[KD][4], t1[KD][4], kxp[KD];
+  int soff[KD];
+  {
+    const int dpo = p.orow_len >> 2, ndo = p.OVL >> 2;
+    auto lds_off = [](unsigned e) -> unsigned { return 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
+#pragma unroll
+    for (int k = 0; k < KD; ++k) {
+      const int d = min(tid + NT * k, ndo - 1);
+      const int pl = HWC ? 0 : d / dpo;
+      const int r0 = 4 * (d - pl * dpo);                            // first byte of the dword inside its plane row
+      soff[k] = (int)(pl * p.oplane_stride) + r0;
+      unsigned kp = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = r0 + j, x = r / p.CS, c = r - x * p.CS;
+        const float m = p.mx[(long long)b * p.Wo + x];
+        const float sc = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
+        const int q = __float2int_rn(sc);                           // cvRound
+        const int i = q >> 5;
+        const int i0 = min(max(i, 0), p.W - 1), i1 = min(max(i + 1, 0), p.W - 1);
+        const unsigned kx = (i0 == i1) ? 0u : (unsigned)(q & 31);  // both taps on one pixel: weight of tap 1 is moot
+        const unsigned e0 = (unsigned)(pl * p.row_len + i0 * p.CS + c);
+        const unsigned e1 = (i0 == i1) ? e0 : (unsigned)(pl * p.row_len + i1 * p.CS + c);
+        t0[k][j] = lds_off(e0);
+        t1[k][j] = lds_off(e1);
+        kp |= kx << (8 * j);
+      }
+      kxp[k] = kp;
+    }
+  }
+  __syncthreads();
+
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  auto row_taps = [&](float m, int& i0, int& i1, unsigned& ky) {
+    const float sc = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
+    const int q = __float2int_rn(sc);
+    const int i = q >> 5;
+    i0 = min(max(i, 0), p.H - 1);
+    i1 = min(max(i + 1, 0), p.H - 1);
+    ky = (unsigned)(q & 31);
+  };
+  int ci0, ci1;
+  unsigned cky;
+  row_taps(s_my[0], ci0, ci1, cky);
+  uint32_t A[KI], C[KI];
+#define ATTWARP_U8I_FETCH()                                                                            \
+  _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                      \
+    A[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)ci0 * p.row_len + goff[k]);            \
+    C[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)ci1 * p.row_len + goff[k]);            \
+  }
+#define ATTWARP_U8I_ROW(q_, vbuf)                                                                      \
+  {                                                                                                    \
+    const unsigned w1_ = cky, w0_ = 32u - cky;                                                         \
+    const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
+      const uint32_t a02_ = A[k] & 0x00ff00ffu, a13_ = (A[k] >> 8) & 0x00ff00ffu;                        \
+      const uint32_t c02_ = C[k] & 0x00ff00ffu, c13_ = (C[k] >> 8) & 0x00ff00ffu;                        \
+      const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
+      const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
+      uint2 st_;                                                                                       \
+      st_.x = __builtin_bit_cast(uint32_t, v02_);                                                      \
+      st_.y = __builtin_bit_cast(uint32_t, v13_);                                                      \
+      *reinterpret_cast<uint2*>((vbuf) + voff[k]) = st_;                                               \
+    }                                                                                                  \
+    if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
+      row_taps(s_my[(q_) + 1], ci0, ci1, cky);                                                         \
+      ATTWARP_U8I_FETCH()                                                                              \
+    }                                                                                                  \
+    __syncthreads();                                                                                   \
+    const char* vb_ = reinterpret_cast<const char*>(vbuf);                                             \
+    uint8_t* orow_ = dst_b + (long long)(y0 + (q_)) * p.orow_len;                                       \
+    _Pragma("unroll") for (int k = 0; k < KD; ++k) {                                                    \
+      unsigned v0_[4], v1_[4];                                                                         \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+        v0_[j] = *reinterpret_cast<const uint16_t*>(vb_ + t0[k][j]);                                   \
+        v1_[j] = *reinterpret_cast<const uint16_t*>(vb_ + t1[k][j]);                                   \
+      }                                                                                                \
+      unsigned o_ = 0;                                                                                 \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+        const int kx_ = (int)((kxp[k] >> (8 * j)) & 0xffu);                                            \
+        const int in_ = (int)(v0_[j] << 5) + 512 + __mul24(kx_, (int)v1_[j] - (int)v0_[j]);            \
+        o_ |= ((unsigned)in_ >> 10) << (8 * j);                                                        \
+      }                                                                                                \
+      if (tid + NT * k < (p.OVL >> 2)) *reinterpret_cast<uint32_t*>(orow_ + soff[k]) = o_;             \
+    }                                                                                                  \
+  }
+  ATTWARP_U8I_FETCH()
+  int q = 0;
+  for (; q + 1 < nrows; q += 2) {
+    ATTWARP_U8I_ROW(q, vrow0)
+    ATTWARP_U8I_ROW(q + 1, vrow1)
+  }
+  if (q < nrows) ATTWARP_U8I_ROW(q, vrow0)
+#undef ATTWARP_U8I_ROW
+#undef ATTWARP_U8I_FETCH
+}
+
+template <int KI>
+static int launch_u8i_ki(const Params& p, hipStream_t st) {
+  const int VLP = ((p.VL + 7) & ~7) + 8;
+  const size_t lds = (size_t)RMAX * sizeof(float) + 2 * (size_t)VLP * sizeof(uint16_t);
+  const int kd = ((p.OVL >> 2) + NT - 1) / NT;
+  const dim3 g(p.nblocks), t(NT);
+#define ATTWARP_U8I_LAUNCH(KD)                                                                              \
+  if (p.NP == 1) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true>), g, t, lds, st, p);                \
+  else hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, false>), g, t, lds, st, p)
+  if (kd <= 1) { ATTWARP_U8I_LAUNCH(1); } else if (kd == 2) { ATTWARP_U8I_LAUNCH(2); }
+  else if (kd == 3) { ATTWARP_U8I_LAUNCH(3); } else { ATTWARP_U8I_LAUNCH(4); }
+#undef ATTWARP_U8I_LAUNCH
+  return check_launch("remap_rows_u8i_kernel");
+}
+static int launch_u8i(const Params& p, hipStream_t st) {
+  const int ki = ((p.VL >> 2) + NT - 1) / NT;
+  switch (ki) {
+    case 1: return launch_u8i_ki<1>(p, st);
+    case 2: return launch_u8i_ki<2>(p, st);
+    case 3: return launch_u8i_ki<3>(p, st);
+    default: return launch_u8i_ki<4>(p, st);
+  }
+}
+
 template <int MODE>
 static int launch_mode(const Params& p, bool tiled, hipStream_t st) {
   constexpr int TILE_KO = 8, TILE_KI = 3;      // 2048 output bytes per tile against 3072 staged source bytes
@@ -394,6 +563,7 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   *handled = true;
+  if (mode == ATTWARP_CV2 && !tiled && tune(TUNE_REMAP_VARIANT) != 2) return u8k::launch_u8i(p, st);   // integer form
   if (mode == ATTWARP_CV2) return u8k::launch_mode<ATTWARP_CV2>(p, tiled, st);
   return u8k::launch_mode<ATTWARP_EXACT>(p, tiled, st);
 }

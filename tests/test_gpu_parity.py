@@ -1465,6 +1465,37 @@ def test_shard_equivalence(dev, world):
     assert torch.equal(torch.cat(parts), full)
 
 
+def test_config3_batch2048_shards_at_full_size(dev):
+    """BASELINE configs[3] at its stated size on one GPU: 2048 float32 336x336 images with their attention stacks
+    (T=20, 32 heads, kv=640), cut into the 8 contiguous per-rank blocks of 256 that `bench.py --gpus 8 --workload
+    336x256` gives every rank.  Each block through the whole path equals the same rows of the unsharded run byte for
+    byte, and a few images equal the CPU oracle."""
+    from attwarp_amd import pipeline
+    from attwarp_amd.dist import shard_range
+    B, T_, S, world = 2048, 20, 336, 8
+    g = torch.Generator(device=dev).manual_seed(2048)
+    img = torch.rand((B, S, S, 3), device=dev, generator=g)
+    rows = torch.empty((T_, B, 32, 640), device=dev)
+    for t in range(T_):
+        rows[t] = torch.softmax(torch.randn((B, 32, 640), device=dev, generator=g), dim=-1)
+    starts = (35 + torch.arange(B, device=dev) % 8).to(torch.int32)
+    full = pipeline.warp_from_attention_stack(img, rows, starts, channels_last=True)
+    for r in range(world):
+        lo, hi = shard_range(B, r, world)
+        assert hi - lo == 256
+        part = pipeline.warp_from_attention_stack(img[lo:hi], rows[:, lo:hi].contiguous(), starts[lo:hi].contiguous(),
+                                                  channels_last=True)
+        assert torch.equal(part, full[lo:hi]), r
+    for b in (0, 1023, 2047):
+        r_np = N(rows[:, b:b + 1])
+        att = O.attn_reduce_stack(r_np, [int(starts[b])]).reshape(1, 1, 24, 24)
+        px, py = O.gt_marginals(att)
+        Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, S), 0))
+        Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, S), 0))
+        mx, my = O.maps_from_cdf(Fx, Fy)
+        assert np.array_equal(N(full[b]), O.remap_bilinear(N(img[b]), mx[0], my[0])), b
+
+
 @pytest.mark.parametrize("name", ["sq500", "sq336", "land", "small"])
 def test_clip_preprocess_bit_exact(dev, golden, name):
     """"next" row 3: warped uint8 image -> CLIP tensor on the GPU == HF CLIPImageProcessor (PIL backend)."""
