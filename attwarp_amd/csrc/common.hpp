@@ -110,7 +110,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // attwarp_debug_set() (include/attwarp.h), which stores into this table of relaxed atomics.  -1 = automatic.
 // No environment variable is ever read by the library.
 enum TuneKey {
-  TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only
+  TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only; 2: uint8 cv2 on the float-pipeline rows kernel (not the integer form)
   TUNE_REMAP_ROWS,          // output rows per workgroup (1..64)
   TUNE_REMAP_CHW_SPLIT,     // 0 / 1: planar images plane by plane
   TUNE_REMAP_TILED,         // 0: rows wider than the LDS row take the generic kernel

@@ -728,8 +728,10 @@ def test_remap_all_modes_layouts_dtypes(dev, shape, kind, mode):
         if dt == np.uint8:
             img = (img * 255).astype(np.uint8)
         ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
-        for variant in ("rows", "gather"):
-            with _lib.debug_override(remap_variant=int(variant == "gather")):
+        # "rows": the staged kernels (uint8 cv2: the integer form); "rows-float": uint8 cv2 on the float-pipeline form;
+        # "gather": the generic kernel
+        for variant in ("rows", "gather", "rows-float"):
+            with _lib.debug_override(remap_variant={"rows": -1, "gather": 1, "rows-float": 2}[variant]):
                 hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
                 chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode=mode))
             assert np.array_equal(hwc, ref), (dt.__name__, variant, "hwc")
