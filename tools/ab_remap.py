@@ -9,14 +9,18 @@ if "--child" in sys.argv:
     import remap_bench as rb
     tag = os.path.basename(os.environ["AB_LIB"])
     for rep in range(2):
-        for mode in ("cv2", "exact"):
-            rb.bench(256, 1024, "hwc", "uniform", mode, tag=tag)
-    rb.bench(256, 1024, "chw", "uniform", "cv2", tag=tag)
-    rb.bench(256, 1024, "hwc", "peaked", "cv2", tag=tag)
-    rb.bench(64, 1024, "hwc", "uniform", "cv2", tag=tag)
-    rb.bench(256, 768, "hwc", "uniform", "cv2", tag=tag)
+        rb.bench(256, 1024, "chw", "uniform", "cv2", tag=tag)
+        rb.bench(256, 1024, "chw", "uniform", "exact", tag=tag)
+        rb.bench(64, 336, "hwc", "uniform", "cv2", 100, tag=tag)
+        rb.bench(256, 336, "hwc", "uniform", "cv2", 50, tag=tag)
+        rb.bench(256, 336, "hwc", "uniform", "exact", 50, tag=tag)
+        rb.bench(256, 336, "chw", "uniform", "cv2", 50, tag=tag)
+    rb.bench(256, 512, "hwc", "uniform", "cv2", 50, tag=tag)
+    rb.bench(256, 336, "hwc", "peaked", "cv2", 50, tag=tag)
+    rb.bench(256, 1024, "chw", "peaked", "cv2", tag=tag)
+    rb.bench(256, 1024, "hwc", "uniform", "cv2", tag=tag)
 else:
     libs = [os.path.abspath(p) for p in sys.argv[1:3]]
-    for rep in range(4):
+    for rep in range(3):
         for lib in libs:
             subprocess.run([sys.executable, __file__, "--child"], env=dict(os.environ, AB_LIB=lib))
