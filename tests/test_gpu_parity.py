@@ -738,6 +738,28 @@ def test_remap_all_modes_layouts_dtypes(dev, shape, kind, mode):
             assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (dt.__name__, variant, "chw")
 
 
+@pytest.mark.parametrize("shape", [(26, 1024, 18, 1024, 4), (24, 1364, 20, 1000, 3), (25, 340, 30, 1364, 3),
+                                   (24, 2048, 11, 2048, 2), (27, 4096, 7, 4096, 1), (30, 700, 9, 256, 3)])
+@pytest.mark.parametrize("kind", ["cdf", "wild"])
+def test_remap_uint8_cv2_integer_kernel_wide_rows(dev, shape, kind):
+    """The integer-arithmetic uint8 cv2 kernel at every (source dwords, output dwords) per-thread count up to its
+    4096-byte row limit, interleaved and planar: equal to the oracle, to the float-pipeline form and to the gather
+    kernel bit for bit."""
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C = shape
+    rng = np.random.default_rng(H * 7 + W + Wo)
+    B = 2
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], "cv2") for b in range(B)])
+    for variant in (-1, 2, 1):
+        with _lib.debug_override(remap_variant=variant):
+            hwc = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode="cv2", channels_last=True))
+            chw = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode="cv2"))
+        assert np.array_equal(hwc, ref), (variant, "hwc")
+        assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (variant, "chw")
+
+
 @pytest.mark.parametrize("C", [1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["cdf", "wild", "identity"])
 def test_remap_cv2_staged_channels_and_edges(dev, C, kind):
