@@ -69,8 +69,15 @@ def launch_ranks(n: int, argv) -> int:
                    MASTER_PORT=port, ATTWARP_BENCH_CHILD="1")
         out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
-    line0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    try:
+        line0, _ = procs[0].communicate(timeout=float(os.environ.get("ATTWARP_BENCH_TIMEOUT_S", "3000")))
+        rcs = [procs[0].returncode] + [p.wait(timeout=120) for p in procs[1:]]
+    except subprocess.TimeoutExpired:
+        print("[bench] ranks did not finish in time; terminating them", file=sys.stderr)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()                         # the exact PIDs this parent started
+        return 1
     if any(rcs):
         print(f"[bench] rank exit codes {rcs}: at least one rank failed", file=sys.stderr)
         for p in procs:
