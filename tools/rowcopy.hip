@@ -39,6 +39,25 @@ __global__ __launch_bounds__(256) void rowcopy(const float4* __restrict__ src, f
     }
   }
 }
+// the resample kernel's block orders: mode 0 = contiguous range of row blocks per XCD, g >= 2 = XCDs interleaved in groups of g
+__global__ __launch_bounds__(256) void rowcopy_swz(const float4* __restrict__ src, float4* __restrict__ dst, int nrows, int R, int nblocks, int g) {
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  {
+    const int n = nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    if (g == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    else if (g >= 2) { const int per = 8 * g, grp = idx / g, within = idx - grp * g, cand = grp * per + xcd * g + within; bid = cand < (n / per) * per ? cand : bid; }
+  }
+  const long long row0 = (long long)bid * R;
+  for (int r = 0; r < R; ++r) {
+    const long long row = row0 + r;
+    if (row >= nrows) break;
+    const float4* s = src + row * 768;
+    float4* d = dst + row * 768;
+    const float4 a = s[tid], b = s[tid + 256], c = s[tid + 512];
+    d[tid] = a; d[tid + 256] = b; d[tid + 512] = c;
+  }
+}
 template <int VPT, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void flatcopy(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -88,6 +107,19 @@ int main() {
       std::sort(ts.begin(), ts.end());
       const char* names[4] = {"plain float4", "dword stores", "nt loads    ", "nt ld + st  "};
       printf("mode=%s R=%3d: %.4f ms  %.2f TB/s\n", names[mode], R, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
+    }
+  for (int g : {0, 1, 4})
+    for (int R : {3, 4, 8}) {
+      std::vector<float> ts;
+      const int grid = (int)((nrows + R - 1) / R);
+      for (int it = 0; it < 12; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(rowcopy_swz, dim3(grid), dim3(256), 0, 0, src, dst, (int)nrows, R, grid, g);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+      }
+      std::sort(ts.begin(), ts.end());
+      printf("rowcopy order=%s R=%d: %.4f ms  %.2f TB/s\n", g == 0 ? "xcd-contiguous" : (g == 1 ? "plain" : "groups-of-4"), R, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
     }
   run_flat<4, false, false>(src, dst, bytes, e0, e1);
   run_flat<4, true, false>(src, dst, bytes, e0, e1);
