@@ -15,8 +15,14 @@ namespace attwarp {
 constexpr int NT = 256;
 
 // ---- element transform applied while summing -------------------------------------------
+// max(v, 0) that propagates NaN, on a float (3 float32 instructions instead of 6 float64-pair ones)
+__device__ __forceinline__ float clamp_pos_f32(float v) {
+  const float c = fmaxf(v, 0.0f);
+  return (v != v) ? v : c;
+}
 struct XfClampPos {  // gt_marginals: A.clamp_min(0)
   __device__ __forceinline__ double operator()(double v) const { return (v != v) ? v : (v > 0.0 ? v : 0.0); }  // NaN propagates
+  __device__ __forceinline__ double from_f32(float v) const { return (double)clamp_pos_f32(v); }
 };
 template <int TR>
 struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION   (TR = ATTWARP_T_*, compile time)
@@ -25,6 +31,15 @@ struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION
     double a = (v != v) ? v : (v > 0.0 ? v : 0.0);       // np.maximum(x, 0) propagates NaN
     if (TR == ATTWARP_T_SQUARE) a = a * a;
     else if (TR == ATTWARP_T_SQRT) a = sqrt(a);            // a >= 0 or NaN here
+    else if (TR == ATTWARP_T_EXP) a = exp(exp_scale * a) / exp_divisor;
+    else if (TR == ATTWARP_T_LOG) a = log(a + 1e-5);
+    return a + 1e-9;
+  }
+  // float32 input: the clamp on the float (exact), the rest as above
+  __device__ __forceinline__ double from_f32(float v) const {
+    double a = (double)clamp_pos_f32(v);
+    if (TR == ATTWARP_T_SQUARE) a = a * a;
+    else if (TR == ATTWARP_T_SQRT) a = sqrt(a);
     else if (TR == ATTWARP_T_EXP) a = exp(exp_scale * a) / exp_divisor;
     else if (TR == ATTWARP_T_LOG) a = log(a + 1e-5);
     return a + 1e-9;
@@ -392,6 +407,101 @@ static int launch_profiles_u8(const void* A, int B, int H, int W, XfAttention<TR
   return check_launch("profiles_u8_kernel");
 }
 
+// ---- float32 input with a cheap transform (gt_marginals' clamp; identity / square attention) --------------------
+// profiles_kernel<float, XF> keeps a band of TRANSFORMED doubles in LDS (8 bytes per element written once and read
+// twice) and reached 3.6 TB/s = 0.45 of the HBM peak on B=256 x 1024 x 1024 (profiles/round2_stage_bench.txt).  Same
+// outputs and summation orders here with the profiles_u8_kernel structure: LDS holds the RAW floats of a band of 64
+// rows x the leaf's <= 128 columns (one buffer, the next band waits in registers: 128 bytes per lane in flight), the
+// transform runs in registers where a value is consumed, waves 0-1 own the row sums ((row, half): 16 x ds_read_b128,
+// four float64 chains, one xor-1 shuffle), waves 2-3 the column sums (ascending rows).  Row stride 136 dwords: the 16
+// lanes of a ds_read_b128 phase (8 rows x 2 halves) cover all 64 banks.  Requires W % 4 == 0, a 16-byte aligned
+// base and every leaf >= 8 long and a multiple of 4.
+constexpr int F32_RB = 64;
+constexpr int F32_STR = 128 + 8;       // dwords
+
+template <typename XF>
+__global__ __launch_bounds__(NT) void profiles_f32_kernel(const float* __restrict__ A, int H, int W, XF xf,
+                                                          const PairwisePlan P, double* __restrict__ col,
+                                                          double* __restrict__ ls) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float tile[F32_RB * F32_STR];
+  const int tid = threadIdx.x, b = blockIdx.y, leaf = blockIdx.x;
+  const int coff = P.off[leaf], len = P.len[leaf], nleaves = P.nleaves;
+  const int m = len >> 3;                                          // steps of the stride-8 accumulators
+  const float* base = A + (size_t)b * H * W + coff;
+  const int gq = tid & 31, gr = tid >> 5;                          // this thread's quad / first row of a band
+  const int nq = len >> 2;
+  constexpr int NPASS = F32_RB / 8;
+  v4f raw[NPASS];
+#define ATTWARP_F32P_FETCH(row0_)                                                                \
+  _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                          \
+    const int r_ = (row0_) + gr + 8 * ps;                                                        \
+    if (r_ < H && gq < nq) raw[ps] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(base + (size_t)r_ * W) + gq); \
+  }
+  ATTWARP_F32P_FETCH(0)
+  double cacc = 0.0;
+  for (int row0 = 0; row0 < H; row0 += F32_RB) {
+    const int nb = min(F32_RB, H - row0);
+    if (gq < nq) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) reinterpret_cast<v4f*>(tile + (gr + 8 * ps) * F32_STR)[gq] = raw[ps];
+    }
+    __syncthreads();
+    if (row0 + F32_RB < H) ATTWARP_F32P_FETCH(row0 + F32_RB)
+    if (tid < 2 * F32_RB) {
+      // ---- rows (waves 0-1): thread = (row, half) ----
+      const int r = tid >> 1, hh = tid & 1;
+      const float* rp = tile + r * F32_STR + 4 * hh;
+      v4f wv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i] = *reinterpret_cast<const v4f*>(rp + 8 * i);   // in-row reads past the leaf: unused
+      double a0 = xf.from_f32(wv[0].x), a1 = xf.from_f32(wv[0].y), a2 = xf.from_f32(wv[0].z), a3 = xf.from_f32(wv[0].w);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) {
+        if (i < m) {                                               // block uniform
+          a0 += xf.from_f32(wv[i].x); a1 += xf.from_f32(wv[i].y); a2 += xf.from_f32(wv[i].z); a3 += xf.from_f32(wv[i].w);
+        }
+      }
+      double u = (a0 + a1) + (a2 + a3);
+      u = u + __shfl_xor(u, 1, WAVE);                              // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+      if (hh == 0 && r < nb) {
+        const float* tp = tile + r * F32_STR;
+        for (int i = 8 * m; i < len; ++i) u += xf.from_f32(tp[i]);
+        ls[((size_t)b * H + row0 + r) * nleaves + leaf] = u;
+      }
+    } else if (tid - 2 * F32_RB < len) {
+      // ---- columns (waves 2-3): ascending rows ----
+      const float* cp = tile + (tid - 2 * F32_RB);
+      for (int r0 = 0; r0 < nb; r0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = cp[(r0 + i) * F32_STR];   // rows >= nb of a partial band: stale, unused
+        if (r0 + 16 <= nb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) cacc = cacc + xf.from_f32(v[i]);
+        } else {
+          for (int i = 0; i < nb - r0; ++i) cacc = cacc + xf.from_f32(v[i]);
+        }
+      }
+    }
+    __syncthreads();                                               // the tile is rewritten by the next band
+  }
+#undef ATTWARP_F32P_FETCH
+  if (tid >= 2 * F32_RB && tid - 2 * F32_RB < len) col[(size_t)b * W + coff + tid - 2 * F32_RB] = cacc;
+}
+
+template <typename XF>
+static int launch_profiles_f32(const void* A, int B, int H, int W, XF xf, const PairwisePlan& P, double* col, double* ls,
+                               hipStream_t st, bool* handled) {
+  *handled = false;
+  if (tune(TUNE_PROFILES_VARIANT) == 1 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 15u) != 0) return ATTWARP_OK;
+  for (int j = 0; j < P.nleaves; ++j)
+    if (P.len[j] < 8 || P.len[j] % 4 != 0) return ATTWARP_OK;
+  *handled = true;
+  hipLaunchKernelGGL((profiles_f32_kernel<XF>), dim3(P.nleaves, B), dim3(NT), 0, st, (const float*)A, H, W, xf, P, col, ls);
+  return check_launch("profiles_f32_kernel");
+}
+
 // ---- A6 finalize: normalise a marginal.  grid = (B, 2) ----------------------------------
 __global__ __launch_bounds__(NT) void marginals_finalize_kernel(const double* __restrict__ col,
                                                                 const double* __restrict__ ls, int nleaves, int H,
@@ -415,18 +525,42 @@ __global__ __launch_bounds__(NT) void marginals_finalize_kernel(const double* __
     smem_d[k] = v;
     acc += (double)(float)v;
   }
-  const float tot = fmaxf((float)block_sum(acc, red), 1e-6f);
+  const float tsum = (float)block_sum(acc, red);
+  const float tot = (tsum != tsum) ? tsum : fmaxf(tsum, 1e-6f);       // torch's clamp_min propagates NaN (fmaxf drops it)
   for (int k = threadIdx.x; k < n; k += blockDim.x) dst[k] = (float)smem_d[k] / tot;
 }
 
 // ---- A5: adaptive average pool.  grid = (oh, B), one band of rows per block ---------------
 __global__ __launch_bounds__(NT) void adaptive_pool_kernel(const float* __restrict__ A, int H, int W, int oh, int ow,
-                                                           int sanitize, float* __restrict__ out) {
+                                                           int sanitize, int vec_ok, float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) double colsum[];   // W doubles
   const int b = blockIdx.y, i = blockIdx.x;
   const int ys = (int)(((long long)i * H) / oh);
   const int ye = (int)((((long long)(i + 1)) * H + oh - 1) / oh);
   const float* base = A + (size_t)b * H * W;
+  if (vec_ok) {
+    // 16 bytes per lane and row, 8 rows in flight: the dword form of this loop below reached 0.61 of the HBM peak on
+    // B=256 x 1024 x 1024 (profiles/round2_stage_bench.txt); same summation order (rows ascending per column)
+    for (int q = threadIdx.x; 4 * q < W; q += blockDim.x) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f* src = reinterpret_cast<const v4f*>(base) + q;
+      const size_t rs = (size_t)W / 4;
+      int r = ys;
+      for (; r + 8 <= ye; r += 8) {
+        v4f v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(src + (size_t)(r + k) * rs);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0 += (double)v[k].x; a1 += (double)v[k].y; a2 += (double)v[k].z; a3 += (double)v[k].w; }
+      }
+      for (; r < ye; ++r) {
+        const v4f v = __builtin_nontemporal_load(src + (size_t)r * rs);
+        a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+      }
+      colsum[4 * q] = a0; colsum[4 * q + 1] = a1; colsum[4 * q + 2] = a2; colsum[4 * q + 3] = a3;
+    }
+  } else
   for (int x = threadIdx.x; x < W; x += blockDim.x) {
     double acc = 0.0;
     int r = ys;
@@ -594,7 +728,9 @@ extern "C" int attwarp_gt_marginals(const float* A, int B, int H, int W, float* 
   double* col = (double*)ws;
   double* ls = col + (size_t)B * W;
   hipStream_t st = as_stream(stream);
-  int rc = launch_profiles<float, XfClampPos>(A, B, H, W, XfClampPos{}, P, col, ls, st);
+  bool handled = false;
+  int rc = launch_profiles_f32<XfClampPos>(A, B, H, W, XfClampPos{}, P, col, ls, st, &handled);
+  if (!handled) rc = launch_profiles<float, XfClampPos>(A, B, H, W, XfClampPos{}, P, col, ls, st);
   if (rc) return rc;
   const int n = H > W ? H : W;
   hipLaunchKernelGGL(marginals_finalize_kernel, dim3(B, 2), dim3(NT), (size_t)n * sizeof(double), st, col, ls,
@@ -608,8 +744,9 @@ extern "C" int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, in
   ATTWARP_REQUIRE(B > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "adaptive_avg_pool: non-positive size");
   if (oh > 65535 || B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "adaptive_avg_pool: oh/B > 65535");
   if (W > 16384) return fail(ATTWARP_E_UNSUPPORTED, "adaptive_avg_pool: W=%d > 16384", W);
+  const int vec_ok = (W % 4 == 0) && (reinterpret_cast<uintptr_t>(A) % 16 == 0);
   hipLaunchKernelGGL(adaptive_pool_kernel, dim3(oh, B), dim3(NT), (size_t)W * sizeof(double), as_stream(stream), A, H,
-                     W, oh, ow, sanitize, out);
+                     W, oh, ow, sanitize, vec_ok, out);
   return check_launch("adaptive_pool_kernel");
 }
 
@@ -638,7 +775,12 @@ extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int 
       rc = launch_profiles_u8<TR>(att, B, h, w, xf, Pw, col, ls, st, &handled);                                   \
       if (!handled) rc = launch_profiles<uint8_t, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);            \
     }                                                                                                             \
-    else if (dtype == ATTWARP_F32) rc = launch_profiles<float, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st); \
+    else if (dtype == ATTWARP_F32) {                                                                              \
+      bool handled = false;                                                                                       \
+      if (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE || tune(TUNE_PROFILES_VARIANT) == 2)                 \
+        rc = launch_profiles_f32<XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st, &handled);                   \
+      if (!handled) rc = launch_profiles<float, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);              \
+    }                                                                                                             \
     else rc = launch_profiles<double, XfAttention<TR>>(att, B, h, w, xf, Pw, col, ls, st);                        \
   } break;
   if (dtype != ATTWARP_U8 && dtype != ATTWARP_F32 && dtype != ATTWARP_F64)

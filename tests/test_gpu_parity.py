@@ -683,6 +683,43 @@ def test_maps_from_uint8_attention_fast_kernel(dev, hw):
                     assert np.array_equal(N(mx)[b], rx) and np.array_equal(N(my)[b], ry), (hw, tr, b)
 
 
+@pytest.mark.parametrize("hw", [(1024, 1024), (336, 336), (333, 500), (100, 1000), (70, 132), (40, 2048)])
+def test_maps_and_marginals_from_float32_fast_kernel(dev, hw):
+    """float32 attention / activation maps through profiles_f32_kernel (raw floats in LDS, the transform in registers,
+    row and column sums on different waves): the oracle's maps (numpy's summation orders) for identity / square, the
+    generic kernel bit for bit for every transform (variant 2 sends sqrt / exp / log through the new kernel too), and
+    gt_marginals against the oracle and the generic kernel -- negative values, NaN and Inf included."""
+    from attwarp_amd import new_method as nm, checkpoint_utils as cu
+    h, w = hw
+    rng = np.random.default_rng(h * 7 + w)
+    att = rng.random((3, h, w), dtype=np.float32) * 3.0 - 0.5            # some negatives: clamped
+    att[1] = rng.normal(1.0, 1e-3, (h, w)).astype(np.float32)
+    att[2, : h // 2] = 0
+    a = T(att, dev)
+    for tr in ("identity", "square", "sqrt", "exp", "log"):
+        for inv in (False, True):
+            kw = dict(transform=tr, exp_scale=1.0, exp_divisor=50.0, apply_inverse=inv)
+            with _lib.debug_override(profiles_variant=1):
+                gx, gy = nm.attention_axis_maps(a, 500, 400, **kw)
+            for variant in (-1, 2):
+                with _lib.debug_override(profiles_variant=variant):
+                    mx, my = nm.attention_axis_maps(a, 500, 400, **kw)
+                assert np.array_equal(N(mx), N(gx), equal_nan=True) and np.array_equal(N(my), N(gy), equal_nan=True), (hw, tr, inv, variant)
+            if tr in ("identity", "square") and not inv:
+                for b in range(3):
+                    rx, ry = O.maps_from_attention(att[b], 500, 400, tr)
+                    assert np.array_equal(N(mx)[b], rx) and np.array_equal(N(my)[b], ry), (hw, tr, b)
+    A = att[:, None].copy()
+    A[0, 0, h // 3, w // 5] = np.nan
+    A[1, 0, h // 2, w // 2] = np.inf
+    px, py = cu.gt_marginals(T(A, dev))
+    with _lib.debug_override(profiles_variant=1):
+        qx, qy = cu.gt_marginals(T(A, dev))
+    pxo, pyo = O.gt_marginals(A)
+    assert np.array_equal(N(px), N(qx), equal_nan=True) and np.array_equal(N(py), N(qy), equal_nan=True)
+    assert np.array_equal(N(px), pxo, equal_nan=True) and np.array_equal(N(py), pyo, equal_nan=True)
+
+
 def test_uniform_attention_gives_identity_warp(dev):
     from attwarp_amd import new_method as nm
     rng = np.random.default_rng(33)

@@ -20,7 +20,14 @@ for (B, S) in [(256, 1024), (64, 336)]:
     rep(f"gt_marginals full-res fp32 B={B} S={S}", timeit(lambda: cu.gt_marginals(A)), B*S*S*4)
     au8 = (A[:, 0] * 255).to(torch.uint8).contiguous()
     rep(f"attention_axis_maps u8 identity B={B} S={S}", timeit(lambda: nm.attention_axis_maps(au8, 500, 500, "identity")), B*S*S)
+    rep(f"attention_axis_maps f32 identity B={B} S={S}", timeit(lambda: nm.attention_axis_maps(a3, S, S, "identity")), B*S*S*4)
     rep(f"attention_axis_maps f32 sqrt B={B} S={S}", timeit(lambda: nm.attention_axis_maps(a3, S, S, "sqrt")), B*S*S*4)
+    from attwarp_amd import _lib
+    with _lib.debug_override(profiles_variant=2):
+        rep(f"attention_axis_maps f32 sqrt (variant 2) B={B} S={S}", timeit(lambda: nm.attention_axis_maps(a3, S, S, "sqrt")), B*S*S*4)
+    with _lib.debug_override(profiles_variant=1):
+        rep(f"gt_marginals full-res fp32 (variant 1) B={B} S={S}", timeit(lambda: cu.gt_marginals(A)), B*S*S*4)
+        rep(f"attention_axis_maps f32 identity (variant 1) B={B} S={S}", timeit(lambda: nm.attention_axis_maps(a3, S, S, "identity")), B*S*S*4)
     m24 = torch.rand(B, 24, 24, device=dev)
     rep(f"revise_mask B={B}", timeit(lambda: ae.revise_mask(m24)), B*576*8)
     rep(f"upsample_mask_lanczos 24->{S} B={B}", timeit(lambda: ae.upsample_mask_lanczos(m24, (S, S))), B*S*S)
