@@ -171,19 +171,49 @@ OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
+def expand2square(images_u8: torch.Tensor, background=None) -> torch.Tensor:
+    """LLaVA-1.5's ``image_aspect_ratio == "pad"`` step (``expand2square`` of the external LLaVA checkout, called by
+    ``process_images``: AGW/attention_extraction/functions.py:262-271) for a uint8 [B,H,W,C] batch on the GPU: the
+    images centred (offset ``(long - short) // 2``) on a square canvas of ``background`` (default
+    ``int(mean * 255)`` per channel, as LLaVA passes it).  Square batches are returned as they are."""
+    dev = require_gpu(images_u8)
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
+        raise TypeError("expand2square expects a uint8 [B,H,W,C] tensor")
+    B, H, W, C = images_u8.shape
+    if H == W:
+        return images_u8
+    if background is None:
+        background = tuple(int(x * 255) for x in OPENAI_CLIP_MEAN)
+    if len(background) < C:
+        raise ValueError(f"background needs {C} channel values; got {len(background)}")
+    n = max(H, W)
+    out = torch.tensor(list(background[:C]), dtype=torch.uint8, device=dev).expand(B, n, n, C).contiguous()
+    if W > H:
+        o = (W - H) // 2
+        out[:, o:o + H] = images_u8
+    else:
+        o = (H - W) // 2
+        out[:, :, o:o + W] = images_u8
+    return out
+
+
 def clip_preprocess(images_u8: torch.Tensor, size: int = 336, dtype: torch.dtype = torch.float16,
-                    mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD) -> torch.Tensor:
+                    mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, pad_to_square: bool = False) -> torch.Tensor:
     """Warped uint8 RGB batch [B,H,W,3] -> CLIP-ready [B,3,size,size] on the GPU ("next" row 3).
 
     Replaces the PNG round trip of the reference (``cv2.imwrite`` new_method.py:491 -> ``Image.open`` +
     ``process_images`` evaluate_accuracy.py:157-158) with two launches.  Arithmetic = HF CLIPImageProcessor
     (PIL backend) as LLaVA-1.5 configures it: PIL BICUBIC resize of the shorter edge to ``size``, center crop,
     ``float32(float64(u8) * (1/255))``, ``(x - mean) / std`` in float32; ``dtype`` float32 or float16
-    (LLaVA casts to float16, functions.py:270-271).  Bit-identical to the processor for float32."""
+    (LLaVA casts to float16, functions.py:270-271).  Bit-identical to the processor for float32.
+    ``pad_to_square=True`` runs :func:`expand2square` first (LLaVA-1.5's ``image_aspect_ratio="pad"``; a no-op for
+    the square warps of the reference drivers)."""
     import ctypes
     dev = require_gpu(images_u8)
     if images_u8.dtype != torch.uint8 or images_u8.dim() != 4:
         raise TypeError("clip_preprocess expects a uint8 [B,H,W,C] tensor")
+    if pad_to_square:
+        images_u8 = expand2square(images_u8, tuple(int(float(v) * 255) for v in mean))
     if dtype not in (torch.float32, torch.float16):
         raise TypeError("clip_preprocess: dtype must be float32 or float16")
     x = images_u8.contiguous()

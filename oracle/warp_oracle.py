@@ -353,6 +353,32 @@ def clip_preprocess(img_rgb_u8: np.ndarray, size: int = 336) -> np.ndarray:
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 
 
+def expand2square(img_rgb_u8: np.ndarray, background=None) -> np.ndarray:
+    """LLaVA-1.5's ``image_aspect_ratio == "pad"`` step in front of the CLIP processor (``process_images`` ->
+    ``expand2square(image, tuple(int(x * 255) for x in image_processor.image_mean))``; external LLaVA checkout,
+    ``llava/mm_utils.py``, NOT part of /root/reference -- restated from the published algorithm, the reference only
+    reaches it through ``process_images``, AGW/attention_extraction/functions.py:262-271 and
+    AGW/evaluate_accuracy.py:157-158).  [H,W,C] uint8 -> [max(H,W), max(H,W), C]: the image pasted at
+    ``(long - short) // 2`` along the short axis on a canvas of the background colour.  A square image (the 500 x 500
+    warps of both reference drivers) is returned unchanged."""
+    img = np.asarray(img_rgb_u8, dtype=np.uint8)
+    h, w, c = img.shape
+    if background is None:
+        background = tuple(int(x * 255) for x in OPENAI_CLIP_MEAN)
+    if h == w:
+        return img
+    n = max(h, w)
+    out = np.empty((n, n, c), np.uint8)
+    out[...] = np.asarray(background[:c], np.uint8)
+    if w > h:
+        o = (w - h) // 2
+        out[o:o + h] = img
+    else:
+        o = (h - w) // 2
+        out[:, o:o + w] = img
+    return out
+
+
 # ---------------------------------------------------------------------------
 # A5  24 x 24 adaptive average pool
 # ---------------------------------------------------------------------------

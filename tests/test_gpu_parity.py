@@ -715,7 +715,8 @@ def test_maps_and_marginals_from_float32_fast_kernel(dev, hw):
     px, py = cu.gt_marginals(T(A, dev))
     with _lib.debug_override(profiles_variant=1):
         qx, qy = cu.gt_marginals(T(A, dev))
-    pxo, pyo = O.gt_marginals(A)
+    with np.errstate(invalid="ignore"):
+        pxo, pyo = O.gt_marginals(A)
     assert np.array_equal(N(px), N(qx), equal_nan=True) and np.array_equal(N(py), N(qy), equal_nan=True)
     assert np.array_equal(N(px), pxo, equal_nan=True) and np.array_equal(N(py), pyo, equal_nan=True)
 
@@ -1604,6 +1605,26 @@ def test_clip_preprocess_staged_equals_generic(dev, shape):
     if C == 3 and H * W <= 600 * 600:
         got = N(pipeline.clip_preprocess(x, size, torch.float32))
         assert np.array_equal(got[0], O.clip_preprocess(img[0], size))
+
+
+@pytest.mark.parametrize("hw", [(300, 420), (421, 300), (336, 336)])
+def test_clip_preprocess_pad_to_square(dev, hw):
+    """LLaVA-1.5's image_aspect_ratio="pad": expand2square (mean-colour canvas, image centred) in front of the CLIP
+    processor arithmetic; wide, tall (odd margin) and already-square images against the oracle, bit for bit."""
+    from attwarp_amd import pipeline
+    H, W = hw
+    rng = np.random.default_rng(H + 3 * W)
+    img = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    x = T(img, dev)
+    sq = pipeline.expand2square(x)
+    for b in range(2):
+        assert np.array_equal(N(sq)[b], O.expand2square(img[b]))
+    assert (sq is x) == (H == W)
+    got = N(pipeline.clip_preprocess(x, 336, torch.float32, pad_to_square=True))
+    for b in range(2):
+        assert np.array_equal(got[b], O.clip_preprocess(O.expand2square(img[b]), 336))
+    bg = (7, 8, 9)
+    assert np.array_equal(N(pipeline.expand2square(x, bg))[1], O.expand2square(img[1], bg))
 
 
 def test_warp_to_clip_pipeline(dev, golden):

@@ -359,6 +359,28 @@ def test_numpy_pairwise_restatement():
 
 
 # ---- "next" row 3: warped image -> CLIP tensor --------------------------------
+@pytest.mark.parametrize("hw", [(30, 47), (48, 31), (20, 20)])
+def test_expand2square_vs_pillow(hw):
+    """The oracle's expand2square against the Pillow calls the published LLaVA helper is made of
+    (Image.new(mode, (n, n), colour) + paste at ((long - short) // 2))."""
+    from PIL import Image
+    h, w = hw
+    rng = np.random.default_rng(h * 5 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    bg = tuple(int(x * 255) for x in O.OPENAI_CLIP_MEAN)
+    pil = Image.fromarray(img)
+    if w == h:
+        ref = pil
+    elif w > h:
+        ref = Image.new(pil.mode, (w, w), bg)
+        ref.paste(pil, (0, (w - h) // 2))
+    else:
+        ref = Image.new(pil.mode, (h, h), bg)
+        ref.paste(pil, ((h - w) // 2, 0))
+    assert np.array_equal(O.expand2square(img), np.asarray(ref))
+    assert bg == (122, 116, 104)
+
+
 def test_pil_bicubic_bit_exact_vs_pillow(golden):
     g = golden("clip_preprocess")
     for (w, h) in [(30, 20), (100, 90), (56, 17)]:
