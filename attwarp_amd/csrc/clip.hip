@@ -27,13 +27,20 @@ namespace clip {
 
 constexpr int NT = 256;
 constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
-constexpr int RV = 8;            // output rows per workgroup of the vertical pass
+constexpr int RV = 8;            // output rows per workgroup of the vertical pass (the per-workgroup table and index set-up is amortised over them)
 
 __device__ __forceinline__ uint8_t clip8(int v) { return (uint8_t)min(max(v >> PIL_PRECISION_BITS, 0), 255); }
+// acc += pixel * coefficient with ONE full-rate instruction: pixels are 8 bit, Pillow's coefficients |k| <= 2^22, so the
+// 24-bit multiply-add is exact (left to itself the compiler emits the quarter-rate v_mul_lo_u32 + an add: the
+// horizontal pass spent 24 of those per pixel and row)
+__device__ __forceinline__ void mad24(int& acc, int px, int k) { asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(px), "v"(k)); }
+// the same with a wave-uniform coefficient (an SGPR operand: no v_mov per tap)
+__device__ __forceinline__ void mad24s(int& acc, int px, int k) { asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(acc) : "v"(px), "s"(k)); }
 
 // grid = (ceil(h / RB), B), NTH threads.  LDS: srow[RB][wcp] | orow[RB][ocp]  (row bytes rounded up to 4).
 // A thread owns output pixel xx (and xx + NTH, ...): its first tap and its <= KS coefficients stay in registers
-// for the RB rows of the block (taps past the pixel's count carry a zero coefficient and re-read the last tap).
+// for the RB rows of the block.  The allocation carries H_SLACK bytes behind orow for the over-read described below.
+constexpr int H_SLACK = 128;
 constexpr int NTH = 384;         // 336 output pixels -> one pixel per thread, 87 % of the lanes busy
 template <int C, int KS>
 __global__ __launch_bounds__(NTH) void clip_h_rows_kernel(const uint8_t* __restrict__ src, int h, int w, int left,
@@ -48,35 +55,55 @@ __global__ __launch_bounds__(NTH) void clip_h_rows_kernel(const uint8_t* __restr
   const int y0 = blockIdx.x * RB, nrows = min(RB, h - y0);
 
   const uint8_t* sp = src + ((size_t)b * h + y0) * wc;
-  if (src_dwords_ok) {          // rows start on 4-byte boundaries: coalesced dword loads
+  if (src_dwords_ok) {          // rows start on 4-byte boundaries: coalesced dword loads, all rows of the block in flight
     const int nd = wc >> 2;
-    for (int r = 0; r < nrows; ++r)
-      for (int d = tid; d < nd; d += NTH)
-        reinterpret_cast<uint32_t*>(srow + (size_t)r * wcp)[d] = reinterpret_cast<const uint32_t*>(sp + (size_t)r * wc)[d];
+    for (int d = tid; d < nd; d += NTH) {
+      for (int r0 = 0; r0 < nrows; r0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const uint32_t*>(sp + (size_t)min(r0 + i, nrows - 1) * wc)[d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (r0 + i < nrows) reinterpret_cast<uint32_t*>(srow + (size_t)(r0 + i) * wcp)[d] = v[i];
+      }
+    }
   } else {
     for (int r = 0; r < nrows; ++r)
       for (int d = tid; d < wc; d += NTH) srow[(size_t)r * wcp + d] = sp[(size_t)r * wc + d];
   }
   __syncthreads();
 
+  // The KS taps x C channels of a pixel are KS*C CONSECUTIVE bytes of the source row starting at xmin*C: they are read
+  // as KS*C/4 + 1 dwords, shifted into place with v_alignbyte_b32 and consumed with a static byte extract + one
+  // v_mad_i32_i24 each (byte reads made the LDS the bottleneck: 24 ds_read_u8 per pixel and row for RGB, 41 % of the
+  // LDS cycles bank conflicts -- profiles/round2_clip_pmc.txt).  Taps past the pixel's count carry a zero coefficient;
+  // the bytes they multiply may lie past the row (the next row, or the slack behind the last one).
+  constexpr int NB = KS * C, NA = NB / 4, NW = NA + 1;
   for (int xx = tid; xx < ow; xx += NTH) {
     const int xo = left + xx;
     const int xmin = bounds[2 * xo], cnt = bounds[2 * xo + 1];
-    int kreg[KS], toff[KS];
+    int kreg[KS];
 #pragma unroll
-    for (int x = 0; x < KS; ++x) {
-      kreg[x] = (x < cnt) ? kk[(size_t)xo * ksize + min(x, ksize - 1)] : 0;
-      toff[x] = (xmin + min(x, cnt - 1)) * C;
-    }
+    for (int x = 0; x < KS; ++x) kreg[x] = (x < cnt) ? kk[(size_t)xo * ksize + min(x, ksize - 1)] : 0;
+    const int o = xmin * C, sh = o & 3;
+    const uint8_t* first = srow + (o & ~3);
     for (int r = 0; r < nrows; ++r) {
-      const uint8_t* row = srow + (size_t)r * wcp;
+      const uint32_t* rw = reinterpret_cast<const uint32_t*>(first + (size_t)r * wcp);
+      uint32_t wv[NW], a[NA];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) wv[i] = rw[i];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = __builtin_amdgcn_alignbyte(wv[i + 1], wv[i], sh);
       int ss[C];
 #pragma unroll
       for (int c = 0; c < C; ++c) ss[c] = 1 << (PIL_PRECISION_BITS - 1);
 #pragma unroll
       for (int x = 0; x < KS; ++x)
 #pragma unroll
-        for (int c = 0; c < C; ++c) ss[c] += (int)row[toff[x] + c] * kreg[x];
+        for (int c = 0; c < C; ++c) {
+          const int j = x * C + c;
+          mad24(ss[c], (int)((a[j >> 2] >> (8 * (j & 3))) & 0xffu), kreg[x]);
+        }
       uint8_t* op = orow + (size_t)r * ocp + xx * C;
 #pragma unroll
       for (int c = 0; c < C; ++c) op[c] = clip8(ss[c]);
@@ -130,12 +157,16 @@ __global__ __launch_bounds__(NT) void clip_v_rows_kernel(const uint8_t* __restri
       toff[n][j] = c * ow + xx;
       lbase[n][j] = c * 256;
     }
-  size_t ooff[NS];                         // planar offset of tile element tid + NT*n (without the row term)
+  // 32-bit offsets inside one image (h * oc and C * oh * ow stay below 2^31 for every shape the entry point admits):
+  // with 64-bit element indices every tap load and every store paid a 64-bit multiply-add
+  const uint8_t* timg = tmp + (size_t)b * h * oc;
+  OutT* oimg = out + (size_t)b * C * oh * ow;
+  int ooff[NS];                            // planar offset of tile element tid + NT*n (without the row term)
 #pragma unroll
   for (int n = 0; n < NS; ++n) {
     const int i = tid + NT * n;
     const int c = i / ow, xx = i - c * ow;
-    ooff[n] = (((size_t)b * C + c) * oh) * ow + xx;
+    ooff[n] = c * oh * ow + xx;
   }
   __syncthreads();
   const int yy0 = blockIdx.x * RV, yy1 = min(yy0 + RV, oh);
@@ -143,19 +174,48 @@ __global__ __launch_bounds__(NT) void clip_v_rows_kernel(const uint8_t* __restri
     const int yo = top + yy;
     const int ymin = bounds[2 * yo], cnt = bounds[2 * yo + 1];
     const int32_t* k = kk + (size_t)yo * ksize;
-    const uint8_t* col = tmp + ((size_t)b * h + ymin) * oc;
+    const uint8_t* col = timg + (unsigned)(ymin * oc);
+    const int hlast = h - 1;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
       const int q = tid + NT * n;
       if (q < nq) {
         int a0 = 1 << (PIL_PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
-        for (int y = 0; y < cnt; ++y) {
-          const uint32_t wv = reinterpret_cast<const uint32_t*>(col + (size_t)y * oc)[q];
-          const int kv = k[y];
-          a0 += (int)(wv & 0xffu) * kv;
-          a1 += (int)((wv >> 8) & 0xffu) * kv;
-          a2 += (int)((wv >> 16) & 0xffu) * kv;
-          a3 += (int)(wv >> 24) * kv;
+        if (ksize == 8) {
+          // rows of exactly 8 coefficients, zero past the count (attwarp.h): one 32-byte scalar load and 8 row loads
+          // without a branch (row indices clamped to the image; the coefficient of a clamped row is zero)
+          uint32_t wv[8];
+          int kv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) kv[i] = __builtin_amdgcn_readfirstlane(k[i]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) wv[i] = reinterpret_cast<const uint32_t*>(col + (unsigned)(min(i, hlast - ymin) * oc))[q];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            mad24s(a0, (int)(wv[i] & 0xffu), kv[i]);
+            mad24s(a1, (int)((wv[i] >> 8) & 0xffu), kv[i]);
+            mad24s(a2, (int)((wv[i] >> 16) & 0xffu), kv[i]);
+            mad24s(a3, (int)(wv[i] >> 24), kv[i]);
+          }
+        } else
+        for (int y0 = 0; y0 < cnt; y0 += 8) {
+          // 8 tap rows requested before the first multiply (taps past the count re-read the last row with a zero
+          // coefficient); one dependent round trip per 8 taps instead of per tap
+          uint32_t wv[8];
+          int kv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int y = min(y0 + i, cnt - 1);
+            wv[i] = reinterpret_cast<const uint32_t*>(col + (unsigned)(y * oc))[q];
+            kv[i] = __builtin_amdgcn_readfirstlane((y0 + i < cnt) ? k[y] : 0);      // wave uniform
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            mad24s(a0, (int)(wv[i] & 0xffu), kv[i]);
+            mad24s(a1, (int)((wv[i] >> 8) & 0xffu), kv[i]);
+            mad24s(a2, (int)((wv[i] >> 16) & 0xffu), kv[i]);
+            mad24s(a3, (int)(wv[i] >> 24), kv[i]);
+          }
         }
         tile[toff[n][0]] = from_f32<OutT>(lut[lbase[n][0] + clip8(a0)]);
         tile[toff[n][1]] = from_f32<OutT>(lut[lbase[n][1] + clip8(a1)]);
@@ -167,7 +227,7 @@ __global__ __launch_bounds__(NT) void clip_v_rows_kernel(const uint8_t* __restri
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
       const int i = tid + NT * n;
-      if (i < oc) out[ooff[n] + (size_t)yy * ow] = tile[i];
+      if (i < oc) oimg[ooff[n] + yy * ow] = tile[i];
     }
     __syncthreads();
   }
@@ -206,7 +266,7 @@ extern "C" int attwarp_clip_preprocess_u8(const uint8_t* src, int B, int h, int 
                                    s, tmp, out, out_dtype, st);
 
   const int src_dwords_ok = (wc % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 3u) == 0);
-  const size_t lds_h = (size_t)RB * (size_t)(wcp + ocp);
+  const size_t lds_h = (size_t)RB * (size_t)(wcp + ocp) + clip::H_SLACK;
   const dim3 gh((unsigned)((h + RB - 1) / RB), B), th(clip::NTH);
 #define ATTWARP_CLIP_H(CC, KS)                                                                                     \
   hipLaunchKernelGGL((clip::clip_h_rows_kernel<CC, KS>), gh, th, lds_h, st, src, h, w, left, size, bounds_x, kk_x,    \
