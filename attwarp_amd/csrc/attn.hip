@@ -95,6 +95,35 @@ __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restric
 struct __attribute__((packed, aligned(4))) F4u {
   float x, y, z, w;
 };
+
+// ---- float32 division by a denominator shared by many numerators -------------------------------------------------
+// The compiler expands an IEEE float32 `a / d` into
+//     ds = div_scale(d, d, a); ns = div_scale(a, d, a); r0 = rcp(ds); e0 = fma(-ds, r0, 1); r1 = fma(e0, r0, r0);
+//     q0 = ns * r1; e1 = fma(-ds, q0, ns); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, ns); q = div_fmas(e2, r1, q1);
+//     result = div_fixup(q, d, a)
+// (11 instructions, one of them the quarter-rate v_rcp_f32; 16.6 VALU instructions per attention element made this
+// kernel VALU bound).  v_div_scale only rescales when an exponent is extreme -- |a| < 2^-103, d denormal or > 2^126,
+// a quotient that is denormal or whose exponents differ by >= 96 -- and v_div_fixup only replaces q for zero /
+// infinite / NaN operands.  Inside  d in [2^-60, 4],  a == 0 or 2^-100 <= a <= 2^20  the scale factors are 1, so
+// r0, e0, r1 depend on d alone and the SAME sequence costs 5 instructions per numerator, bit for bit the result of
+// `a / d` (a == 0 gives +0 through the sequence, as div_fixup does).  Anything outside that box takes `a / d` itself.
+struct SharedDiv {
+  float d, r1;
+  __device__ __forceinline__ explicit SharedDiv(float den) : d(den) {
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+    r1 = __builtin_fmaf(e0, r0, r0);
+  }
+  __device__ __forceinline__ float operator()(float a) const {
+    const float q0 = fmul(a, r1);
+    const float e1 = __builtin_fmaf(-d, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+  }
+};
+constexpr uint32_t SDIV_NUM_LO = 0x0D800000u;   // 2^-100
+constexpr uint32_t SDIV_NUM_HI = 0x49800000u;   // 2^20
 template <int NV, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* __restrict__ attn, int heads,
                                                                    int64_t sb, int64_t sh, int64_t row_off,
@@ -132,12 +161,35 @@ __global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* 
             s += ((double)v[u][i].x + (double)v[u][i].y) + ((double)v[u][i].z + (double)v[u][i].w);
         s = wave_sum(s);
         const float den = fadd((float)s, 1e-12f);
+        // smallest non-zero and largest bit pattern of this lane's numerators (0 - 1 wraps to the top: zeros do not
+        // lower the minimum; negative, infinite and NaN numerators exceed SDIV_NUM_HI)
+        uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          acc[i][0] += (double)(v[u][i].x / den);
-          acc[i][1] += (double)(v[u][i].y / den);
-          acc[i][2] += (double)(v[u][i].z / den);
-          acc[i][3] += (double)(v[u][i].w / den);
+          const uint32_t bx = __float_as_uint(v[u][i].x), by = __float_as_uint(v[u][i].y),
+                         bz = __float_as_uint(v[u][i].z), bw = __float_as_uint(v[u][i].w);
+          lo = min(min(lo, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
+          hi = max(max(hi, bx), max(by, max(bz, bw)));
+        }
+        const bool box = den >= 8.673617379884035e-19f && den <= 4.0f &&       // 2^-60 .. 4 (wave uniform)
+                         __all(lo >= SDIV_NUM_LO - 1u && hi <= SDIV_NUM_HI);
+        if (box) {
+          const SharedDiv dv(den);
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            acc[i][0] += (double)dv(v[u][i].x);
+            acc[i][1] += (double)dv(v[u][i].y);
+            acc[i][2] += (double)dv(v[u][i].z);
+            acc[i][3] += (double)dv(v[u][i].w);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) {
+            acc[i][0] += (double)(v[u][i].x / den);
+            acc[i][1] += (double)(v[u][i].y / den);
+            acc[i][2] += (double)(v[u][i].z / den);
+            acc[i][3] += (double)(v[u][i].w / den);
+          }
         }
       }
     }

@@ -66,6 +66,41 @@ def test_attn_steps_vs_oracle_and_golden(dev, golden):
     assert hl.step_attentions == [] and hl.batch_size == 0
 
 
+def test_attn_step_division_matches_ieee_everywhere(dev):
+    """The float32 step kernel divides by (row sum + 1e-12) with a reciprocal shared by the row when the operands sit
+    inside the box where v_div_scale does not rescale (attn.hip, SharedDiv) and with the plain IEEE division outside:
+    rows of real softmax values, rows with exponents on and beyond the box edges (2^-100, 2^-103, denormals, 2^20,
+    1e30), zeros, negative values, tiny and huge row sums, Inf and NaN -- numpy's float32 division bit for bit."""
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(2024)
+    B, heads, kv, ntok = 6, 32, 640, 576
+    a = rng.random((B, heads, 1, kv), dtype=np.float32)
+    a[0] = np.exp(rng.normal(0, 6, (heads, 1, kv))).astype(np.float32)
+    a[0] /= a[0].sum(-1, keepdims=True)                                     # a real softmax: wide dynamic range
+    edge = np.array([2.0 ** -100, np.nextafter(np.float32(2.0 ** -100), np.float32(0)), 2.0 ** -103, 1e-40, 1e-45, 0.0,
+                     2.0 ** 20, np.nextafter(np.float32(2.0 ** 20), np.float32(np.inf)), 1e30, 3e-39], np.float32)
+    a[1, :, 0, 40:40 + ntok] = rng.choice(edge, (heads, ntok))                # sums dominated by 2^20 / 1e30 entries
+    a[1, ::2, 0, 40:40 + ntok] = np.minimum(a[1, ::2, 0, 40:40 + ntok], np.float32(1.0))
+    a[2] = (a[2] * np.float32(1e-22)).astype(np.float32)                      # row sums ~ 3e-20 < 2^-60: IEEE path
+    a[2, 5] = a[2, 5] * np.float32(1e-12)                                     # ... and below 1e-12: den = 1e-12
+    a[3, :, 0, ::7] = 0.0
+    a[3, 3, 0, 100] = -0.25                                                   # negative numerator
+    a[3, 4, 0, 101] = np.inf
+    a[3, 6, 0, 102] = np.nan
+    a[4] = rng.choice(np.array([0.0, 1e-30, 1.0, 0.5, 3.0], np.float32), (heads, 1, kv))
+    a[5, :, 0, :] = np.float32(2.0 ** -100) * rng.integers(1, 1 << 20, (heads, kv)).astype(np.float32)
+    starts = [40, 40, 35, 64, 0, 17]
+    ends = [st + ntok for st in starts]
+    hl = ae.BatchMaskHookLogger(model=None, device=dev)
+    hl.set_batch_image_token_ranges(starts, ends)
+    hl._process_attention(T(a, dev))
+    got = N(hl.step_attentions[-1])
+    with np.errstate(all="ignore"):
+        ref = O.attn_reduce_step(a, starts, ends)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert np.isfinite(ref[[0, 2, 4, 5]]).all() and not np.isfinite(ref[3]).all()
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_attn_steps_low_precision(dev, golden, dt):
     from attwarp_amd import attention_extraction as ae
