@@ -70,6 +70,65 @@ __global__ __launch_bounds__(256) void flatcopy(const float4* __restrict__ src, 
 #pragma unroll
   for (int i = 0; i < VPT; ++i) { if (NTS) __builtin_nontemporal_store(v[i], d + base + 256 * i); else d[base + 256 * i] = v[i]; }
 }
+// Locality probe: the 4 KB-per-workgroup nontemporal copy (the fastest, state-immune form) with the chunk a workgroup
+// copies displaced from its dispatch slot.  mode 0: chunk = (slot + shift) mod n (shift 8 keeps "chunk mod 8 == XCD",
+// shifts 1..7 break it); mode 1: XCD k owns the k-th contiguous eighth of the buffer; mode 2: source chunk displaced
+// by `shift` from the destination chunk (reads and writes of a workgroup land on different 4 KB slots).
+__global__ __launch_bounds__(256) void flatcopy_map(const float4* __restrict__ src, float4* __restrict__ dst, int nchunks,
+                                                    int mode, int shift) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* s = reinterpret_cast<const v4f*>(src);
+  v4f* d = reinterpret_cast<v4f*>(dst);
+  int slot = blockIdx.x, cs, cd;
+  if (mode == 0) { cd = slot + shift; if (cd >= nchunks) cd -= nchunks; cs = cd; }
+  else if (mode == 1) { const int q = nchunks >> 3; cd = (slot & 7) * q + (slot >> 3); cs = cd; }
+  else { cd = slot; cs = slot + shift; if (cs >= nchunks) cs -= nchunks; }
+  const v4f v = __builtin_nontemporal_load(s + (long long)cs * 256 + threadIdx.x);
+  __builtin_nontemporal_store(v, d + (long long)cd * 256 + threadIdx.x);
+}
+static void run_map(const float4* src, float4* dst, size_t bytes, int mode, int shift, hipEvent_t e0, hipEvent_t e1) {
+  std::vector<float> ts;
+  const int nchunks = (int)(bytes / 4096);
+  for (int it = 0; it < 12; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(flatcopy_map, dim3(nchunks), dim3(256), 0, 0, src, dst, nchunks, mode, shift);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("flat 4KB copy mode=%d shift=%2d: %.4f ms  %.2f TB/s\n", mode, shift, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
+}
+// Occupancy probe: the nontemporal flat copy with a dynamic LDS allocation that limits the workgroups per CU
+// (bytes in flight per CU = workgroups x 256 x VPT x 16).
+template <int VPT>
+__global__ __launch_bounds__(256) void flatcopy_occ(const float4* __restrict__ src, float4* __restrict__ dst) {
+  extern __shared__ float4 pad_lds[];
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* s = reinterpret_cast<const v4f*>(src);
+  v4f* d = reinterpret_cast<v4f*>(dst);
+  const long long base = (long long)blockIdx.x * (256 * VPT) + threadIdx.x;
+  v4f v[VPT];
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) v[i] = __builtin_nontemporal_load(s + base + 256 * i);
+#pragma unroll
+  for (int i = 0; i < VPT; ++i) __builtin_nontemporal_store(v[i], d + base + 256 * i);
+}
+template <int VPT>
+static void run_occ(const float4* src, float4* dst, size_t bytes, int wgs_per_cu, hipEvent_t e0, hipEvent_t e1) {
+  std::vector<float> ts;
+  const long long n4 = (long long)bytes / 16;
+  const size_t lds = wgs_per_cu >= 8 ? 0 : (size_t)(160 * 1024 / wgs_per_cu) - 512;
+  if (lds > 65536) hipFuncSetAttribute((const void*)flatcopy_occ<VPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int it = 0; it < 12; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((flatcopy_occ<VPT>), dim3((unsigned)(n4 / (256 * VPT))), dim3(256), lds, 0, src, dst);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("flat nt copy %d float4/thread, <= %d workgroups/CU (%3d KB in flight/CU): %.4f ms  %.2f TB/s\n", VPT, wgs_per_cu,
+         wgs_per_cu * 4 * VPT, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
+}
 template <int VPT, bool NTL, bool NTS>
 static void run_flat(const float4* src, float4* dst, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
   std::vector<float> ts;
@@ -129,5 +188,12 @@ int main() {
   run_flat<2, true, true>(src, dst, bytes, e0, e1);
   run_flat<8, true, true>(src, dst, bytes, e0, e1);
   run_flat<3, true, true>(src, dst, bytes, e0, e1);
+  for (int w : {8, 6, 4, 3, 2, 1}) run_occ<1>(src, dst, bytes, w, e0, e1);
+  for (int w : {8, 4, 3, 2, 1}) run_occ<2>(src, dst, bytes, w, e0, e1);
+  for (int w : {8, 4, 2, 1}) run_occ<3>(src, dst, bytes, w, e0, e1);
+  for (int w : {8, 4, 2, 1}) run_occ<4>(src, dst, bytes, w, e0, e1);
+  for (int shift : {0, 8, 1}) run_map(src, dst, bytes, 0, shift, e0, e1);
+  run_map(src, dst, bytes, 1, 0, e0, e1);
+  for (int shift : {1, 24}) run_map(src, dst, bytes, 2, shift, e0, e1);
   return 0;
 }
