@@ -98,6 +98,49 @@ static void run_map(const float4* src, float4* dst, size_t bytes, int mode, int 
   std::sort(ts.begin(), ts.end());
   printf("flat 4KB copy mode=%d shift=%2d: %.4f ms  %.2f TB/s\n", mode, shift, ts[ts.size() / 2], 2.0 * bytes / ts[ts.size() / 2] / 1e9);
 }
+// Tile probe: the traffic of a resample with ONE output row third (4 KB) per workgroup -- two 16-byte loads per thread
+// (the same column third of source rows y and y+1: the second is the halo the next row's workgroup reads again) and
+// one 16-byte store.  order 0: row-major linear; 1: a contiguous range of that order per XCD; 2: per XCD a contiguous
+// range of rows, walked column third by column third in chunks of `chunk` rows (consecutive workgroups of an XCD read
+// consecutive rows of one third: the halo comes from that XCD's L2).
+__global__ __launch_bounds__(256) void tilecopy(const float4* __restrict__ src, float4* __restrict__ dst, int nrows,
+                                                int order, int chunk, int nt) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int n = nrows * 3;
+  int bid = blockIdx.x;
+  long long y; int j;
+  if (order >= 1) {
+    const int q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+  }
+  if (order <= 1) { y = bid / 3; j = bid - 3 * (int)y; }
+  else {
+    const int per = 3 * chunk, c = bid / per, w = bid - c * per;
+    j = w / chunk; y = (long long)c * chunk + (w - j * chunk);
+    if (y >= nrows) return;
+  }
+  const long long y1 = min(y + 1, (long long)nrows - 1);
+  const v4f* s0 = reinterpret_cast<const v4f*>(src) + y * 768 + 256 * j + threadIdx.x;
+  const v4f* s1 = reinterpret_cast<const v4f*>(src) + y1 * 768 + 256 * j + threadIdx.x;
+  v4f a = (nt & 1) ? __builtin_nontemporal_load(s0) : *s0;
+  const v4f b = *s1;
+  if (b.x == 12345.678f) a.x += 1.0f;
+  v4f* d = reinterpret_cast<v4f*>(dst) + y * 768 + 256 * j + threadIdx.x;
+  if (nt & 2) __builtin_nontemporal_store(a, d); else *d = a;
+}
+static void run_tile(const float4* src, float4* dst, int nrows, int order, int chunk, int nt, hipEvent_t e0, hipEvent_t e1) {
+  std::vector<float> ts;
+  const int grid = order == 2 ? ((nrows + chunk - 1) / chunk) * chunk * 3 : nrows * 3;
+  for (int it = 0; it < 12; ++it) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(tilecopy, dim3(grid), dim3(256), 0, 0, src, dst, nrows, order, chunk, nt);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); if (it >= 2) ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("tile copy (4 KB out + 2 x 4 KB in per workgroup) order=%d chunk=%3d nt=%d: %.4f ms  %.2f TB/s algorithmic\n", order, chunk, nt,
+         ts[ts.size() / 2], 2.0 * nrows * 12288.0 / ts[ts.size() / 2] / 1e9);
+}
 // Occupancy probe: the nontemporal flat copy with a dynamic LDS allocation that limits the workgroups per CU
 // (bytes in flight per CU = workgroups x 256 x VPT x 16).
 template <int VPT>
@@ -188,6 +231,11 @@ int main() {
   run_flat<2, true, true>(src, dst, bytes, e0, e1);
   run_flat<8, true, true>(src, dst, bytes, e0, e1);
   run_flat<3, true, true>(src, dst, bytes, e0, e1);
+  for (int nt : {0, 2, 3}) {
+    run_tile(src, dst, (int)nrows, 0, 0, nt, e0, e1);
+    run_tile(src, dst, (int)nrows, 1, 0, nt, e0, e1);
+    for (int chunk : {8, 32, 128}) run_tile(src, dst, (int)nrows, 2, chunk, nt, e0, e1);
+  }
   for (int w : {8, 6, 4, 3, 2, 1}) run_occ<1>(src, dst, bytes, w, e0, e1);
   for (int w : {8, 4, 3, 2, 1}) run_occ<2>(src, dst, bytes, w, e0, e1);
   for (int w : {8, 4, 2, 1}) run_occ<3>(src, dst, bytes, w, e0, e1);
