@@ -31,6 +31,35 @@ template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b 
   return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
 }
 
+// ---- float32 division by a denominator shared by many numerators -------------------------------------------------
+// The compiler expands an IEEE float32 `a / d` into
+//     ds = div_scale(d, d, a); ns = div_scale(a, d, a); r0 = rcp(ds); e0 = fma(-ds, r0, 1); r1 = fma(e0, r0, r0);
+//     q0 = ns * r1; e1 = fma(-ds, q0, ns); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, ns); q = div_fmas(e2, r1, q1);
+//     result = div_fixup(q, d, a)
+// (11 instructions, one of them the quarter-rate v_rcp_f32; 16.6 VALU instructions per attention element made this
+// kernel VALU bound).  v_div_scale only rescales when an exponent is extreme -- |a| < 2^-103, d denormal or > 2^126,
+// a quotient that is denormal or whose exponents differ by >= 96 -- and v_div_fixup only replaces q for zero /
+// infinite / NaN operands.  Inside  d in [2^-60, 4],  a == 0 or 2^-100 <= a <= 2^20  the scale factors are 1, so
+// r0, e0, r1 depend on d alone and the SAME sequence costs 5 instructions per numerator, bit for bit the result of
+// `a / d` (a == 0 gives +0 through the sequence, as div_fixup does).  Anything outside that box takes `a / d` itself.
+struct SharedDiv {
+  float d, r1;
+  __device__ __forceinline__ explicit SharedDiv(float den) : d(den) {
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    const float e0 = __builtin_fmaf(-den, r0, 1.0f);
+    r1 = __builtin_fmaf(e0, r0, r0);
+  }
+  __device__ __forceinline__ float operator()(float a) const {
+    const float q0 = fmul(a, r1);
+    const float e1 = __builtin_fmaf(-d, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+  }
+};
+constexpr uint32_t SDIV_NUM_LO = 0x0D800000u;   // 2^-100
+constexpr uint32_t SDIV_NUM_HI = 0x49800000u;   // 2^20
+
 // One workgroup per (pseudo-)sample.  Each wave takes heads w, w+4, ...; lane l owns tokens
 // l, l+64, ... (NPL = ceil(ntok/64) values per head in registers).  Heads are processed HU at a
 // time so that HU*NPL independent coalesced loads (256 B per wave instruction) are in flight per
@@ -96,34 +125,6 @@ struct __attribute__((packed, aligned(4))) F4u {
   float x, y, z, w;
 };
 
-// ---- float32 division by a denominator shared by many numerators -------------------------------------------------
-// The compiler expands an IEEE float32 `a / d` into
-//     ds = div_scale(d, d, a); ns = div_scale(a, d, a); r0 = rcp(ds); e0 = fma(-ds, r0, 1); r1 = fma(e0, r0, r0);
-//     q0 = ns * r1; e1 = fma(-ds, q0, ns); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, ns); q = div_fmas(e2, r1, q1);
-//     result = div_fixup(q, d, a)
-// (11 instructions, one of them the quarter-rate v_rcp_f32; 16.6 VALU instructions per attention element made this
-// kernel VALU bound).  v_div_scale only rescales when an exponent is extreme -- |a| < 2^-103, d denormal or > 2^126,
-// a quotient that is denormal or whose exponents differ by >= 96 -- and v_div_fixup only replaces q for zero /
-// infinite / NaN operands.  Inside  d in [2^-60, 4],  a == 0 or 2^-100 <= a <= 2^20  the scale factors are 1, so
-// r0, e0, r1 depend on d alone and the SAME sequence costs 5 instructions per numerator, bit for bit the result of
-// `a / d` (a == 0 gives +0 through the sequence, as div_fixup does).  Anything outside that box takes `a / d` itself.
-struct SharedDiv {
-  float d, r1;
-  __device__ __forceinline__ explicit SharedDiv(float den) : d(den) {
-    const float r0 = __builtin_amdgcn_rcpf(den);
-    const float e0 = __builtin_fmaf(-den, r0, 1.0f);
-    r1 = __builtin_fmaf(e0, r0, r0);
-  }
-  __device__ __forceinline__ float operator()(float a) const {
-    const float q0 = fmul(a, r1);
-    const float e1 = __builtin_fmaf(-d, q0, a);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-d, q1, a);
-    return __builtin_fmaf(e2, r1, q1);
-  }
-};
-constexpr uint32_t SDIV_NUM_LO = 0x0D800000u;   // 2^-100
-constexpr uint32_t SDIV_NUM_HI = 0x49800000u;   // 2^20
 template <int NV, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* __restrict__ attn, int heads,
                                                                    int64_t sb, int64_t sh, int64_t row_off,

@@ -99,6 +99,29 @@ def test_attn_step_division_matches_ieee_everywhere(dev):
         ref = O.attn_reduce_step(a, starts, ends)
     assert np.array_equal(got, ref, equal_nan=True)
     assert np.isfinite(ref[[0, 2, 4, 5]]).all() and not np.isfinite(ref[3]).all()
+    # the generic kernel (any dtype / stride; plain IEEE division) on the same kind of input: float16 rows with subnormal
+    # halves, 65504, zeros, a negative, Inf, NaN and rows whose sum rounds to 0 or overflows in float16 ...
+    h = rng.random((B, heads, 1, kv), dtype=np.float32).astype(np.float16)
+    h[0] = (np.exp(rng.normal(0, 4, (heads, 1, kv))) * 1e-3).astype(np.float16)
+    h[1, :, 0, :] = rng.choice(np.array([0.0, 6e-8, 6.1e-5, 1.0, 65504.0, 0.333], np.float16), (heads, kv))
+    h[2] = np.float16(6e-8) * (rng.random((heads, 1, kv)) < 0.01)                    # sums of a few subnormals
+    h[2, 7] = 0                                                                     # all-zero row: 0 / 0
+    h[3, 3, 0, 100] = np.float16(-0.25)
+    h[3, 4, 0, 101] = np.float16(np.inf)
+    h[3, 6, 0, 102] = np.float16(np.nan)
+    h[4] = np.float16(60000.0) * (rng.random((heads, 1, kv)) < 0.5)                  # row sums overflow float16
+    hl.reinit()
+    hl.set_batch_image_token_ranges(starts, ends)
+    hl._process_attention(T(h, dev))
+    with np.errstate(all="ignore"):
+        ref16 = O.attn_reduce_step(h, starts, ends)
+    assert np.array_equal(N(hl.step_attentions[-1]), ref16, equal_nan=True)
+    # ... and float32 rows with a non-unit kv stride (a transposed view): generic kernel, float32 division
+    at = np.ascontiguousarray(a.transpose(0, 1, 3, 2))                               # [B, heads, kv, 1]
+    hl.reinit()
+    hl.set_batch_image_token_ranges(starts, ends)
+    hl._process_attention(T(at, dev).transpose(2, 3))
+    assert np.array_equal(N(hl.step_attentions[-1]), ref, equal_nan=True)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
