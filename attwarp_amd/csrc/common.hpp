@@ -36,6 +36,17 @@ __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b)
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
 // a + t*(b-a), three roundings (no FMA): the oracle's _lerp
+// Coordinate -> taps conventions shared by every resample kernel (and restated by oracle/):
+//  * cv2 mode: q = cvRound(32 * m) as OpenCV computes it on x86 (cvtss2si / cvtps2dq): a product that is NaN or does
+//    not fit a 32-bit integer becomes INT_MIN ("integer indefinite"), i.e. pixel 0 with a zero fraction after the
+//    replicate border -- for NaN, +-Inf and huge coordinates of EITHER sign;
+//  * exact mode: the coordinate is clamped to [-1, size] first (NaN counts as -1), so non-finite coordinates land on an
+//    edge pixel and never produce a NaN weight.
+__device__ __forceinline__ int cv_round_q5(float m) {
+  const float s = fmul(m, 32.0f);
+  return (s >= -2147483648.0f && s < 2147483648.0f) ? __float2int_rn(s) : (int)0x80000000;
+}
+__device__ __forceinline__ float clamp_coord(float m, int size) { return fminf(fmaxf(m, -1.0f), (float)size); }
 __device__ __forceinline__ float lerp_rn(float a, float b, float t) { return fadd(a, fmul(t, fsub(b, a))); }
 
 // ---- wave / block reductions ---------------------------------------------------

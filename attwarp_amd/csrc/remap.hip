@@ -30,11 +30,11 @@ struct Taps {
 };
 
 __device__ __forceinline__ Taps taps_exact(float m, int size) {
-  const float fl = floorf(m);
+  const float mc = clamp_coord(m, size);
+  const float fl = floorf(mc);
   Taps t;
-  t.f = fsub(m, fl);
-  const float cl = fminf(fmaxf(fl, -1.0f), (float)size);
-  const int i = (int)cl;
+  t.f = fsub(mc, fl);
+  const int i = (int)fl;
   t.i0 = min(max(i, 0), size - 1);
   t.i1 = min(max(i + 1, 0), size - 1);
   return t;
@@ -42,8 +42,7 @@ __device__ __forceinline__ Taps taps_exact(float m, int size) {
 
 // OpenCV's INTER_BITS=5 coordinate quantisation: q = cvRound(m*32), index q>>5, fraction q&31.
 __device__ __forceinline__ Taps taps_cv2(float m, int size) {
-  const float s = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
-  const int q = __float2int_rn(s);
+  const int q = cv_round_q5(m);
   const int i = q >> 5;
   Taps t;
   t.f = (float)(q & 31) * 0.03125f;

@@ -41,14 +41,14 @@ __device__ __forceinline__ Taps taps(float m, int size) {
   Taps t;
   int i;
   if (MODE == ATTWARP_CV2) {
-    const float s = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
-    const int q = __float2int_rn(s);      // cvRound
+    const int q = cv_round_q5(m);         // cvRound
     i = q >> 5;
     t.f = (float)(q & 31);
   } else {
-    const float fl = floorf(m);
-    t.f = fsub(m, fl);
-    i = (int)fminf(fmaxf(fl, -1.0f), (float)size);
+    const float mc = clamp_coord(m, size);
+    const float fl = floorf(mc);
+    t.f = fsub(mc, fl);
+    i = (int)fl;
   }
   t.i0 = min(max(i, 0), size - 1);
   t.i1 = min(max(i + 1, 0), size - 1);
@@ -386,8 +386,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       for (int j = 0; j < 4; ++j) {
         const int r = r0 + j, x = r / p.CS, c = r - x * p.CS;
         const float m = p.mx[(long long)b * p.Wo + x];
-        const float sc = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
-        const int q = __float2int_rn(sc);                           // cvRound
+        const int q = cv_round_q5(m);                               // cvRound
         const int i = q >> 5;
         const int i0 = min(max(i, 0), p.W - 1), i1 = min(max(i + 1, 0), p.W - 1);
         const unsigned kx = (i0 == i1) ? 0u : (unsigned)(q & 31);  // both taps on one pixel: weight of tap 1 is moot
@@ -404,8 +403,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
 
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   auto row_taps = [&](float m, int& i0, int& i1, unsigned& ky) {
-    const float sc = fminf(fmaxf(fmul(m, 32.0f), -2.0e9f), 2.0e9f);
-    const int q = __float2int_rn(sc);
+    const int q = cv_round_q5(m);
     const int i = q >> 5;
     i0 = min(max(i, 0), p.H - 1);
     i1 = min(max(i + 1, 0), p.H - 1);

@@ -210,7 +210,11 @@ ATTWARP_API int attwarp_axis_maps_from_attention(const void* att, int dtype, int
 /* ---- A12 / A13 tail: cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps,
  * AGW/new_method.py:268-271, MN/checkpoint_utils.py:195-198.
  * src [B,H,W,C] (HWC) or [B,C,H,W] (CHW), dtype F32 or U8 -> dst same layout with (H_out,W_out).
- * map_x [B,W_out], map_y [B,H_out] float32 source coordinates.  C <= 4. */
+ * map_x [B,W_out], map_y [B,H_out] float32 source coordinates.  C <= 4.
+ * Coordinates outside the image take the replicate border.  Non-finite / huge coordinates: mode CV2 follows
+ * cvRound(32 * m) of OpenCV's x86 builds (NaN, +-Inf and products outside int32 -> INT_MIN -> pixel 0, zero fraction,
+ * for either sign); mode EXACT clamps the coordinate to [-1, size] first (NaN counts as -1).  No output is NaN
+ * unless a source pixel is. */
 ATTWARP_API int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int layout, int B, int C, int H, int W,
                            int H_out, int W_out, const float* map_x, const float* map_y, int mode,
                            void* stream);

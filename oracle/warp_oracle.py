@@ -731,6 +731,10 @@ def _axis_taps(m: np.ndarray, size: int):
     fraction is taken BEFORE clamping (replicate border: both taps collapse on
     the edge pixel, the weight no longer matters)."""
     m = np.asarray(m, dtype=F32)
+    # the coordinate is clamped to [-1, size] first, NaN counting as -1 (C fmaxf semantics): non-finite and huge
+    # coordinates land on an edge pixel and never produce a NaN weight
+    m = np.where(np.isnan(m), F32(-1), m).astype(F32)
+    m = np.minimum(np.maximum(m, F32(-1)), F32(size)).astype(F32)
     fl = np.floor(m)
     frac = (m - fl).astype(F32)
     i0 = fl.astype(np.int64)
@@ -782,7 +786,15 @@ def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: 
 
 
 def _cv_round(v: np.ndarray) -> np.ndarray:
-    return np.rint(v.astype(F64)).astype(np.int64)     # cvRound: round half to even
+    """``cvRound(float)`` as OpenCV's x86 builds compute it (``cvtss2si`` / ``cvtps2dq`` in ``v_round``): round half to
+    even; a NaN or a value that does not fit a 32-bit integer gives INT_MIN ("integer indefinite") -- after ``>> 5``,
+    ``saturate_cast<short>`` and the replicate border that is pixel 0 with a zero fraction, for NaN, +-Inf and huge
+    coordinates of either sign."""
+    v = np.asarray(v, dtype=F32)
+    ok = (v >= F32(-2147483648.0)) & (v < F32(2147483648.0))          # False for NaN
+    with np.errstate(invalid="ignore"):
+        r = np.rint(np.where(ok, v, F32(0)).astype(F64)).astype(np.int64)
+    return np.where(ok, r, np.int64(-2147483648))
 
 
 def _remap_cv2_compat(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.ndarray:

@@ -169,16 +169,18 @@ static void axis_taps(const float* m, int n, int size, int mode, int* i0, int* i
   for (int x = 0; x < n; ++x) {
     int i;
     if (mode == 1) {
-      float s = m[x] * 32.0f;
-      s = s < -2.0e9f ? -2.0e9f : (s > 2.0e9f ? 2.0e9f : s);
-      const long q = lrintf(s);                 /* cvRound: round half to even (default rounding mode) */
+      const float s = m[x] * 32.0f;
+      /* cvRound on x86 (cvtss2si): round half to even; NaN or a value outside int32 gives INT_MIN */
+      const long q = (s >= -2147483648.0f && s < 2147483648.0f) ? lrintf(s) : -2147483648L;
       i = (int)(q >> 5);
       f[x] = (float)(q & 31) * 0.03125f;
     } else {
-      const float fl = floorf(m[x]);
-      f[x] = m[x] - fl;
-      float cl = fl < -1.0f ? -1.0f : fl; cl = cl > (float)size ? (float)size : cl;
-      i = (int)cl;
+      /* the coordinate is clamped to [-1, size] first (NaN counts as -1) */
+      float mc = (m[x] != m[x]) ? -1.0f : m[x];
+      mc = mc < -1.0f ? -1.0f : (mc > (float)size ? (float)size : mc);
+      const float fl = floorf(mc);
+      f[x] = mc - fl;
+      i = (int)fl;
     }
     i0[x] = clampi(i, 0, size - 1); i1[x] = clampi(i + 1, 0, size - 1);
   }

@@ -938,6 +938,42 @@ def test_remap_wide_rows_column_tiles(dev, shape, kind, mode):
     assert np.array_equal(got8, ref8)
 
 
+@pytest.mark.parametrize("shape", [(40, 56, 33, 47, 3, "hwc"), (336, 336, 336, 336, 3, "hwc"), (64, 1024, 50, 1024, 3, "chw"),
+                                   (30, 1100, 26, 1100, 4, "hwc"), (31, 29, 31, 29, 2, "chw")])
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_remap_non_finite_and_huge_coordinates(dev, shape, mode):
+    """NaN, +-Inf, +-1e30, +-3e9, the int32 edge of cvRound(32 m) and other out-of-range coordinates sprinkled over
+    both maps: every kernel family (generic, staged rows, plane split, column tiles; float32 and uint8, integer uint8
+    form) follows the oracle's conventions bit for bit (cv2: x86 cvRound -> INT_MIN -> pixel 0; exact: clamp to
+    [-1, size], NaN = -1) and no output is NaN.  (tools/fuzz_remap.py is the randomised long form of this test.)"""
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C, layout = shape
+    rng = np.random.default_rng(H * 7 + Wo)
+    B = 2
+    mx = (rng.random((B, Wo)) * W).astype(np.float32)
+    my = (rng.random((B, Ho)) * H).astype(np.float32)
+    sp = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 6.8e7, 67108860.0, -67108864.0, -67108868.0, 65536.0,
+                   -65536.0, W - 1, W - 0.5, -0.5, -1.0, -1.5, W + 0.25, 1 / 64, 3 / 64], np.float32)
+    for m in (mx, my):
+        k = max(4, m.size // 6)
+        m.reshape(-1)[rng.integers(0, m.size, k)] = rng.choice(sp, k)
+    mx[0, :len(sp)] = sp[:Wo][:len(sp)] if Wo >= len(sp) else mx[0, :len(sp)]
+    for dt in (np.float32, np.uint8):
+        img = rng.random((B, H, W, C), dtype=np.float32)
+        if dt == np.uint8:
+            img = (img * 255).astype(np.uint8)
+        with np.errstate(all="ignore"):
+            ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
+        assert np.isfinite(ref.astype(np.float64)).all()
+        x = T(img if layout == "hwc" else np.ascontiguousarray(img.transpose(0, 3, 1, 2)), dev)
+        for over in ({}, {"remap_variant": 1}, {"remap_variant": 2}):
+            with _lib.debug_override(**over):
+                got = N(cu.remap_separable(x, T(mx, dev), T(my, dev), mode=mode, channels_last=(layout == "hwc")))
+            if layout == "chw":
+                got = got.transpose(0, 2, 3, 1)
+            assert np.array_equal(got, ref), (shape, mode, dt.__name__, over)
+
+
 @pytest.mark.parametrize("R", [1, 5, 64])
 @pytest.mark.parametrize("mode", ["exact", "cv2"])
 def test_remap_rows_block_boundaries(dev, R, mode):

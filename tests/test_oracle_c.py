@@ -71,6 +71,46 @@ def test_c_remap(C, layout, mode):
 
 
 @pytest.mark.parametrize("mode", ["exact", "cv2"])
+def test_non_finite_and_huge_coordinates(C, mode):
+    """Coordinates no image has: the conventions both oracles (and the kernels) follow.  cv2: cvRound as OpenCV's x86
+    builds compute it -- NaN, +-Inf and products outside int32 give INT_MIN, i.e. pixel 0 with a zero fraction, for
+    either sign; exact: the coordinate is clamped to [-1, size] first, NaN counting as -1."""
+    rng = np.random.default_rng(6)
+    H, W = 9, 11
+    img = rng.random((H, W, 1), dtype=np.float32)
+    sp = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 6.8e7, 67108860.0, 65536.0, -65536.0, W - 1, W - 0.5,
+                   -0.5, -1.0, -1.5, W + 0.25, 1 / 64, 3 / 64], np.float32)
+    my = np.array([2.25], np.float32)
+    with np.errstate(all="ignore"):
+        out = O.remap_bilinear(img, sp, my, mode)[0, :, 0]
+    assert np.isfinite(out).all()
+    row = O.remap_bilinear(img, np.arange(W, dtype=np.float32), my, mode)[0, :, 0]       # the blended row itself
+    first, last = row[0], row[W - 1]
+    if mode == "cv2":
+        # 32 * 6.8e7 >= 2^31 -> INT_MIN -> pixel 0; 32 * 67108860 = 2147483520 fits -> far right -> last pixel;
+        # (-0.5, -1.5, W + 0.25: both taps on the edge pixel but fractional table weights, p*w0 + p*w1 -- within an ulp of p)
+        expect_first = [0, 1, 2, 3, 4, 5, 6, 7, 10, 14, 17]
+        expect_last = [8, 9, 11, 12]
+        np.testing.assert_allclose(out[[13, 15]], first, rtol=2e-7)
+        np.testing.assert_allclose(out[16], last, rtol=2e-7)
+    else:
+        expect_first = [0, 2, 4, 6, 10, 13, 14, 15]
+        expect_last = [1, 3, 5, 7, 8, 9, 11, 12, 16]
+    assert np.array_equal(out[expect_first], np.full(len(expect_first), first))
+    assert np.array_equal(out[expect_last], np.full(len(expect_last), last))
+    # the plain-C oracle follows the same conventions
+    assert np.array_equal(C.remap_bilinear(img, sp, my, "hwc", mode)[0, :, 0], out)
+    # uint8 sources too, and along the other axis
+    img8 = (img * 255).astype(np.uint8)
+    with np.errstate(all="ignore"):
+        o8 = O.remap_bilinear(np.ascontiguousarray(img8.transpose(1, 0, 2)), my, sp, mode)[:, 0, 0]
+    r8 = O.remap_bilinear(np.ascontiguousarray(img8.transpose(1, 0, 2)), my, np.arange(W, dtype=np.float32), mode)[:, 0, 0]
+    assert np.array_equal(o8[expect_first], np.full(len(expect_first), r8[0]))
+    assert np.array_equal(o8[expect_last], np.full(len(expect_last), r8[W - 1]))
+    assert np.array_equal(o8[[13, 15]], [r8[0]] * 2) and o8[16] == r8[W - 1]         # integer weights: exact
+
+
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
 def test_c_whole_path(C, mode):
     rng = np.random.default_rng(5)
     T, heads, kv, S = 3, 32, 640, 48
