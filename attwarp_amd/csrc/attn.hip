@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void mask_postproc_kernel(const float* __restri
     float v = x[k] / sd;
     v = fmul(v, coe);
     v = (float)(1.0 / (1.0 + exp(-(double)v)));
-    x[k] = fminf(fmaxf(v, 0.0f), 1.0f);
+    x[k] = (v != v) ? v : fminf(fmaxf(v, 0.0f), 1.0f);     // torch.clamp propagates NaN (a constant map: 0 / 0 above)
   }
   __syncthreads();
   // Conv2d(1,1,ks,padding=(ks-1)/2,padding_mode="replicate"), all weights 1/ks^2

@@ -355,6 +355,17 @@ def test_revise_mask(dev, golden):
     np.testing.assert_allclose(one, g["mask0_k5_c4"], rtol=0, atol=5e-7)
     with pytest.raises(AssertionError):
         ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
+    # a constant map: normalize("min") divides 0 by 0 and torch carries the NaN through sigmoid, clamp and the box
+    # filter (the up-sampled uint8 mask is then all 0 and the warp the identity) -- found by tools/fuzz_stages.py
+    flat = np.full((2, 24, 24), 0.3, np.float32)
+    flat[1] = g["masks"][0]
+    with np.errstate(all="ignore"):
+        ref_flat = O.revise_mask(flat, 3, 10)
+    got_flat = N(ae.revise_mask(T(flat, dev), 3, 10))
+    assert np.isnan(ref_flat[0]).all() and np.isnan(got_flat[0]).all()
+    assert np.abs(got_flat[1] - ref_flat[1]).max() <= 6e-8
+    up = N(ae.upsample_mask_lanczos(T(got_flat, dev), (64, 48)))
+    assert not up[0].any() and up[1].any()
 
 
 @pytest.mark.parametrize("variant", [-1, 1, 2])    # column-strip kernel (up-sampling) / two-kernel form / row-block fused kernel

@@ -1,0 +1,144 @@
+"""Dev tool: randomised differential run of the per-stage entry points against the numpy oracle (bit for bit unless a
+tolerance is written next to the stage): attention maps from uint8 / float32 / float64 attention with every transform
+(A13), PDF -> CDF -> maps chain with hostile densities (A8-A11), cdf repair / resample (A10), attention reduce with
+random geometry (A1/A2), LANCZOS mask up-sample vs the Pillow restatement (A4), revise_mask (A3), adaptive pool and
+gt_marginals (A5/A6), safe_softmax (A7).   usage: fuzz_stages.py [seconds per stage] [seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from attwarp_amd import checkpoint_utils as cu, attention_extraction as ae, new_method as nm, pipeline, model
+from oracle import warp_oracle as O
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+N = lambda t: t.detach().cpu().numpy()
+def run(name, gen):
+    t0 = time.time(); n = bad = 0
+    while time.time() - t0 < budget:
+        with np.errstate(all="ignore"):
+            r = gen()
+        if r is None: continue
+        ok, desc = r
+        n += 1
+        if not ok:
+            bad += 1
+            if bad <= 5: print("  MISMATCH", name, desc, flush=True)
+    print(f"{name:34s} {n:6d} cases  {bad:5d} mismatches", flush=True)
+
+def dim(lo=1, hi=1300):
+    r = rng.random()
+    if r < 0.4: return int(rng.integers(lo, 64))
+    if r < 0.8: return int(rng.integers(64, 400))
+    return int(rng.integers(400, hi))
+
+def g_att_maps():
+    B = int(rng.integers(1, 4)); h, w = dim(2), dim(2)
+    kind = rng.choice(["u8", "f32", "f64"])
+    if kind == "u8": att = rng.integers(0, 256, (B, h, w), dtype=np.uint8)
+    elif kind == "f32": att = (rng.random((B, h, w), dtype=np.float32) * 4 - 0.5).astype(np.float32)
+    else: att = rng.random((B, h, w)) * 4 - 0.5
+    r = rng.random()
+    if r < 0.15: att[0] = 0
+    elif r < 0.3: att[0, : h // 2] = 0
+    elif r < 0.4 and kind != "u8": att[0, rng.integers(0, h), rng.integers(0, w)] = rng.choice([np.nan, np.inf, 1e30, -5.0])
+    tr = rng.choice(["identity", "square", "sqrt", "exp", "log"]); inv = bool(rng.random() < 0.3)
+    nw, nh = dim(1, 1100), dim(1, 1100)
+    es, ed = float(rng.choice([1.0, 0.05, 3.0])), float(rng.choice([1.0, 50.0]))
+    mx, my = nm.attention_axis_maps(T(att), nw, nh, tr, es, ed, inv)
+    ok = True
+    if tr in ("identity", "square") and not inv:        # numpy's own summation orders: bit for bit
+        for b in range(B):
+            rx, ry = O.maps_from_attention(att[b], nw, nh, tr, es, ed, inv)
+            ok &= np.array_equal(N(mx)[b], rx, equal_nan=True) and np.array_equal(N(my)[b], ry, equal_nan=True)
+    else:                                               # device libm vs numpy libm: 1 ulp on exp / log / sqrt sums
+        for b in range(B):
+            rx, ry = O.maps_from_attention(att[b], nw, nh, tr, es, ed, inv)
+            for g, r_ in ((N(mx)[b], rx), (N(my)[b], ry)):
+                fin = np.isfinite(r_) & np.isfinite(g)
+                ok &= np.array_equal(np.isfinite(r_), np.isfinite(g)) and (not fin.any() or np.max(np.abs(g[fin] - r_[fin])) <= 2e-3 * max(1.0, np.max(np.abs(r_[fin]))) * 1e-3 + 1e-3)
+    return ok, (kind, B, h, w, tr, inv, nw, nh, es, ed)
+
+def g_pdf_chain():
+    B = int(rng.integers(1, 5)); W, H = dim(24), dim(24); Wo, Ho = dim(1), dim(1)
+    px = rng.random((B, 24), dtype=np.float32); py = rng.random((B, 24), dtype=np.float32)
+    r = rng.random()
+    if r < 0.2: px[0] = 0
+    elif r < 0.3: px[0, rng.integers(0, 24)] = rng.choice([np.nan, np.inf, -1.0, 1e30])
+    elif r < 0.5: px = (px ** 8).astype(np.float32)
+    px /= np.maximum(px.sum(1, keepdims=True), 1e-6); py /= py.sum(1, keepdims=True)
+    mx, my = pipeline.axis_maps_from_pdf(T(px), T(py), (H, W), (Ho, Wo))
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
+    rx, ry = O.maps_from_cdf(Fx, Fy, (Ho, Wo))
+    # the right-inverse matvec is float64 on both sides with the same table; maps: <= 2 ulp of the coordinate range
+    ok = np.allclose(N(mx), rx, rtol=0, atol=2e-4 * max(W, 1) / 1000 + 1e-4, equal_nan=True) and np.allclose(N(my), ry, rtol=0, atol=2e-4 * max(H, 1) / 1000 + 1e-4, equal_nan=True)
+    return ok, (B, W, H, Wo, Ho)
+
+def g_cdf_stages():
+    B = int(rng.integers(1, 4)); L = dim(2); L2 = dim(2)
+    p = rng.random((B, L), dtype=np.float32)
+    r = rng.random()
+    if r < 0.2: p[0] = 0
+    elif r < 0.4: p[0, rng.integers(0, L)] = rng.choice([np.nan, np.inf, -3.0])
+    elif r < 0.6: p = (p ** 12).astype(np.float32)
+    F = cu.cdf_from_density(T(p)); Fo = O.cdf_from_density(p)
+    ok = np.array_equal(N(F), Fo, equal_nan=True)
+    G = rng.random((B, L), dtype=np.float32); G.sort(axis=1)
+    if rng.random() < 0.5: G[:, L // 3: L // 2] = G[:, L // 3: L // 3 + 1]
+    ok &= np.array_equal(N(cu._make_strictly_increasing(T(G))), O.make_strictly_increasing(G), equal_nan=True)
+    ok &= np.allclose(N(cu.resample_cdf(T(G), L2)), O.resample_cdf(G, L2), rtol=3e-7, atol=1e-7, equal_nan=True)
+    return ok, (B, L, L2)
+
+def g_attn():
+    B = int(rng.integers(1, 5)); heads = int(rng.integers(1, 40)); ntok = int(rng.choice([576, 576, 64, 100, 577, 4, 1000]))
+    kv = ntok + int(rng.integers(0, 90)); q = int(rng.integers(1, 3))
+    dt = rng.choice([np.float32, np.float16])
+    a = rng.random((B, heads, q, kv), dtype=np.float32)
+    if rng.random() < 0.3: a = np.exp(rng.normal(0, 5, a.shape)).astype(np.float32); a /= a.sum(-1, keepdims=True)
+    a = a.astype(dt)
+    starts = [int(rng.integers(0, kv - ntok + 1)) for _ in range(B)]
+    ends = [s + ntok for s in starts]
+    hl = ae.BatchMaskHookLogger(model=None, device=dev)
+    hl.set_batch_image_token_ranges(starts, ends)
+    hl._process_attention(T(a))
+    ok = np.array_equal(N(hl.step_attentions[-1]), O.attn_reduce_step(a, starts, ends), equal_nan=True)
+    return ok, (B, heads, ntok, kv, q, dt.__name__, starts)
+
+def g_lanczos():
+    B = int(rng.integers(1, 4)); h, w = int(rng.integers(2, 40)), int(rng.integers(2, 40))
+    H, W = dim(1, 1200), dim(1, 1200)
+    m = rng.random((B, h, w), dtype=np.float32)
+    up = ae.upsample_mask_lanczos(T(m), (W, H))
+    ok = all(np.array_equal(N(up)[b], O.lanczos_resize_u8(O.mask_to_u8(m[b]), W, H)) for b in range(B))
+    return ok, (B, h, w, H, W)
+
+def g_pool_marg():
+    B = int(rng.integers(1, 3)); H, W = dim(24), dim(24)
+    A = (rng.random((B, 1, H, W), dtype=np.float32) * 3 - 0.5).astype(np.float32)
+    ok = np.array_equal(N(pipeline.adaptive_avg_pool2d(T(A))), O.adaptive_avg_pool24(A))
+    px, py = cu.gt_marginals(T(A)); pxo, pyo = O.gt_marginals(A)
+    ok &= np.array_equal(N(px), pxo) and np.array_equal(N(py), pyo)
+    return ok, (B, H, W)
+
+def g_revise_softmax():
+    B = int(rng.integers(1, 5)); n = int(rng.choice([24, 24, 16, 7, 32])); ks = int(rng.choice([1, 3, 5, 7])); coe = float(rng.choice([10.0, 1.0, 30.0]))
+    m = rng.random((B, n, n), dtype=np.float32)
+    if rng.random() < 0.2: m[0] = m[0, 0, 0]
+    got = N(ae.revise_mask(T(m), kernel_size=ks, enhance_coe=coe))
+    ref = np.stack([O.revise_mask(m[b], ks, coe) for b in range(B)])
+    ok = np.allclose(got, ref, rtol=0, atol=3e-7, equal_nan=True)              # device expf vs numpy: <= 1 ulp before the box filter
+    L = dim(2); x = (rng.standard_normal((B, L)) * 10).astype(np.float32)
+    if rng.random() < 0.4: x[0, rng.integers(0, L)] = rng.choice([np.nan, np.inf, -np.inf])
+    ok &= np.allclose(N(model.safe_softmax(T(x))), O.safe_softmax(x), rtol=3e-7, atol=1e-9)
+    return ok, (B, n, ks, coe, L)
+
+for name, gen in (("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
+                  ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),
+                  ("LANCZOS mask up-sample (A4)", g_lanczos), ("pool24 + gt_marginals (A5-A6)", g_pool_marg),
+                  ("revise_mask + safe_softmax (A3,A7)", g_revise_softmax)):
+    try:
+        run(name, gen)
+    except Exception as e:   # noqa: BLE001
+        print(f"{name}: EXCEPTION {type(e).__name__}: {e}", flush=True)
