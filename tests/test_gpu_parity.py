@@ -1871,3 +1871,19 @@ def test_overlapped_warp_equals_serial(dev):
     ow2 = pipeline.OverlappedWarp(imgs[1], rws[1], starts, channels_last=True)
     ow2.prime(); ow2.prime2()
     assert torch.equal(ow2.run(19), refs[1])
+
+
+def test_randomised_differential_runs(dev):
+    """A short run of the two fuzzers (tools/fuzz_remap.py, tools/fuzz_stages.py: random shapes, dtypes, layouts, modes,
+    hostile values; every stage entry point against the oracle): no mismatch.  The long runs behind DESIGN section 4 are
+    the same scripts with a larger time budget."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, args in (("fuzz_remap.py", ["6", "11"]), ("fuzz_stages.py", ["1", "11"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", script)] + args, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "MISMATCH" not in r.stdout and "EXCEPTION" not in r.stdout, r.stdout[-3000:]
+        lines = [l for l in r.stdout.splitlines() if "mismatches" in l]
+        assert lines and all(" 0 mismatches" in l for l in lines), r.stdout[-3000:]
+

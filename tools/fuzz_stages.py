@@ -134,7 +134,53 @@ def g_revise_softmax():
     ok &= np.allclose(N(model.safe_softmax(T(x))), O.safe_softmax(x), rtol=3e-7, atol=1e-9)
     return ok, (B, n, ks, coe, L)
 
-for name, gen in (("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
+def g_clip():
+    B = int(rng.integers(1, 3)); H, W = int(rng.integers(8, 700)), int(rng.integers(8, 700)); size = int(rng.choice([336, 224, 335, 64, 100]))
+    C = 3
+    img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+    pad = bool(rng.random() < 0.3)
+    got = N(pipeline.clip_preprocess(T(img), size, torch.float32, pad_to_square=pad))
+    ok = True
+    for b in range(B):
+        src = O.expand2square(img[b]) if pad else img[b]
+        ok &= np.array_equal(got[b], O.clip_preprocess(src, size))
+    return ok, (B, H, W, size, pad)
+
+def g_probe():
+    B = int(rng.integers(1, 4)); D = int(rng.choice([128, 64, 96])); Hkv = int(rng.choice([1, 2, 4, 8])); H = Hkv * int(rng.choice([1, 2, 4]))
+    ntok = int(rng.choice([576, 64, 100])); kv = ntok + int(rng.integers(8, 120))
+    dt = rng.choice([np.float16, np.float32])
+    q = rng.standard_normal((B, H, D)).astype(dt); k = rng.standard_normal((B, Hkv, kv, D)).astype(dt)
+    pads = np.array([int(rng.integers(0, 8)) for _ in range(B)], np.int32)
+    starts = np.array([int(rng.integers(int(pads[b]), kv - ntok + 1)) for b in range(B)], np.int32)
+    sc = float(D) ** -0.5
+    got = N(ae.probe_last_query(T(q), T(k), T(starts), ntok, T(pads), sc))
+    ok = np.array_equal(got, O.attn_probe_step(q, k, starts, ntok, sc, pads), equal_nan=True)
+    return ok, (B, H, Hkv, D, ntok, kv, dt.__name__)
+
+def g_mn_tail():
+    B = int(rng.integers(1, 5)); Lt = int(rng.integers(1, 40)); D = int(rng.choice([16, 100, 4096])); Ch = int(rng.choice([4, 16, 256])); Hh, Ww = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    tok = rng.standard_normal((B, Lt, D)).astype(np.float32); msk = (rng.random((B, Lt)) > 0.4).astype(np.float32)
+    if rng.random() < 0.2: msk[0] = 0
+    ok = np.array_equal(N(model.masked_token_mean(T(tok), T(msk[:, :, None]))), O.masked_token_mean(tok, msk))
+    v = rng.standard_normal((B, Ch, Hh, Ww)).astype(np.float32); gb = rng.standard_normal((B, 2 * Ch)).astype(np.float32)
+    vx, vy = model.film_axis_means(T(v), T(gb)); ox, oy = O.film_axis_means(v, gb)
+    ok &= np.array_equal(N(vx), ox) and np.array_equal(N(vy), oy)
+    return ok, (B, Lt, D, Ch, Hh, Ww)
+
+def g_chain_u8():
+    h, w = dim(8, 700), dim(8, 700); nw, nh = dim(4, 700), dim(4, 700)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    att = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    if rng.random() < 0.1: att[:] = 0
+    tr = rng.choice(["identity", "square"]); mode = rng.choice(["cv2", "exact"])
+    got = nm.warp_image_by_attention(img, att, nw, nh, transform=tr, exp_scale=1.0, exp_divisor=1.0, apply_inverse=False, mode=mode)
+    ok = np.array_equal(got, O.warp_image_by_attention(img, att, nw, nh, tr, mode=mode))
+    return ok, (h, w, nw, nh, tr, mode)
+
+for name, gen in (("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail),
+                  ("warp_image_by_attention chain", g_chain_u8),
+                  ("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
                   ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),
                   ("LANCZOS mask up-sample (A4)", g_lanczos), ("pool24 + gt_marginals (A5-A6)", g_pool_marg),
                   ("revise_mask + safe_softmax (A3,A7)", g_revise_softmax)):
