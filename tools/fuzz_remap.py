@@ -43,9 +43,22 @@ while time.time() - t0 < budget:
     if dt == np.uint8: img = (img * 255).astype(np.uint8)
     with np.errstate(all="ignore"):
         ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
-    x = torch.from_numpy(img if layout == "hwc" else np.ascontiguousarray(img.transpose(0, 3, 1, 2))).to(dev)
-    got = cu.remap_separable(x, torch.from_numpy(mx).to(dev), torch.from_numpy(my).to(dev), mode=mode,
-                             channels_last=(layout == "hwc")).cpu().numpy()
+    xh = img if layout == "hwc" else np.ascontiguousarray(img.transpose(0, 3, 1, 2))
+    view = rng.random()
+    if view < 0.25:          # a view at an element offset into a larger allocation: base pointer not 16-byte aligned
+        off = int(rng.integers(1, 8))
+        flat = torch.zeros(xh.size + 8, dtype=torch.from_numpy(xh).dtype, device=dev)
+        flat[off:off + xh.size] = torch.from_numpy(xh).to(dev).reshape(-1)
+        x = flat[off:off + xh.size].view(xh.shape)
+    elif view < 0.4:         # a non-contiguous view (every other image of a larger batch)
+        big = torch.from_numpy(np.repeat(xh, 2, axis=0)).to(dev)
+        x = big[::2]
+    else:
+        x = torch.from_numpy(xh).to(dev)
+    tmx, tmy = torch.from_numpy(mx).to(dev), torch.from_numpy(my).to(dev)
+    if rng.random() < 0.2:   # maps as column slices of a wider tensor (strided rows)
+        tmx = torch.cat([tmx, tmx], dim=1)[:, :mx.shape[1]]
+    got = cu.remap_separable(x, tmx, tmy, mode=mode, channels_last=(layout == "hwc")).cpu().numpy()
     if layout == "chw": got = got.transpose(0, 2, 3, 1)
     n += 1
     key = (layout, dt.__name__, mode, kind); fams[key] = fams.get(key, 0) + 1
