@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Randomised run of the ORACLE against the REFERENCE ITSELF (build container only: imports /root/reference by path
+with the stubs of make_golden.py; nothing here travels to the GPU box).  The committed goldens pin the oracle on a few
+dozen hand-picked inputs; this script throws random and hostile inputs (zeros, constants, NaN, Inf, negatives, tiny
+densities, ties) at every stage the reference can run on the CPU and compares with the tolerances of
+tests/test_oracle_golden.py.   usage: python tests/golden/fuzz_reference.py [seconds per stage] [seed]"""
+import os, sys, time
+import numpy as np, torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, HERE)
+import make_golden as MG
+from oracle import warp_oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+MG._install_stubs()
+torch.set_num_threads(1)
+new_method = MG._load("ref_new_method", os.path.join(MG.AGW, "new_method.py"))
+ckpt = MG._load("ref_checkpoint_utils", os.path.join(MG.MN, "checkpoint_utils.py"))
+model = MG._load("ref_model", os.path.join(MG.MN, "model.py"))
+sys.path.insert(0, os.path.join(MG.AGW, "attention_extraction"))
+llava = MG._load("ref_llava", os.path.join(MG.AGW, "attention_extraction", "llava.py"))
+CAP = MG.CAPTURED
+
+def run(name, gen):
+    t0 = time.time(); n = bad = 0
+    while time.time() - t0 < budget:
+        with np.errstate(all="ignore"):
+            r = gen()
+        if r is None: continue
+        ok, desc = r
+        n += 1
+        if not ok:
+            bad += 1
+            if bad <= 5: print("  MISMATCH", name, desc, flush=True)
+    print(f"{name:40s} {n:6d} cases  {bad:5d} mismatches", flush=True)
+    return bad
+
+def close(a, b, rtol, atol=0.0):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    if a.shape != b.shape: return False
+    nan = np.isnan(a) | np.isnan(b)
+    if not np.array_equal(np.isnan(a), np.isnan(b)): return False
+    inf = np.isinf(a) | np.isinf(b)
+    if not np.array_equal(a[inf & ~nan], b[inf & ~nan]): return False
+    f = ~nan & ~inf
+    return bool(np.all(np.abs(a[f] - b[f]) <= atol + rtol * np.abs(b[f])))
+
+def g_attn():
+    B = int(rng.integers(1, 4)); heads = int(rng.integers(1, 34)); ntok = int(rng.choice([576, 24, 100])); kv = ntok + int(rng.integers(0, 70)); q = int(rng.integers(1, 4))
+    a = rng.random((B, heads, q, kv), dtype=np.float32)
+    if rng.random() < 0.3: a = np.exp(rng.normal(0, 5, a.shape)).astype(np.float32); a /= a.sum(-1, keepdims=True)
+    if rng.random() < 0.1: a[0, 0] = 0
+    starts = [int(rng.integers(0, kv - ntok + 1)) for _ in range(B)]; ends = [s + ntok for s in starts]
+    lg = llava.BatchMaskHookLogger(model=None, device="cpu", layer_index=20)
+    lg.set_batch_image_token_ranges(starts, ends)
+    lg._process_attention(torch.from_numpy(a))
+    ref = lg.step_attentions[-1].numpy()
+    got = O.attn_reduce_step(a, starts, ends)
+    ok = close(got, ref, 1e-6, 1e-12)          # torch accumulates the row sums and the head mean in float32: a few ulps
+    rel = float(np.nanmax(np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30))) if not ok else 0.0
+    return ok, (B, heads, ntok, kv, q, "max rel", rel)
+
+def g_revise():
+    n = 24; ks = int(rng.choice([1, 3, 5])); coe = float(rng.choice([10.0, 1.0, 30.0]))
+    m = rng.random((n, n), dtype=np.float32)
+    r = rng.random()
+    if r < 0.15: m[:] = m[0, 0]
+    elif r < 0.3: m = (m ** 6).astype(np.float32)
+    ref = llava.revise_mask(torch.from_numpy(m.copy()), kernel_size=ks, enhance_coe=coe).detach().numpy()
+    got = O.revise_mask(m, ks, coe)
+    # float32 mean / std in torch vs float64 in the oracle: ~1e-7 relative on the standardised value, times the
+    # enhance coefficient, times the sigmoid's slope (<= 1/4)
+    ok = close(got, ref.reshape(n, n), 0, 6e-7 * max(1.0, coe / 3))
+    err = float(np.nanmax(np.abs(got - ref.reshape(n, n)))) if not ok else 0.0
+    return ok, (ks, coe, float(m.min()), float(m.max()), "max abs", err)
+
+def g_marg_softmax():
+    B = int(rng.integers(1, 4)); H, W = int(rng.integers(1, 70)), int(rng.integers(1, 70))
+    A = (rng.standard_normal((B, 1, H, W)) * 2).astype(np.float32)
+    r = rng.random()
+    if r < 0.15: A[0] = -1.0
+    elif r < 0.3: A[0, 0, 0, 0] = rng.choice([np.nan, np.inf])
+    px, py = ckpt.gt_marginals(torch.from_numpy(A.copy()))
+    ox, oy = O.gt_marginals(A)
+    ok = close(ox, px.numpy(), 6e-7, 1e-9) and close(oy, py.numpy(), 6e-7, 1e-9)
+    L = int(rng.integers(2, 60)); x = (rng.standard_normal((B, L)) * 8).astype(np.float32)
+    r = rng.random()
+    if r < 0.3: x[0, rng.integers(0, L)] = rng.choice([np.nan, np.inf, -np.inf])
+    elif r < 0.4: x[0] = -np.inf
+    ok &= close(O.safe_softmax(x), model.safe_softmax(torch.from_numpy(x.copy()), dim=1, eps=1e-6).numpy(), 6e-7, 1e-9)
+    return ok, (B, H, W, L)
+
+def g_pdf_cdf():
+    B = int(rng.integers(1, 4)); L = int(rng.choice([24, 50, 336, 500, 97]))
+    y = rng.random((B, 24), dtype=np.float32); y /= y.sum(1, keepdims=True)
+    x_ref = ckpt.upsample_pdf_right_inverse(torch.from_numpy(y.copy()), L).numpy() if L >= 24 else None
+    ok = True
+    if x_ref is not None:
+        ok &= close(O.upsample_pdf_right_inverse(y, L), x_ref, 0, 4e-7 * max(1e-6, float(np.abs(x_ref).max())) * 4)
+    p = rng.random((B, L), dtype=np.float32)
+    r = rng.random()
+    if r < 0.15: p[0] = 0
+    elif r < 0.4: p[0, rng.integers(0, L)] = rng.choice([np.nan, np.inf, -2.0])
+    elif r < 0.6: p = (p ** 10).astype(np.float32)
+    ok &= close(O.cdf_from_density(p), ckpt.cdf_from_density(torch.from_numpy(p.copy())).numpy(), 0, 2.5e-7)
+    F = np.sort(rng.random((B, 24), dtype=np.float32), axis=1)
+    r = rng.random()
+    if r < 0.3: F[0, 5:9] = F[0, 5]
+    elif r < 0.5: F[0, 3] = F[0, 2] - 0.05
+    elif r < 0.6: F[0, 10] = np.nan
+    ok &= close(O.make_strictly_increasing(F), ckpt._make_strictly_increasing(torch.from_numpy(F.copy())).numpy(), 3e-7, 1e-7)
+    L2 = int(rng.choice([336, 100, 1024]))
+    ok &= close(O.resample_cdf(F, L2), ckpt.resample_cdf(torch.from_numpy(F.copy()), L2).numpy(), 3e-7, 2e-7)
+    return ok, (B, L, L2)
+
+def g_maps_cdf():
+    H, W = int(rng.integers(24, 400)), int(rng.integers(24, 400))
+    out = None if rng.random() < 0.4 else (int(rng.integers(2, 500)), int(rng.integers(2, 500)))
+    p = rng.random((1, W), dtype=np.float32); q = rng.random((1, H), dtype=np.float32)
+    r = rng.random()
+    if r < 0.3: p[0, W // 4: W // 2] = 0
+    elif r < 0.4: p[0] = 0
+    Fx = ckpt.cdf_from_density(torch.from_numpy(p)); Fy = ckpt.cdf_from_density(torch.from_numpy(q))
+    ckpt.warp_from_cdf_torch(torch.zeros(1, 1, H, W), Fx, Fy, out)
+    mx_ref, my_ref = CAP["map_x"][0].copy(), CAP["map_y"][:, 0].copy()
+    ox, oy = O.maps_from_cdf(Fx.numpy(), Fy.numpy(), out if out else (H, W))
+    return (np.array_equal(ox[0], mx_ref, equal_nan=True) and np.array_equal(oy[0], my_ref, equal_nan=True)), (H, W, out)
+
+def g_maps_att():
+    h, w = int(rng.integers(2, 200)), int(rng.integers(2, 200)); nw, nh = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+    kind = rng.choice(["u8", "f32", "f64"])
+    if kind == "u8": att = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif kind == "f32": att = (rng.random((h, w), dtype=np.float32) * 3 - 0.4).astype(np.float32)
+    else: att = rng.standard_normal((h, w))
+    r = rng.random()
+    if r < 0.1: att[:] = 0
+    elif r < 0.2: att[: h // 2] = 0
+    elif r < 0.3 and kind != "u8": att[rng.integers(0, h), rng.integers(0, w)] = rng.choice([np.nan, np.inf, 1e30])
+    tr = rng.choice(["identity", "square", "sqrt", "exp", "log", "bogus"]); inv = bool(rng.random() < 0.4)
+    es, ed = float(rng.choice([1.0, 0.01, 2.0])), float(rng.choice([1.0, 2.0, 50.0]))
+    new_method.set_transform_function(tr, es, ed, inv)
+    new_method.warp_image_by_attention(np.zeros((h, w, 3), np.uint8), att, nw, nh)
+    mx_ref, my_ref = CAP["map_x"][0].copy(), CAP["map_y"][:, 0].copy()
+    ox, oy = O.maps_from_attention(att, nw, nh, tr if tr != "bogus" else "identity", es, ed, inv)
+    return (np.array_equal(ox, mx_ref, equal_nan=True) and np.array_equal(oy, my_ref, equal_nan=True)), (kind, h, w, nw, nh, tr, inv, es, ed)
+
+total = 0
+for name, gen in (("A1 _process_attention", g_attn), ("A3 revise_mask", g_revise), ("A6/A7 gt_marginals, safe_softmax", g_marg_softmax),
+                  ("A8-A10 pdf / cdf / repair / resample", g_pdf_cdf), ("A11 maps of warp_from_cdf_torch", g_maps_cdf),
+                  ("A13 maps of warp_image_by_attention", g_maps_att)):
+    try:
+        total += run(name, gen)
+    except Exception as e:   # noqa: BLE001
+        import traceback; traceback.print_exc()
+        print(f"{name}: EXCEPTION {type(e).__name__}: {e}", flush=True); total += 1
+sys.exit(1 if total else 0)

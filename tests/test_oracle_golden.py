@@ -1,5 +1,6 @@
 """Pin the CPU oracle (oracle/warp_oracle.py) to the golden vectors captured
 from the reference itself (tests/golden/make_golden.py).  CPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -433,3 +434,19 @@ def test_config1_single_image_chain_vs_reference(golden):
         out = O.warp_image_by_attention(img[..., ::-1].copy(), g["mota"], n, n)
         assert out.shape == (n, n, 3) and out.dtype == np.uint8
         assert np.array_equal(out, O.remap_bilinear(img[..., ::-1].copy(), g[f"mx_{n}"], g[f"my_{n}"]))
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("ATTWARP_REFERENCE", "/root/reference")),
+                    reason="the reference checkout exists in the build container only")
+def test_oracle_vs_reference_randomised():
+    """tests/golden/fuzz_reference.py: the oracle against the reference ITSELF (imported by path with the stubs of
+    make_golden.py) on random and hostile inputs -- zeros, constants, NaN, Inf, negatives, ties -- for every stage the
+    reference can run on the CPU (A1, A3, A6-A11, A13; maps bit for bit).  Skipped where the reference is absent (the
+    GPU box); the committed goldens are the portable pin."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "golden", "fuzz_reference.py"), "1.5", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout and "EXCEPTION" not in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.stdout.count(" 0 mismatches") == 6, r.stdout[-3000:]
+
