@@ -188,8 +188,25 @@ def g_blend_mask():
     # (one level at one of the 576 mask pixels reaches <= 6 % of the up-sampled pixels, by <= 2 levels near the lobes)
     return (d.max() <= 2 and (d > 0).mean() < 0.08), (W, H, ks, coe, int(d.max()), float((d > 0).mean()))
 
+def g_marginalnet():
+    from attwarp_amd import model as ours
+    dv, dtx, hid = int(rng.integers(4, 40)), int(rng.integers(4, 40)), int(rng.integers(2, 24))
+    B, Lt = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+    fh, fw = int(rng.integers(3, 26)), int(rng.integers(3, 26)); H, W = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    ref_net = model.MarginalNet(d_vis_in=dv, d_txt_in=dtx, hidden=hid).eval()
+    net = ours.MarginalNet(dv, dtx, hid).eval()
+    net.load_state_dict(ref_net.state_dict())                       # same parameter names and shapes
+    fmap = torch.randn(B, dv, fh, fw); tok = torch.randn(B, Lt, dtx); msk = (torch.rand(B, Lt, 1) > 0.4).float()
+    if rng.random() < 0.2: msk[0] = 0
+    with torch.no_grad():
+        px, py = ref_net(fmap, H, W, tok, msk)
+        lx, ly = net.forward_logits(fmap, H, W, tok, msk)
+    ok = close(O.safe_softmax(lx.numpy()), px.numpy(), 2e-6, 1e-9) and close(O.safe_softmax(ly.numpy()), py.numpy(), 2e-6, 1e-9)
+    return ok, (dv, dtx, hid, B, Lt, fh, fw, H, W)
+
 total = 0
-for name, gen in (("Pillow LANCZOS / BICUBIC (A4, f3)", g_pillow), ("blend_mask mask branch (A3+A4)", g_blend_mask),
+for name, gen in (("MarginalNet forward (f1)", g_marginalnet), ("Pillow LANCZOS / BICUBIC (A4, f3)", g_pillow), ("blend_mask mask branch (A3+A4)", g_blend_mask),
                   ("A1 _process_attention", g_attn), ("A3 revise_mask", g_revise), ("A6/A7 gt_marginals, safe_softmax", g_marg_softmax),
                   ("A8-A10 pdf / cdf / repair / resample", g_pdf_cdf), ("A11 maps of warp_from_cdf_torch", g_maps_cdf),
                   ("A13 maps of warp_image_by_attention", g_maps_att)):

@@ -448,5 +448,5 @@ def test_oracle_vs_reference_randomised():
     r = subprocess.run([sys.executable, os.path.join(here, "golden", "fuzz_reference.py"), "1.5", "7"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout and "EXCEPTION" not in r.stdout, (r.stdout[-3000:], r.stderr[-2000:])
-    assert r.stdout.count(" 0 mismatches") == 8, r.stdout[-3000:]
+    assert r.stdout.count(" 0 mismatches") == 9, r.stdout[-3000:]
 
