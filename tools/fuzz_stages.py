@@ -168,6 +168,19 @@ def g_mn_tail():
     ok &= np.array_equal(N(vx), ox) and np.array_equal(N(vy), oy)
     return ok, (B, Lt, D, Ch, Hh, Ww)
 
+def g_marginalnet():
+    dv, dtx, hid = int(rng.integers(4, 40)), int(rng.integers(4, 40)), int(rng.integers(2, 24))
+    B, Lt = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+    fh, fw = int(rng.integers(3, 26)), int(rng.integers(3, 26)); H, W = (fh, fw) if rng.random() < 0.5 else (int(rng.integers(3, 30)), int(rng.integers(3, 30)))
+    torch.manual_seed(int(rng.integers(0, 1 << 30)))
+    net = model.MarginalNet(dv, dtx, hid).to(dev).eval()
+    fmap = torch.randn(B, dv, fh, fw, device=dev); tok = torch.randn(B, Lt, dtx, device=dev); msk = (torch.rand(B, Lt, 1, device=dev) > 0.4).float()
+    with torch.no_grad():
+        px, py = net(fmap, H, W, tok, msk)                                  # library GEMMs + the fused HIP tail
+        lx, ly = net.forward_logits(fmap, H, W, tok, msk)                   # all stock ops
+    ok = np.allclose(N(px), O.safe_softmax(N(lx)), rtol=3e-6, atol=1e-9) and np.allclose(N(py), O.safe_softmax(N(ly)), rtol=3e-6, atol=1e-9)
+    return ok, (dv, dtx, hid, B, Lt, fh, fw, H, W)
+
 def g_chain_u8():
     h, w = dim(8, 700), dim(8, 700); nw, nh = dim(4, 700), dim(4, 700)
     img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -178,7 +191,7 @@ def g_chain_u8():
     ok = np.array_equal(got, O.warp_image_by_attention(img, att, nw, nh, tr, mode=mode))
     return ok, (h, w, nw, nh, tr, mode)
 
-for name, gen in (("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail),
+for name, gen in (("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
                   ("warp_image_by_attention chain", g_chain_u8),
                   ("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
                   ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),
