@@ -288,7 +288,82 @@ def make_marginalnet_full_golden(model):
     np.savez_compressed(os.path.join(OUT, "marginalnet_full.npz"), **out)
 
 
+def make_random_cases(new_method, ckpt, llava):
+    """Randomised, partly hostile cases through the reference (complements the hand-picked goldens; the long-form
+    version of this is fuzz_reference.py).  Inputs are smooth + sparse so that the file compresses; stored: inputs and
+    the reference's outputs only."""
+    rng = np.random.default_rng(4242)
+    out = {}
+    names = []
+    # ---- A13: maps of warp_image_by_attention (bit-exact target) ----
+    for i in range(48):
+        h, w = int(rng.integers(2, 70)), int(rng.integers(2, 90)); nw, nh = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        kind = ["u8", "f32", "f64"][i % 3]
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 0.5 + 0.5 * np.sin(xx / (3.0 + i % 7)) * np.cos(yy / (2.0 + i % 5))
+        base[rng.integers(0, h), rng.integers(0, w)] += 4.0
+        if kind == "u8": att = np.clip(base * 60, 0, 255).astype(np.uint8)
+        elif kind == "f32": att = (base - 0.3).astype(np.float32)
+        else: att = (base - 0.6).astype(np.float64)
+        r = i % 12
+        if r == 3: att[:] = 0
+        elif r == 5: att[: h // 2] = 0
+        elif r == 7 and kind != "u8": att[h // 2, w // 2] = np.nan
+        elif r == 9 and kind != "u8": att[0, 0] = np.inf
+        elif r == 11 and kind != "u8": att[:] = -1.0
+        tr = ["identity", "square", "sqrt", "exp", "log", "bogus"][i % 6]; inv = bool((i // 6) % 2)
+        es, ed = [(1.0, 1.0), (0.01, 2.0), (2.0, 50.0)][i % 3]
+        new_method.set_transform_function(tr, es, ed, inv)
+        with np.errstate(all="ignore"):
+            new_method.warp_image_by_attention(np.zeros((h, w, 3), np.uint8), att, nw, nh)
+        key = f"a13_{i}"
+        out[key + "_att"] = att; out[key + "_mx"] = CAPTURED["map_x"][0].copy(); out[key + "_my"] = CAPTURED["map_y"][:, 0].copy()
+        out[key + "_par"] = np.array([nw, nh, ["identity", "square", "sqrt", "exp", "log", "bogus"].index(tr), int(inv), es, ed])
+        names.append(key)
+    # ---- A9 + A11: cdf_from_density -> maps of warp_from_cdf_torch (bit-exact target) ----
+    for i in range(40):
+        H, W = int(rng.integers(24, 160)), int(rng.integers(24, 200))
+        osz = None if i % 3 == 0 else (int(rng.integers(2, 260)), int(rng.integers(2, 260)))
+        p = (0.2 + np.abs(np.sin(np.arange(W) / (2.0 + i % 9)))).astype(np.float32); q = (0.1 + np.abs(np.cos(np.arange(H) / (3.0 + i % 4)))).astype(np.float32)
+        r = i % 10
+        if r == 1: p[W // 4: W // 2] = 0
+        elif r == 3: p[:] = 0
+        elif r == 5: q[: H // 3] = 0; q[-3:] = 0
+        elif r == 7: p[W // 2] = np.nan
+        elif r == 9: p = (p ** 12).astype(np.float32)
+        Fx = ckpt.cdf_from_density(torch.from_numpy(p[None].copy())); Fy = ckpt.cdf_from_density(torch.from_numpy(q[None].copy()))
+        ckpt.warp_from_cdf_torch(torch.zeros(1, 1, H, W), Fx, Fy, osz)
+        key = f"a11_{i}"
+        out[key + "_p"] = p; out[key + "_q"] = q; out[key + "_Fx"] = Fx.numpy()[0]; out[key + "_Fy"] = Fy.numpy()[0]
+        out[key + "_mx"] = CAPTURED["map_x"][0].copy(); out[key + "_my"] = CAPTURED["map_y"][:, 0].copy()
+        out[key + "_out"] = np.array(osz if osz else (H, W))
+        names.append(key)
+    # ---- A3: revise_mask incl. a constant map ----
+    for i in range(12):
+        yy, xx = np.mgrid[0:24, 0:24]
+        m = (0.5 + 0.45 * np.sin(xx / (1.5 + i)) * np.cos(yy / (2.5 + i % 3))).astype(np.float32)
+        if i == 4: m[:] = 0.25
+        ks, coe = [(3, 10.0), (5, 4.0), (1, 30.0)][i % 3]
+        with np.errstate(all="ignore"):
+            rev = llava.revise_mask(torch.from_numpy(m.copy()), kernel_size=ks, enhance_coe=coe).detach().numpy().reshape(24, 24)
+        key = f"a3_{i}"
+        out[key + "_m"] = m; out[key + "_rev"] = rev; out[key + "_par"] = np.array([ks, coe])
+        names.append(key)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "random_cases.npz"), **out)
+    print("random_cases.npz", os.path.getsize(os.path.join(OUT, "random_cases.npz")) / 1024, "KiB,", len(names), "cases")
+
+
 def main():
+    if "--only-random" in sys.argv:
+        _install_stubs()
+        torch.set_num_threads(1)
+        new_method = _load("ref_new_method", os.path.join(AGW, "new_method.py"))
+        ckpt = _load("ref_checkpoint_utils", os.path.join(MN, "checkpoint_utils.py"))
+        sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
+        llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
+        make_random_cases(new_method, ckpt, llava)
+        return
     if "--only-mnfull" in sys.argv:
         _install_stubs()
         torch.set_num_threads(1)
@@ -490,6 +565,8 @@ def main():
                         **{"sd|" + k: v for k, v in sd.items()})
     n_full = sum(p.numel() for p in model.MarginalNet(1024, 4096, 256).parameters())
     print("MarginalNet(1024,4096,256) params:", n_full)
+
+    make_random_cases(new_method, ckpt, llava)
 
     tot = 0
     for f in sorted(os.listdir(OUT)):

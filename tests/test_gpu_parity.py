@@ -708,6 +708,42 @@ def test_maps_from_attention_vs_reference_golden(dev, golden):
     assert n_diff <= 1e-3 * n_elem, (n_diff, n_elem)
 
 
+def test_kernels_vs_random_reference_cases(dev, golden):
+    """The kernels against tests/golden/random_cases.npz -- 100 randomised, partly hostile cases that make_golden.py ran
+    through the REFERENCE (no oracle in between): A13 maps bit for bit (exp / log: the device libm, one float32 ulp on
+    < 0.1 % of the entries), A9 CDFs within 2.5e-7 and the A11 maps of the reference's own CDFs bit for bit, A3 within
+    the float32-vs-float64 reduction tolerance, the constant map NaN for NaN."""
+    from attwarp_amd import new_method as nm, checkpoint_utils as cu, attention_extraction as ae
+    g = golden("random_cases")
+    trs = ["identity", "square", "sqrt", "exp", "log", "bogus"]
+    n_elem = n_diff = 0
+    for key in [str(k) for k in g["names"]]:
+        if key.startswith("a13_"):
+            nw, nh, ti, inv, es, ed = g[key + "_par"]
+            tr = trs[int(ti)]
+            mx, my = nm.attention_axis_maps(T(g[key + "_att"], dev)[None], int(nw), int(nh), tr, float(es), float(ed), bool(inv))
+            for got, ref in ((N(mx)[0], g[key + "_mx"]), (N(my)[0], g[key + "_my"])):
+                if tr in ("identity", "square", "sqrt", "bogus"):
+                    assert np.array_equal(got, ref, equal_nan=True), key
+                    continue
+                fin = np.isfinite(ref)
+                assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+                n_elem += fin.sum(); n_diff += (got[fin] != ref[fin]).sum()
+                np.testing.assert_allclose(got[fin], ref[fin], rtol=2.5e-7, atol=1e-30, err_msg=key)
+        elif key.startswith("a11_"):
+            Fx = cu.cdf_from_density(T(g[key + "_p"][None], dev)); Fy = cu.cdf_from_density(T(g[key + "_q"][None], dev))
+            np.testing.assert_allclose(N(Fx)[0], g[key + "_Fx"], rtol=0, atol=2.5e-7, err_msg=key)
+            np.testing.assert_allclose(N(Fy)[0], g[key + "_Fy"], rtol=0, atol=2.5e-7, err_msg=key)
+            mx, my = cu.axis_maps_from_cdf(T(g[key + "_Fx"][None], dev), T(g[key + "_Fy"][None], dev), tuple(int(v) for v in g[key + "_out"]))
+            assert np.array_equal(N(mx)[0], g[key + "_mx"], equal_nan=True) and np.array_equal(N(my)[0], g[key + "_my"], equal_nan=True), key
+        else:
+            ks, coe = g[key + "_par"]
+            rev = N(ae.revise_mask(T(g[key + "_m"], dev), int(ks), float(coe)))
+            assert np.array_equal(np.isnan(rev), np.isnan(g[key + "_rev"])), key
+            np.testing.assert_allclose(rev, g[key + "_rev"], rtol=0, atol=6e-7 * max(1.0, float(coe) / 3), err_msg=key)
+    assert n_diff <= 2e-3 * max(n_elem, 1), (n_diff, n_elem)
+
+
 @pytest.mark.parametrize("hw", [(1024, 1024), (500, 333), (129, 1000), (7, 5)])
 def test_maps_from_attention_bit_exact_vs_numpy_order(dev, hw):
     """Sizes whose pairwise tree is irregular (leaf lengths 80/88/..., tails, n < 8)."""

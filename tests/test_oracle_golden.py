@@ -436,6 +436,34 @@ def test_config1_single_image_chain_vs_reference(golden):
         assert np.array_equal(out, O.remap_bilinear(img[..., ::-1].copy(), g[f"mx_{n}"], g[f"my_{n}"]))
 
 
+def test_oracle_vs_random_reference_cases(golden):
+    """tests/golden/random_cases.npz: 100 randomised, partly hostile cases run through the reference by
+    make_golden.py (zero / half-empty / NaN / Inf / negative attention, zero and spiky densities, a constant mask)."""
+    g = golden("random_cases")
+    trs = ["identity", "square", "sqrt", "exp", "log", "bogus"]
+    for key in [str(k) for k in g["names"]]:
+        if key.startswith("a13_"):
+            nw, nh, ti, inv, es, ed = g[key + "_par"]
+            tr = trs[int(ti)]
+            with np.errstate(all="ignore"):
+                mx, my = O.maps_from_attention(g[key + "_att"], int(nw), int(nh), tr if tr != "bogus" else "identity",
+                                               float(es), float(ed), bool(inv))
+            assert np.array_equal(mx, g[key + "_mx"], equal_nan=True) and np.array_equal(my, g[key + "_my"], equal_nan=True), key
+        elif key.startswith("a11_"):
+            with np.errstate(all="ignore"):
+                Fx = O.cdf_from_density(g[key + "_p"][None]); Fy = O.cdf_from_density(g[key + "_q"][None])
+            np.testing.assert_allclose(Fx[0], g[key + "_Fx"], rtol=0, atol=2.5e-7, err_msg=key)
+            np.testing.assert_allclose(Fy[0], g[key + "_Fy"], rtol=0, atol=2.5e-7, err_msg=key)
+            mx, my = O.maps_from_cdf(g[key + "_Fx"][None], g[key + "_Fy"][None], tuple(int(v) for v in g[key + "_out"]))
+            assert np.array_equal(mx[0], g[key + "_mx"], equal_nan=True) and np.array_equal(my[0], g[key + "_my"], equal_nan=True), key
+        else:
+            ks, coe = g[key + "_par"]
+            with np.errstate(all="ignore"):
+                rev = O.revise_mask(g[key + "_m"], int(ks), float(coe))
+            assert np.array_equal(np.isnan(rev), np.isnan(g[key + "_rev"])), key
+            np.testing.assert_allclose(rev, g[key + "_rev"], rtol=0, atol=6e-7 * max(1.0, float(coe) / 3), err_msg=key)
+
+
 @pytest.mark.skipif(not os.path.isdir(os.environ.get("ATTWARP_REFERENCE", "/root/reference")),
                     reason="the reference checkout exists in the build container only")
 def test_oracle_vs_reference_randomised():
