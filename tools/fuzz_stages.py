@@ -181,6 +181,32 @@ def g_marginalnet():
     ok = np.allclose(N(px), O.safe_softmax(N(lx)), rtol=3e-6, atol=1e-9) and np.allclose(N(py), O.safe_softmax(N(ly)), rtol=3e-6, atol=1e-9)
     return ok, (dv, dtx, hid, B, Lt, fh, fw, H, W)
 
+def g_stack_chain():
+    """attention stack -> warped batch (the bench's path) against the oracle stage by stage, every size a multiple of
+    nothing in particular; float32 and float16 rows, both layouts and modes."""
+    B = int(rng.integers(1, 4)); Tn = int(rng.integers(1, 6)); heads = int(rng.integers(1, 9)); kv = 576 + int(rng.integers(0, 70))
+    H, W = int(rng.integers(24, 120)), int(rng.integers(24, 120))
+    osz = None if rng.random() < 0.5 else (int(rng.integers(4, 130)), int(rng.integers(4, 130)))
+    dt = np.float32 if rng.random() < 0.6 else np.float16
+    rows = rng.random((Tn, B, heads, kv), dtype=np.float32)
+    if rng.random() < 0.3: rows = np.exp(rng.normal(0, 3, rows.shape)).astype(np.float32)
+    rows = (rows / rows.sum(-1, keepdims=True)).astype(dt)
+    starts = np.array([int(rng.integers(0, kv - 576 + 1)) for _ in range(B)], np.int32)
+    cl = bool(rng.random() < 0.5); mode = str(rng.choice(["cv2", "exact"]))
+    img = rng.random((B, H, W, 3), dtype=np.float32)
+    x = T(img if cl else img.transpose(0, 3, 1, 2))
+    got = N(pipeline.warp_from_attention_stack(x, T(rows), T(starts), osz, channels_last=cl, mode=mode))
+    if not cl: got = got.transpose(0, 2, 3, 1)
+    att = O.attn_reduce_stack(rows, starts).astype(np.float32).reshape(B, 1, 24, 24)
+    px, py = O.gt_marginals(att)
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0)); Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
+    mx, my = O.maps_from_cdf(Fx, Fy, osz if osz else (H, W))
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
+    # (the right-inverse matvec of the oracle is float64 numpy, the kernel's an ordered float64 loop: same table, <= 1 ulp
+    #  of a float32 density, which may move a map entry by an ulp and a pixel by |grad| * 2^-17)
+    ok = np.allclose(got, ref, rtol=0, atol=2e-5)
+    return ok, (B, Tn, heads, kv, H, W, osz, dt.__name__, cl, mode, float(np.abs(got - ref).max()))
+
 def g_chain_u8():
     h, w = dim(8, 700), dim(8, 700); nw, nh = dim(4, 700), dim(4, 700)
     img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -192,7 +218,7 @@ def g_chain_u8():
     return ok, (h, w, nw, nh, tr, mode)
 
 for name, gen in (("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
-                  ("warp_image_by_attention chain", g_chain_u8),
+                  ("warp_image_by_attention chain", g_chain_u8), ("attention stack -> warp (bench path)", g_stack_chain),
                   ("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
                   ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),
                   ("LANCZOS mask up-sample (A4)", g_lanczos), ("pool24 + gt_marginals (A5-A6)", g_pool_marg),
