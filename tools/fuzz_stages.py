@@ -72,8 +72,7 @@ def g_pdf_chain():
     Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0))
     Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
     rx, ry = O.maps_from_cdf(Fx, Fy, (Ho, Wo))
-    # the right-inverse matvec is float64 on both sides with the same table; maps: <= 2 ulp of the coordinate range
-    ok = np.allclose(N(mx), rx, rtol=0, atol=2e-4 * max(W, 1) / 1000 + 1e-4, equal_nan=True) and np.allclose(N(my), ry, rtol=0, atol=2e-4 * max(H, 1) / 1000 + 1e-4, equal_nan=True)
+    ok = np.array_equal(N(mx), rx, equal_nan=True) and np.array_equal(N(my), ry, equal_nan=True)      # bit for bit
     return ok, (B, W, H, Wo, Ho)
 
 def g_cdf_stages():
@@ -202,9 +201,7 @@ def g_stack_chain():
     Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, W), 0)); Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, H), 0))
     mx, my = O.maps_from_cdf(Fx, Fy, osz if osz else (H, W))
     ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
-    # (the right-inverse matvec of the oracle is float64 numpy, the kernel's an ordered float64 loop: same table, <= 1 ulp
-    #  of a float32 density, which may move a map entry by an ulp and a pixel by |grad| * 2^-17)
-    ok = np.allclose(got, ref, rtol=0, atol=2e-5)
+    ok = np.array_equal(got, ref)                                                                       # bit for bit
     return ok, (B, Tn, heads, kv, H, W, osz, dt.__name__, cl, mode, float(np.abs(got - ref).max()))
 
 def g_chain_u8():
