@@ -1,10 +1,10 @@
-"""Dev tool: randomised differential run of the resample entry point against the oracle -- random batch / sizes /
+"""Test infrastructure (imports oracle/): randomised differential run of the resample entry point against the oracle -- random batch / sizes /
 channels / layout / dtype / mode / map kinds (monotone, wild, NaN / Inf / huge coordinates, identity), sizes picked so
 that every kernel family is hit (staged rows, CHW plane split, column tiles, uint8 integer form, generic gather).
 usage: fuzz_remap.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from attwarp_amd import checkpoint_utils as cu
 from oracle import warp_oracle as O

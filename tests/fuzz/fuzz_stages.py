@@ -1,11 +1,11 @@
-"""Dev tool: randomised differential run of the per-stage entry points against the numpy oracle (bit for bit unless a
+"""Test infrastructure (imports oracle/): randomised differential run of the per-stage entry points against the numpy oracle (bit for bit unless a
 tolerance is written next to the stage): attention maps from uint8 / float32 / float64 attention with every transform
 (A13), PDF -> CDF -> maps chain with hostile densities (A8-A11), cdf repair / resample (A10), attention reduce with
 random geometry (A1/A2), LANCZOS mask up-sample vs the Pillow restatement (A4), revise_mask (A3), adaptive pool and
 gt_marginals (A5/A6), safe_softmax (A7).   usage: fuzz_stages.py [seconds per stage] [seed]"""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from attwarp_amd import checkpoint_utils as cu, attention_extraction as ae, new_method as nm, pipeline, model
 from oracle import warp_oracle as O

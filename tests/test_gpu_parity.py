@@ -356,7 +356,7 @@ def test_revise_mask(dev, golden):
     with pytest.raises(AssertionError):
         ae.revise_mask(T(g["masks"][0], dev), kernel_size=4)
     # a constant map: normalize("min") divides 0 by 0 and torch carries the NaN through sigmoid, clamp and the box
-    # filter (the up-sampled uint8 mask is then all 0 and the warp the identity) -- found by tools/fuzz_stages.py
+    # filter (the up-sampled uint8 mask is then all 0 and the warp the identity) -- found by tests/fuzz/fuzz_stages.py
     flat = np.full((2, 24, 24), 0.3, np.float32)
     flat[1] = g["masks"][0]
     with np.errstate(all="ignore"):
@@ -992,7 +992,7 @@ def test_remap_non_finite_and_huge_coordinates(dev, shape, mode):
     """NaN, +-Inf, +-1e30, +-3e9, the int32 edge of cvRound(32 m) and other out-of-range coordinates sprinkled over
     both maps: every kernel family (generic, staged rows, plane split, column tiles; float32 and uint8, integer uint8
     form) follows the oracle's conventions bit for bit (cv2: x86 cvRound -> INT_MIN -> pixel 0; exact: clamp to
-    [-1, size], NaN = -1) and no output is NaN.  (tools/fuzz_remap.py is the randomised long form of this test.)"""
+    [-1, size], NaN = -1) and no output is NaN.  (tests/fuzz/fuzz_remap.py is the randomised long form of this test.)"""
     from attwarp_amd import checkpoint_utils as cu
     H, W, Ho, Wo, C, layout = shape
     rng = np.random.default_rng(H * 7 + Wo)
@@ -1910,13 +1910,13 @@ def test_overlapped_warp_equals_serial(dev):
 
 
 def test_randomised_differential_runs(dev):
-    """A short run of the two fuzzers (tools/fuzz_remap.py, tools/fuzz_stages.py: random shapes, dtypes, layouts, modes,
+    """A short run of the two fuzzers (tests/fuzz/fuzz_remap.py, tests/fuzz/fuzz_stages.py: random shapes, dtypes, layouts, modes,
     hostile values; every stage entry point against the oracle): no mismatch.  The long runs behind DESIGN section 4 are
     the same scripts with a larger time budget."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for script, args in (("fuzz_remap.py", ["6", "11"]), ("fuzz_stages.py", ["1", "11"])):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", script)] + args, capture_output=True, text=True,
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", script)] + args, capture_output=True, text=True,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         assert "MISMATCH" not in r.stdout and "EXCEPTION" not in r.stdout, r.stdout[-3000:]
