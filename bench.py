@@ -179,15 +179,28 @@ class Step:
         from attwarp_amd import attention_extraction as ae, checkpoint_utils as cu, pipeline
         self.torch, self.ae, self.cu, self.pipeline = torch, ae, cu, pipeline
         self.B, self.S, self.mode, self.layout = B, S, mode, layout
-        self.img, self.rows, self.starts = make_inputs(B, S, dev, seed, layout)
-        self.out = torch.empty_like(self.img)
+        # A batch whose images + output + attention rows fit the 256 MB Infinity Cache would be served from it when
+        # every step re-used the same buffers (B=64 at 336x336: 279 MB).  Small workloads therefore ROTATE over nrot
+        # independent batches (>= 2 GiB in total), so that every step streams its data from HBM like a fresh batch
+        # would; the 1024x1024 B=256 batch is 6.8 GB on its own (nrot = 1).
+        batch_bytes = 2 * B * S * S * 3 * 4 + T_STEPS * B * HEADS * KV * 4
+        self.nrot = max(1, min(8, -(-(2 << 30) // batch_bytes)))
+        self.sets = []
+        for i in range(self.nrot):
+            img, rows, starts = make_inputs(B, S, dev, seed + 1000 * i, layout)
+            self.sets.append((img, rows, torch.empty_like(img)))
+        self.starts = starts
+        self.img, self.rows, self.out = self.sets[0]
         self.starts_tiled = self.starts.repeat(T_STEPS)
         self.events = []
+        self.k = 0
 
     def __call__(self, record: bool = False):
         # same three launches as attwarp_amd.pipeline.warp_from_attention_stack, with HIP events between them
         # (torch's current stream == the stream the kernels are launched on)
         torch = self.torch
+        self.img, self.rows, self.out = self.sets[self.k % self.nrot]
+        self.k += 1
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if record else None
         if record:
             ev[0].record()
@@ -202,6 +215,16 @@ class Step:
             ev[3].record()
             self.events.append(ev)
         return self.out
+
+    def set_layout(self, layout):
+        """Re-lay every rotating batch out as HWC / CHW (fresh output buffers)."""
+        torch = self.torch
+        if layout != self.layout:
+            perm = (0, 3, 1, 2) if layout == "chw" else (0, 2, 3, 1)
+            self.sets = [(img.permute(*perm).contiguous(), rows, None) for (img, rows, _) in self.sets]
+            self.sets = [(img, rows, torch.empty_like(img)) for (img, rows, _) in self.sets]
+            self.layout = layout
+            self.img, self.rows, self.out = self.sets[0]
 
     def stage_ms(self):
         """Mean duration of the three kernels of a step: (attention reduce, maps, resample)."""
@@ -361,7 +384,7 @@ def main():
                                f"({'cv2.remap arithmetic: 1/32-px coordinates, 4 table weights' if args.mode == 'cv2' else 'unquantised bilinear = grid_sample'}) "
                                f"(BASELINE configs[{cfg_idx}])",
                    "mode": args.mode, "batch_per_gpu": B, "image_size": S, "layout": args.layout.upper(),
-                   "global_batch": world * B,
+                   "global_batch": world * B, "rotating_batches": step.nrot,
                    "sharding": "contiguous image blocks per rank, no data-path collective"},
         "roofline": roof,
     }
@@ -402,9 +425,7 @@ def main():
         step.mode = args.mode
         # the other layout (CHW is what warp_from_cdf_torch receives, MN/checkpoint_utils.py:152)
         lay2 = "chw" if args.layout == "hwc" else "hwc"
-        step.img = step.img.permute(0, 3, 1, 2).contiguous() if lay2 == "chw" else step.img.permute(0, 2, 3, 1).contiguous()
-        step.out = torch.empty_like(step.img)
-        step.layout = lay2
+        step.set_layout(lay2)
         w3, _ = time_steps(step, args.steps, args.warmup, D)
         result[f"also_{lay2}"] = {"workload": f"same batch as [B,3,S,S] planar float32, mode={args.mode}" if lay2 == "chw"
                                   else f"same batch as [B,S,S,3], mode={args.mode}",
@@ -419,7 +440,9 @@ def main():
         step2 = Step(B2, S2, dev, seed=99, mode=args.mode, layout=args.layout)
         w4, _ = time_steps(step2, n2, args.warmup, D)
         st2 = step2.stage_ms()
-        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), mode={args.mode}, eager launches",
+        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), mode={args.mode}, eager launches, rotating over "
+                                      f"{step2.nrot} independent batches (a single 279 MB batch would sit in the 256 MB Infinity Cache)",
+                          "rotating_batches": step2.nrot,
                           "value": round(B2 * n2 / w4, 1), "unit": "images/s", "ms_per_step": round(w4 / n2 * 1e3, 4),
                           "stages_ms": [round(v, 4) for v in st2], "roofline": roofline_of(step2)}
         # the same workload with the resample of batch k overlapped with reduce + maps of batch k+1 (one HIP graph with
@@ -438,7 +461,9 @@ def main():
         w5 = time.perf_counter() - t0
         same = bool(torch.equal(ow.out, step2.out))
         result["also_overlapped"] = {"workload": f"batch-{B2} {S2}x{S2}, resample(k) || maps(k+1) || reduce(k+2) as three branches of "
-                                                 f"one HIP graph (pipeline.OverlappedWarp), exactly {n2} of each kernel timed", "value": round(B2 * n2 / w5, 1),
+                                                 f"one HIP graph (pipeline.OverlappedWarp), exactly {n2} of each kernel timed; ONE batch "
+                                                 f"re-used by every step (static graph buffers): its 279 MB largely stay in the Infinity Cache",
+                                     "value": round(B2 * n2 / w5, 1),
                                      "unit": "images/s", "ms_per_step": round(w5 / n2 * 1e3, 4),
                                      "bit_identical_to_serial": same}
         del step2, ow
