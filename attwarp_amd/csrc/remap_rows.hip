@@ -65,21 +65,36 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   int R = (int)((24 * 1024 + row_bytes / 2) / row_bytes);
   R = R < 4 ? 4 : (R > 16 ? 16 : R);
   if (tiled) R = 8;
-  // Block order: a contiguous range of row blocks per XCD (group = 0).  Alternatives kept behind the test hook
-  // ("remap_noswz" = 1: plain order, g >= 2: XCDs interleaved in groups of g blocks; "remap_rows"; "remap_nt") were
-  // measured in round 2 and none is a win across boxes and shapes -- on boxes in the slow state R=3 with groups of 4
-  // gains 2-3.5 % at 1024x1024x3 but loses 5 % on peaked maps and 15 % at 768x768x3; nontemporal loads of block-private
-  // rows gain 3 % on boxes in the fast state and lose 1-2 % in the slow state.
-  int group = 0;
+  // Block order and row blocks per workgroup.  Two box / allocation states exist on MI355X: with a
+  // contiguous range of row blocks per XCD (group = 0) the eight XCDs stream eight regions ~B/8 images apart, which is
+  // the fastest order on some leases (1.09 ms at 1024x1024x3 B=256) and the slowest on others (1.175 ms); with the XCDs
+  // interleaved in groups of g row blocks (g - 1 of g halo seams still meet in one L2) all of them work in ONE compact
+  // window and the time is the same on both kinds of lease.  Rows of >= 10 KB therefore run R = 3 with groups of 4
+  // (cv2: 1.12-1.13 ms on three slow leases, 1.11 on a fast one; exact: groups of 3, 1.106 ms); the choice is made for
+  // the worst case (profiles/round3_order_sweeps.md).  cpw = row blocks per workgroup, strided by the workgroups of
+  // the image: the column-tap prologue is paid once per cpw blocks (peaked maps 0.97 -> 0.93 ms, 768x768x3 0.84 -> 0.76).
+  int group = 0, cpw = 1;
+  if (!tiled && row_bytes >= 10 * 1024) {
+    R = 3;
+    group = mode == ATTWARP_CV2 ? 4 : 3;
+    cpw = mode == ATTWARP_CV2 ? 2 : 1;
+  } else if (!tiled && row_bytes >= 5 * 1024 && mode == ATTWARP_CV2) {
+    cpw = 4;
+  }
   if (const int v = tune(TUNE_REMAP_ROWS); v >= 1 && v <= RMAX) R = v;
   if (R > Ho) R = Ho;
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
-  const long long nb = (long long)p.nblk * B * p.ntiles;
+  if (const int v = tune(TUNE_REMAP_CPW); v >= 1) cpw = v;
+  while (cpw > 1 && (long long)((p.nblk + cpw - 1) / cpw) * B * p.ntiles < 4096) cpw >>= 1;   // keep the chip filled
+  p.wpi = (p.nblk + cpw - 1) / cpw;
+  const long long nb = (long long)p.wpi * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   p.alt_dir = tune(TUNE_REMAP_ALT) != 0;
   p.no_swz = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : group;
+  p.skew = 0;
+  if (const int v = tune(TUNE_REMAP_SKEW); v >= 0) p.skew = v;
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
   // nontemporal loads for block-private rows: measurement option only (see remap_rows_kernel.hpp)

@@ -116,11 +116,13 @@ struct RowsParams {
   int OVL;           // NP*orow_len   output floats per virtual row
   long long img_stride, plane_stride, oimg_stride, oplane_stride;  // in floats
   int R;             // output rows per block
-  int nblk;          // blocks per image
+  int nblk;          // row blocks per image
+  int wpi;           // workgroups per image (and column tile): workgroup j owns row blocks j, j + wpi, j + 2 wpi, ...
   int nblocks;       // total
   int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
   int no_swz;        // block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g blocks
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
+  int skew;          // block order 0: XCD x starts x * skew blocks into its contiguous range
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
   int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads (large streaming batches)
@@ -166,7 +168,12 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   int bid = blockIdx.x;
   {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    if (p.no_swz == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    if (p.no_swz == 0) {
+      const int len = (xcd < r) ? q + 1 : q, start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      int j = idx + xcd * p.skew;                          // XCD x starts x * skew blocks into its range (wraps)
+      if (p.skew) j %= len;
+      bid = start + j;
+    }
     else if (p.no_swz >= 2) {
       // XCD x owns every 8th GROUP of g consecutive row blocks (g = no_swz): neighbouring blocks of a group still share
       // an L2 (halo hits for g-1 of g seams), while the eight XCDs work in one compact window of memory
@@ -176,26 +183,22 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
       bid = cand < (n / per) * per ? cand : bid;          // the ragged tail keeps the plain order
     }
   }
-  int b, rb, tile = 0;
+  int b, rb0, tile = 0;
   if (TILED) {          // (image, tile, row block): row blocks of one tile stay neighbours (halo rows meet in L2)
-    const int per_img = p.nblk * p.ntiles;
+    const int per_img = p.wpi * p.ntiles;
     b = bid / per_img;
     const int rem = bid - b * per_img;
-    tile = rem / p.nblk;
-    rb = rem - tile * p.nblk;
+    tile = rem / p.wpi;
+    rb0 = rem - tile * p.wpi;
   } else {
-    b = bid / p.nblk;
-    rb = bid - b * p.nblk;
+    b = bid / p.wpi;
+    rb0 = bid - b * p.wpi;
   }
-  const int y0 = rb * p.R;
-  const int y1 = min(y0 + p.R, p.Ho);
-  const int nrows = y1 - y0;
 
   const float* src_b = p.src + (long long)b * p.img_stride;
   float* dst_b = p.dst + (long long)b * p.oimg_stride;
 
   const int bm = b / p.map_div;
-  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
 
   // ---- column taps, once per block, kept in registers.  Lanes past the end of the row duplicate
   //      the last element (same value to the same address): the row loop has no per-lane branches.
@@ -261,6 +264,15 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
   }
   }
+
+  // Row blocks of this workgroup: rb0, rb0 + wpi, ...  (wpi == nblk: exactly one).  With more than one, the column-tap
+  // prologue above is paid once for all of them while the workgroups of an image still sweep it as one compact window.
+  for (int rb = rb0; rb < p.nblk; rb += p.wpi) {
+  const int y0 = rb * p.R;
+  const int y1 = min(y0 + p.R, p.Ho);
+  const int nrows = y1 - y0;
+  if (rb != rb0) __syncthreads();   // the previous block's last gather is done with s_my and the row buffers
+  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
   __syncthreads();
 
   if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
         *reinterpret_cast<float*>(orow + ooff[k]) = o_;
       }
     }
-    return;
+    continue;
   }
 
   float4 X0[KI], X1[KI];
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
     ATTWARP_DO_ROW(q + 1, rows1);
   }
   if (q < nrows) ATTWARP_DO_ROW(q, rows0);
+  }   // row blocks of this workgroup
 #undef ATTWARP_DO_ROW
 #undef ATTWARP_ENSURE
 #undef ATTWARP_BLEND

@@ -262,6 +262,26 @@ def roofline_of(step, traffic=None):
             "kernel_ms_min": round(min(rm), 4), "launches_timed": len(rm)}
 
 
+def calibration_of(step, n: int = 20):
+    """torch.add(a, 1, out=b) over the step's own image and output buffers, timed with HIP events in this process right
+    after the measurement: what a plain streaming kernel reaches on THIS box for the same bytes (boxes and allocations
+    differ by several per cent) -- read `roofline.frac` against `calibration.frac`."""
+    import torch
+    ts = []
+    for i in range(n + 3):
+        img, _, out = step.sets[i % step.nrot]
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); torch.add(img, 1.0, out=out); e1.record()
+        torch.cuda.synchronize()
+        if i >= 3:
+            ts.append(e0.elapsed_time(e1))
+    mean = sum(ts) / len(ts)
+    alg = 2.0 * step.S * step.S * 3 * 4 * step.B
+    return {"kernel": "torch.add(images, 1, out=warped): same bytes, same buffers, same process",
+            "torch_add_ms": round(mean, 4), "torch_add_ms_min": round(min(ts), 4),
+            "achieved": round(alg / (mean * 1e-3) / 1e9, 1), "frac": round(alg / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def load_pmc_traffic(workload: str, mode: str):
     """HBM bytes per launch of the remap kernel from the committed rocprofv3 --pmc summary
     (profiles/pmc_traffic.json, collected with this same command).  None if absent."""
@@ -363,6 +383,9 @@ def main():
     ms_per_step = wall / args.steps * 1e3
     value = world * B * args.steps / wall
     roof = roofline_of(step, load_pmc_traffic(args.workload, args.mode))
+    if roof["traffic"] is not None:                 # a committed constant, not a counter read in this run
+        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier lease)"
+    roof["calibration"] = calibration_of(step)
 
     result = {
         "metric": "warped images/sec",
