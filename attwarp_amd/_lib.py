@@ -65,6 +65,9 @@ SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_axis_maps_from_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                   c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "attwarp_warp_step_fused": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "attwarp_remap_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_int, c_void_p]),
 }

@@ -12,6 +12,7 @@
 // (float16 in LLaVA), so every reference op boundary rounds to that dtype; reductions are
 // accumulated in double and rounded once (see oracle/warp_oracle.py, module docstring).
 #include "common.hpp"
+#include "attn_f32v.hpp"
 
 namespace attwarp {
 
@@ -19,14 +20,6 @@ constexpr int NT = 256;
 constexpr int MAXPL = 16;          // tokens per lane: ntok <= 1024
 constexpr int MAX_NTOK = MAXPL * WAVE;
 
-template <typename T> __device__ __forceinline__ T add_tiny(T s);   // s + 1e-12 evaluated in dtype T
-template <> __device__ __forceinline__ float add_tiny<float>(float s) { return fadd(s, 1e-12f); }
-template <> __device__ __forceinline__ __half add_tiny<__half>(__half s) {
-  return __float2half_rn(fadd(__half2float(s), 1e-12f));
-}
-template <> __device__ __forceinline__ __hip_bfloat16 add_tiny<__hip_bfloat16>(__hip_bfloat16 s) {
-  return __float2bfloat16(fadd(__bfloat162float(s), 1e-12f));
-}
 // attention rows are read exactly once per step: nontemporal loads keep them from displacing what the resample kernel
 // of the same step left in (and needs from) the L2 / Infinity Cache -- in-step time of this kernel at B=256: 0.110 ->
 // 0.074 ms (1024 x 1024 step), 0.112 -> 0.084 ms (336 x 336 step), stand-alone unchanged
@@ -42,56 +35,30 @@ template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b 
   return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
 }
 
-// ---- float32 division by a denominator shared by many numerators -------------------------------------------------
-// The compiler expands an IEEE float32 `a / d` into
-//     ds = div_scale(d, d, a); ns = div_scale(a, d, a); r0 = rcp(ds); e0 = fma(-ds, r0, 1); r1 = fma(e0, r0, r0);
-//     q0 = ns * r1; e1 = fma(-ds, q0, ns); q1 = fma(e1, r1, q0); e2 = fma(-ds, q1, ns); q = div_fmas(e2, r1, q1);
-//     result = div_fixup(q, d, a)
-// (11 instructions, one of them the quarter-rate v_rcp_f32; 16.6 VALU instructions per attention element made this
-// kernel VALU bound).  v_div_scale only rescales when an exponent is extreme -- |a| < 2^-103, d denormal or > 2^126,
-// a quotient that is denormal or whose exponents differ by >= 96 -- and v_div_fixup only replaces q for zero /
-// infinite / NaN operands.  Inside  d in [2^-60, 4],  a == 0 or 2^-100 <= a <= 2^20  the scale factors are 1, so
-// r0, e0, r1 depend on d alone and the SAME sequence costs 5 instructions per numerator, bit for bit the result of
-// `a / d` (a == 0 gives +0 through the sequence, as div_fixup does).  Anything outside that box takes `a / d` itself.
-struct SharedDiv {
-  float d, r1;
-  __device__ __forceinline__ explicit SharedDiv(float den) : d(den) {
-    const float r0 = __builtin_amdgcn_rcpf(den);
-    const float e0 = __builtin_fmaf(-den, r0, 1.0f);
-    r1 = __builtin_fmaf(e0, r0, r0);
-  }
-  __device__ __forceinline__ float operator()(float a) const {
-    const float q0 = fmul(a, r1);
-    const float e1 = __builtin_fmaf(-d, q0, a);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(-d, q1, a);
-    return __builtin_fmaf(e2, r1, q1);
-  }
-};
-constexpr uint32_t SDIV_NUM_LO = 0x0D800000u;   // 2^-100
-constexpr uint32_t SDIV_NUM_HI = 0x49800000u;   // 2^20
-
-// One workgroup per (pseudo-)sample.  Each wave takes heads w, w+4, ...; lane l owns tokens
-// l, l+64, ... (NPL = ceil(ntok/64) values per head in registers).  Heads are processed HU at a
-// time so that HU*NPL independent coalesced loads (256 B per wave instruction) are in flight per
-// lane before the first reduction: the kernel is a pure stream over heads*ntok elements per sample.
+// One workgroup per (pseudo-)sample, any dtype / kv stride / slice length.  Each wave takes heads w, w+4, ...; lane l
+// owns tokens l, l+64, ... (NPL = ceil(ntok/64) values per head in registers).  Heads are processed HU at a time so
+// that HU*NPL independent coalesced loads are in flight per lane before the first reduction.  The float32 sums follow
+// the path's fixed order (attn_f32v.hpp): with one token per lane the four tokens of a quad sit in four neighbouring
+// lanes (two xor-shuffles give every lane (x0 + x1) + (x2 + x3)), register i' belongs to 256-token block i'/4 and to
+// the lane group r = i' mod 4 of the canonical 64 lanes (canonical lane = 16 r + lane/4), so a lane keeps four running
+// sums s_r; the butterfly's first two steps (o = 32, 16) combine the s_r, the last four are shuffles over lane/4.
 // grid = nb
 template <typename T, int NPL, int HU>
 __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restrict__ attn, int heads, int64_t sb,
                                                               int64_t sh, int64_t row_off, int64_t skv,
                                                               const int32_t* __restrict__ starts, int starts_mod,
                                                               int max_start, int ntok, T* __restrict__ out) {
-  __shared__ double part[NT / WAVE][NPL * WAVE];
+  __shared__ float part[NT / WAVE][NPL * WAVE];
   constexpr int NW = NT / WAVE;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-  // a slice start outside [0, kv_len - ntok] is clamped (the reference's Python slice clamps too, llava.py:390;
-  // an unclamped start would read outside the attention row)
+  // a slice start outside [0, kv_len - ntok] is clamped for memory safety; the host shims reject such starts
+  // (the reference would raise: a truncated slice cannot be stacked, llava.py:390-395)
   const int st = min(max(starts[b % starts_mod], 0), max_start);
   const T* base = attn + (int64_t)b * sb + row_off + (int64_t)st * skv;
-  double acc[NPL];
+  float acc[NPL];
 #pragma unroll
-  for (int i = 0; i < NPL; ++i) acc[i] = 0.0;
+  for (int i = 0; i < NPL; ++i) acc[i] = 0.0f;
   for (int h0 = wid; h0 < heads; h0 += NW * HU) {
     T v[HU][NPL];
 #pragma unroll
@@ -108,14 +75,22 @@ __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restric
     for (int u = 0; u < HU; ++u) {
       const int h = h0 + u * NW;
       if (h < heads) {                                            // wave uniform
-        double s = 0.0;
+        float sr[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < NPL; ++i)
-          if (lane + WAVE * i < ntok) s += (double)to_f32<T>(v[u][i]);
-        s = wave_sum(s);
-        const T den = add_tiny<T>(from_f64<T>(s));      // (row sum + 1e-12) in the model dtype
+        for (int i = 0; i < NPL; ++i) {
+          const float x = (lane + WAVE * i < ntok) ? to_f32<T>(v[u][i]) : 0.0f;
+          const float pr = fadd(x, __shfl_xor(x, 1, WAVE));       // (x0 + x1) in lanes 0,1; (x2 + x3) in lanes 2,3
+          const float q = fadd(pr, __shfl_xor(pr, 2, WAVE));      // (x0 + x1) + (x2 + x3) in all four
+          sr[i & 3] = fadd(sr[i & 3], q);
+        }
+        float s = fadd(fadd(sr[0], sr[2]), fadd(sr[1], sr[3]));   // butterfly o = 32, then o = 16
+        s = fadd(s, __shfl_xor(s, 32, WAVE));                     // o = 8, 4, 2, 1 over lane / 4
+        s = fadd(s, __shfl_xor(s, 16, WAVE));
+        s = fadd(s, __shfl_xor(s, 8, WAVE));
+        s = fadd(s, __shfl_xor(s, 4, WAVE));
+        const T den = add_tiny<T>(from_f32<T>(s));      // (row sum + 1e-12) in the model dtype
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) acc[i] += (double)to_f32<T>(div_t<T>(v[u][i], den));
+        for (int i = 0; i < NPL; ++i) acc[i] = fadd(acc[i], to_f32<T>(div_t<T>(v[u][i], den)));
       }
     }
   }
@@ -124,103 +99,18 @@ __global__ __launch_bounds__(NT) void attn_reduce_step_kernel(const T* __restric
   __syncthreads();
   const T nheads = from_f32<T>((float)heads);
   for (int t = threadIdx.x; t < ntok; t += NT) {
-    double m = 0.0;
-    for (int w = 0; w < NW; ++w) m += part[w][t];
-    out[(int64_t)b * ntok + t] = div_t<T>(from_f64<T>(m), nheads);    // mean = sum / N in dtype T
+    float m = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) m = fadd(m, part[w][t]);
+    out[(int64_t)b * ntok + t] = div_t<T>(from_f32<T>(m), nheads);    // mean = sum / N in dtype T
   }
 }
 
-// float32 rows with unit kv stride: the same reduction with 16-byte loads (4-byte aligned: the image-token
-// slice starts at an arbitrary token).  Lane l owns tokens 4l..4l+3 (+256 per vector); NV = ceil(ntok/256).
-struct __attribute__((packed, aligned(4))) F4u {
-  float x, y, z, w;
-};
-
-template <int NV, int HU>
-__global__ __launch_bounds__(NT) void attn_reduce_step_f32v_kernel(const float* __restrict__ attn, int heads,
-                                                                   int64_t sb, int64_t sh, int64_t row_off,
-                                                                   const int32_t* __restrict__ starts, int starts_mod,
-                                                                   int max_start, int ntok, float* __restrict__ out) {
-  __shared__ double part[NT / WAVE][NV * 4 * WAVE];
-  constexpr int NW = NT / WAVE;
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-  // a slice start outside [0, kv_len - ntok] is clamped (the reference's Python slice clamps too, llava.py:390;
-  // an unclamped start would read outside the attention row)
-  const int st = min(max(starts[b % starts_mod], 0), max_start);
-  const float* base = attn + (int64_t)b * sb + row_off + st;
-  double acc[NV][4];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0;
-  for (int h0 = wid; h0 < heads; h0 += NW * HU) {
-    F4u v[HU][NV];
-#pragma unroll
-    for (int u = 0; u < HU; ++u) {
-      const float* rp = base + (int64_t)min(h0 + u * NW, heads - 1) * sh;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int t = min(4 * lane + 4 * WAVE * i, ntok - 4);       // clamped: tail lanes re-read, masked below
-        {   // nontemporal, as nt_load above
-          typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
-          const v4f_a4 q = __builtin_nontemporal_load(reinterpret_cast<const v4f_a4*>(rp + t));
-          v[u][i].x = q.x; v[u][i].y = q.y; v[u][i].z = q.z; v[u][i].w = q.w;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < HU; ++u) {
-      if (h0 + u * NW < heads) {                                    // wave uniform
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-          if (4 * lane + 4 * WAVE * i < ntok)
-            s += ((double)v[u][i].x + (double)v[u][i].y) + ((double)v[u][i].z + (double)v[u][i].w);
-        s = wave_sum(s);
-        const float den = fadd((float)s, 1e-12f);
-        // smallest non-zero and largest bit pattern of this lane's numerators (0 - 1 wraps to the top: zeros do not
-        // lower the minimum; negative, infinite and NaN numerators exceed SDIV_NUM_HI)
-        uint32_t lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-          const uint32_t bx = __float_as_uint(v[u][i].x), by = __float_as_uint(v[u][i].y),
-                         bz = __float_as_uint(v[u][i].z), bw = __float_as_uint(v[u][i].w);
-          lo = min(min(lo, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
-          hi = max(max(hi, bx), max(by, max(bz, bw)));
-        }
-        const bool box = den >= 8.673617379884035e-19f && den <= 4.0f &&       // 2^-60 .. 4 (wave uniform)
-                         __all(lo >= SDIV_NUM_LO - 1u && hi <= SDIV_NUM_HI);
-        if (box) {
-          const SharedDiv dv(den);
-#pragma unroll
-          for (int i = 0; i < NV; ++i) {
-            acc[i][0] += (double)dv(v[u][i].x);
-            acc[i][1] += (double)dv(v[u][i].y);
-            acc[i][2] += (double)dv(v[u][i].z);
-            acc[i][3] += (double)dv(v[u][i].w);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < NV; ++i) {
-            acc[i][0] += (double)(v[u][i].x / den);
-            acc[i][1] += (double)(v[u][i].y / den);
-            acc[i][2] += (double)(v[u][i].z / den);
-            acc[i][3] += (double)(v[u][i].w / den);
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) part[wid][4 * lane + 4 * WAVE * i + j] = acc[i][j];
-  __syncthreads();
-  const float nheads = (float)heads;
-  for (int t = threadIdx.x; t < ntok; t += NT) {
-    double m = 0.0;
-    for (int w = 0; w < NW; ++w) m += part[w][t];
-    out[(int64_t)b * ntok + t] = (float)m / nheads;
-  }
+// rows with unit kv stride and a slice length that is a multiple of 4: four tokens per lane (body: attn_f32v.hpp)
+template <typename T, int NV, int HU>
+__global__ __launch_bounds__(NT) void attn_reduce_step_v4_kernel(const AttnStepArgsT<T> a) {
+  extern __shared__ __attribute__((aligned(16))) float attn_part[];
+  attn_reduce_v4_block<T, NV, HU>(a, blockIdx.x, attn_part);
 }
 
 // mean over steps.  steps [Tn, n] -> out [n]
@@ -679,13 +569,21 @@ __global__ __launch_bounds__(NT) void clip_v_kernel(const uint8_t* __restrict__ 
 template <typename T>
 static int launch_step(const void* attn, int nb, int heads, int64_t sb, int64_t sh, int64_t row_off, int64_t skv,
                        const int32_t* starts, int starts_mod, int max_start, int ntok, void* out, hipStream_t st) {
-  if constexpr (sizeof(T) == 4) {
-    // float32, contiguous kv, slice length a multiple of 4 and <= 768: 16-byte loads
-    if (skv == 1 && ntok % 4 == 0 && ntok >= 4 && ntok <= 3 * 4 * WAVE && sb % 1 == 0) {
-      hipLaunchKernelGGL((attn_reduce_step_f32v_kernel<3, 4>), dim3(nb), dim3(NT), 0, st, (const float*)attn, heads,
-                         sb, sh, row_off, starts, starts_mod, max_start, ntok, (float*)out);
-      return check_launch("attn_reduce_step_f32v_kernel");
-    }
+  // contiguous kv, slice length a multiple of 4 and <= 768: four tokens per lane (16-byte / 8-byte loads)
+  if (skv == 1 && ntok % 4 == 0 && ntok >= 4 && ntok <= 3 * 4 * WAVE) {
+    AttnStepArgsT<T> a;
+    a.attn = (const T*)attn; a.heads = heads; a.sb = sb; a.sh = sh; a.row_off = row_off; a.starts = starts;
+    a.starts_mod = starts_mod; a.max_start = max_start; a.ntok = ntok; a.out = (T*)out;
+    const int hu = tune(TUNE_ATTN_HU);
+    if (hu == 2)
+      hipLaunchKernelGGL((attn_reduce_step_v4_kernel<T, 3, 2>), dim3(nb), dim3(NT), attn_v4_lds_bytes<3>(), st, a);
+    else if (hu == 8)
+      hipLaunchKernelGGL((attn_reduce_step_v4_kernel<T, 3, 8>), dim3(nb), dim3(NT), attn_v4_lds_bytes<3>(), st, a);
+    else if (hu == 1)
+      hipLaunchKernelGGL((attn_reduce_step_v4_kernel<T, 3, 1>), dim3(nb), dim3(NT), attn_v4_lds_bytes<3>(), st, a);
+    else
+      hipLaunchKernelGGL((attn_reduce_step_v4_kernel<T, 3, 4>), dim3(nb), dim3(NT), attn_v4_lds_bytes<3>(), st, a);
+    return check_launch("attn_reduce_step_v4_kernel");
   }
   if (ntok <= 9 * WAVE)      // 576 image tokens (LLaVA-1.5): 9 per lane, 4 heads in flight
     hipLaunchKernelGGL((attn_reduce_step_kernel<T, 9, 4>), dim3(nb), dim3(NT), 0, st, (const T*)attn, heads, sb, sh,

@@ -12,103 +12,18 @@
 // axis) pairs run concurrently on different CUs.
 #include "common.hpp"
 #include "interp.hpp"
+#include "axis_blocks.hpp"
 
 namespace attwarp {
 
 constexpr int NT = 256;
 constexpr int MAX_L = 16384;  // LDS: (L+1) doubles + L floats
 
-// ---- A11 core: CDF (float, LDS or global) -> knots -> map ------------------------------
-// MN/checkpoint_utils.py:167-193.  xn: LDS double[L+1].
-__device__ void map_from_cdf_block(const float* F, int L, int n_out, double* xn, float* map) {
-  const int len = L + 1;
-  for (int k = threadIdx.x; k < len; k += blockDim.x)
-    xn[k] = (k == 0) ? 0.0 : (double)F[k - 1] * (double)n_out;   // concatenate(([0.0], F)) * float(n_out)
-  __syncthreads();
-  if (threadIdx.x == 0) xn[len - 1] = (double)n_out;              // x_new_map_fwd[-1] = W_out
-  __syncthreads();
-  int tie = 0;
-  for (int k = threadIdx.x; k + 1 < len; k += blockDim.x) tie |= ((xn[k + 1] - xn[k]) <= 0.0);
-  tie = __syncthreads_or(tie);
-  if (tie) {
-    // += (1e-4 / max(W_out,1)) * np.arange(size, dtype=float32): python scalar * float32 array
-    // is a float32 product (then promoted to float64 by the in-place add)
-    const float c = (float)(1e-4 / (double)max(n_out, 1));
-    for (int k = threadIdx.x; k < len; k += blockDim.x) xn[k] += (double)fmul(c, (float)k);
-    __syncthreads();
-  }
-  const bool mono = block_is_sorted(xn, len);
-  np_interp_block(xn, len, n_out, map, mono);
-}
-
 __global__ __launch_bounds__(NT) void axis_map_from_cdf_kernel(const float* __restrict__ F, int L, int n_out,
                                                                float* __restrict__ map) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   const int b = blockIdx.x;
   map_from_cdf_block(F + (size_t)b * L, L, n_out, smem_d, map + (size_t)b * n_out);
-}
-
-// ---- A9 core: density (LDS float, in place) -> CDF -----------------------------------
-// MN/checkpoint_utils.py:30-41.  p: LDS float[L], overwritten by the CDF.  red: LDS double[NT/64].
-__device__ void cdf_from_density_block(float* p, int L, double* red) {
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < L; k += blockDim.x) {
-    float v = p[k];
-    v = (isnan(v) || isinf(v)) ? 0.0f : fmaxf(v, 0.0f);   // clamp_min(0) then nan_to_num(->0)
-    p[k] = v;
-    acc += (double)v;
-  }
-  const float denom = fmaxf((float)block_sum(acc, red), 1e-6f);
-  __syncthreads();
-  for (int k = threadIdx.x; k < L; k += blockDim.x) p[k] = p[k] / denom;
-  __syncthreads();
-  // Running sum in double (what torch's CPU cumsum does), rounded to float32 per prefix.
-  // The values are float32 in [0,1] summing to ~1.  If every non-zero value is >= 2^-28, every partial sum
-  // is a multiple of 2^-51 below 2 and therefore EXACT in double: any association gives the same bits, so
-  // a parallel scan equals the sequential one.  Otherwise (denormal-ish densities) one lane runs the
-  // sequential scan.
-  int small = 0;
-  double lsum = 0.0;
-  const int per = (L + (int)blockDim.x - 1) / (int)blockDim.x;      // consecutive elements per thread
-  const int k0 = threadIdx.x * per, k1 = min(k0 + per, L);
-  for (int k = k0; k < k1; ++k) {
-    const float v = p[k];
-    small |= (v != 0.0f) && (v < 3.7252902984619140625e-9f);          // 2^-28
-    lsum += (double)v;
-  }
-  small = __syncthreads_or(small || !(lsum < 2.0));
-  if (!small) {
-    // exclusive scan of the per-thread sums: wave shuffle scan, then the wave totals through LDS
-    double inc = lsum;
-    const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-      const double t = __shfl_up(inc, o, WAVE);
-      if (lane >= o) inc += t;
-    }
-    if (lane == WAVE - 1) red[wid] = inc;
-    __syncthreads();
-    double base = inc - lsum;
-    for (int w = 0; w < wid; ++w) base += red[w];
-    double c = base;
-    for (int k = k0; k < k1; ++k) {
-      c += (double)p[k];
-      p[k] = (float)c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) p[L - 1] = 1.0f;
-    __syncthreads();
-    return;
-  }
-  if (threadIdx.x == 0) {
-    double c = 0.0;
-    for (int k = 0; k < L; ++k) {
-      c += (double)p[k];
-      p[k] = (float)c;
-    }
-    p[L - 1] = 1.0f;
-  }
-  __syncthreads();
 }
 
 __global__ __launch_bounds__(NT) void cdf_from_density_kernel(const float* __restrict__ pin, int L,
@@ -121,39 +36,6 @@ __global__ __launch_bounds__(NT) void cdf_from_density_kernel(const float* __res
   __syncthreads();
   cdf_from_density_block(p, L, red);
   for (int k = threadIdx.x; k < L; k += blockDim.x) Fout[(size_t)b * L + k] = p[k];
-}
-
-// ---- A8 core: right-inverse up-sample ---------------------------------------------------
-// MN/checkpoint_utils.py:64-131.  y: Lo floats (global), inv: Lo x Lo doubles (global),
-// tmp: LDS float[Lo], out: float[L] (LDS or global).
-__device__ __forceinline__ void adaptive_window(int k, int L, int Lo, int& s, int& e) {
-  // k < Lo <= 64 and L <= 16384: the products fit 32 bits
-  s = (int)(((unsigned)k * (unsigned)L) / (unsigned)Lo);
-  e = (int)(((unsigned)(k + 1) * (unsigned)L + (unsigned)Lo - 1u) / (unsigned)Lo);
-}
-
-__device__ void right_inverse_block(const float* y, int Lo, int L, const double* inv, float* tmp, float* out,
-                                    bool clamp0) {
-  for (int k = threadIdx.x; k < Lo; k += blockDim.x) {
-    double acc = 0.0;
-    for (int j = 0; j < Lo; ++j) acc = acc + (double)y[j] * inv[(size_t)k * Lo + j];
-    tmp[k] = (float)acc;
-  }
-  __syncthreads();
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
-    const int k0 = (int)(((unsigned)l * (unsigned)Lo) / (unsigned)L);
-    float x = 0.0f;
-    for (int k = max(k0 - 1, 0); k <= min(k0 + 1, Lo - 1); ++k) {
-      int s, e;
-      adaptive_window(k, L, Lo, s, e);
-      if (l >= s && l < e) {
-        const float a = 1.0f / (float)max(e - s, 1);
-        x = fadd(x, fmul(tmp[k], a));
-      }
-    }
-    out[l] = clamp0 ? fmaxf(x, 0.0f) : x;
-  }
-  __syncthreads();
 }
 
 __global__ __launch_bounds__(NT) void right_inverse_kernel(const float* __restrict__ y, int Lo, int L,
@@ -186,69 +68,13 @@ __global__ __launch_bounds__(NT) void axis_maps_from_pdf_kernel(const float* __r
   map_from_cdf_block(p, L, n_out, xn, map);
 }
 
-// ---- A2 + A6 + A8 + A9 + A11 fused: per-step attention maps -> inverse maps, one launch -------------
-// steps [T,B,g*g] float32 (A1 output) -> mean over steps (A2, llava.py:409-411) -> marginals of the
-// g x g map (A6) -> right-inverse up-sample, clamp, CDF, inverse map (as axis_maps_from_pdf_kernel).
-// Bit-identical to running the stages one by one.  grid = (B, 2).
-__global__ __launch_bounds__(NT) void axis_maps_from_steps_kernel(const float* __restrict__ steps, int T, int B, int g,
-                                                                  int W, int H, int W_out, int H_out,
-                                                                  const double* __restrict__ inv_x,
-                                                                  const double* __restrict__ inv_y,
-                                                                  float* __restrict__ map_x, float* __restrict__ map_y,
-                                                                  float* __restrict__ att_out) {
+// ---- A2 + A6 + A8 + A9 + A11 fused: per-step attention maps -> inverse maps, one launch (body: axis_blocks.hpp) ------
+// grid = (B, 2): y = 0 -> x axis, y = 1 -> y axis.
+__global__ __launch_bounds__(NT) void axis_maps_from_steps_kernel(const StepsMapsArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   __shared__ float tmp[64];
   __shared__ float pm[64];
-  const int b = blockIdx.x, axis = blockIdx.y;
-  const int L = axis ? H : W, n_out = axis ? H_out : W_out, ntok = g * g;
-  const double* inv = axis ? inv_y : inv_x;
-  float* map = (axis ? map_y : map_x) + (size_t)b * n_out;
-  double* red = smem_d;                         // 8
-  double* xn = smem_d + 8;                      // L+1
-  float* p = reinterpret_cast<float*>(xn + L + 1 + ((L + 1) & 1));   // L floats
-  float* att = p + L;                           // g*g floats
-  // A2: mean over generation steps (float64 accumulate, one rounding, float32 divide)
-  for (int i = threadIdx.x; i < ntok; i += blockDim.x) {
-    double acc = 0.0;
-    const float* sp = steps + (size_t)b * ntok + i;
-    const size_t tstride = (size_t)B * ntok;
-    int t = 0;
-    for (; t + 8 <= T; t += 8) {          // 8 independent loads in flight, then the ordered accumulation
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(t + u) * tstride];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += (double)v[u];
-    }
-    for (; t < T; ++t) acc += (double)sp[(size_t)t * tstride];
-    const float m = (float)acc / (float)T;
-    att[i] = m;
-    if (att_out && axis == 0) att_out[(size_t)b * ntok + i] = m;
-  }
-  __syncthreads();
-  // A6: marginal along this axis (x: sum over rows; y: sum over columns), clamp >= 0, normalise
-  for (int k = threadIdx.x; k < g; k += blockDim.x) {
-    double acc = 0.0;
-    for (int j = 0; j < g; ++j) {
-      const float v = axis ? att[k * g + j] : att[j * g + k];
-      acc += (double)((v != v) ? v : (v > 0.0f ? v : 0.0f));
-    }
-    pm[k] = (float)acc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < g; ++k) tot += (double)pm[k];
-    tmp[0] = fmaxf((float)tot, 1e-6f);
-  }
-  __syncthreads();
-  const float tot = tmp[0];
-  __syncthreads();
-  if (threadIdx.x < g) pm[threadIdx.x] = pm[threadIdx.x] / tot;
-  __syncthreads();
-  right_inverse_block(pm, g, L, inv, tmp, p, true);
-  cdf_from_density_block(p, L, red);
-  map_from_cdf_block(p, L, n_out, xn, map);
+  axis_maps_from_steps_block<24>(a, blockIdx.x, blockIdx.y, smem_d, tmp, pm);
 }
 
 // ---- A7: safe_softmax over dim=1, MN/model.py:8-14 ---------------------------------------
@@ -410,9 +236,10 @@ extern "C" int attwarp_axis_maps_from_steps(const float* steps, int T, int B, in
   const int L = W > H ? W : H;
   if (L > 8192) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: max(W,H)=%d > 8192", L);
   if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: B > 65535");
-  const size_t lds = (size_t)(8 + L + 2) * sizeof(double) + (size_t)(L + g * g) * sizeof(float);
-  hipLaunchKernelGGL(axis_maps_from_steps_kernel, dim3(B, 2), dim3(NT), lds, as_stream(stream), steps, T, B, g, W, H,
-                     W_out, H_out, inv_x, inv_y, map_x, map_y, att_out);
+  StepsMapsArgs a;
+  a.steps = steps; a.T = T; a.B = B; a.g = g; a.W = W; a.H = H; a.W_out = W_out; a.H_out = H_out;
+  a.inv_x = inv_x; a.inv_y = inv_y; a.map_x = map_x; a.map_y = map_y; a.att_out = att_out;
+  hipLaunchKernelGGL(axis_maps_from_steps_kernel, dim3(B, 2), dim3(NT), steps_maps_lds_bytes(L, g), as_stream(stream), a);
   return check_launch("axis_maps_from_steps_kernel");
 }
 

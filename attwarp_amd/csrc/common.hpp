@@ -136,6 +136,7 @@ enum TuneKey {
   TUNE_PROFILES_VARIANT,    // 1: generic (non byte-packed) profile kernel for uint8 attention
   TUNE_REMAP_CPW,           // row blocks per workgroup of the float32 staged resample (strided inside the image)
   TUNE_REMAP_SKEW,          // XCD x starts x * skew blocks into its contiguous range of row blocks
+  TUNE_ATTN_HU,             // heads in flight per wave of the four-tokens-per-lane attention reduce (1, 2, 4, 8)
   TUNE_COUNT
 };
 int tune(TuneKey k);        // current override or -1

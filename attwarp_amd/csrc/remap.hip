@@ -136,8 +136,9 @@ static int launch_gather(const void* src, void* dst, int B, int C, int H, int W,
   return check_launch("remap_gather_kernel");
 }
 
+struct StepExtra;
 int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
-                      const float* mx, const float* my, int mode, hipStream_t st, bool* handled);
+                      const float* mx, const float* my, int mode, hipStream_t st, bool* handled, StepExtra* ex);
 int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                          const float* mx, const float* my, int mode, hipStream_t st, bool* handled);
 
@@ -162,7 +163,7 @@ extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int
   if (dtype == ATTWARP_F32) {
     bool handled = false;
     int rc = launch_remap_rows((const float*)src, (float*)dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, st,
-                               &handled);
+                               &handled, nullptr);
     if (handled) return rc;
   } else {
     bool handled = false;

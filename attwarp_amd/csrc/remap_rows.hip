@@ -1,15 +1,19 @@
 // Host side of the float32 staged resample (kernel: remap_rows_kernel.hpp) + the EXACT-mode instantiations.
 #include "remap_rows_kernel.hpp"
 
+#include <cstring>
+
 namespace attwarp {
 
-int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st) {
-  return launch_rows_mode<ATTWARP_EXACT, false, 1, 4>(p, tile_ko, st);
+int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex) {
+  return launch_rows_mode<ATTWARP_EXACT, false, 1, 4>(p, tile_ko, st, ex);
 }
 
 // Returns via *handled whether the fast path took the request.
+// ex != nullptr: the fused step (block ranges for the map construction and the attention reduce of other batches are
+// appended to the resample's grid; ex->nR8 is filled in here).
 int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
-                      const float* mx, const float* my, int mode, hipStream_t st, bool* handled) {
+                      const float* mx, const float* my, int mode, hipStream_t st, bool* handled, StepExtra* ex) {
   *handled = false;
   if (tune(TUNE_REMAP_VARIANT) == 1) return ATTWARP_OK;  // force the generic gather kernel (A/B measurements, tests)
   RowsParams p;
@@ -103,8 +107,58 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)
   const int tile_ko = tiled ? TILE_KO : 0;
-  if (mode == ATTWARP_CV2) return launch_rows_cv2(p, tile_ko, st);
-  return launch_rows_exact(p, tile_ko, st);
+  if (ex) ex->nR8 = (p.nblocks + 7) / 8;
+  if (mode == ATTWARP_CV2) return launch_rows_cv2(p, tile_ko, st, ex);
+  return launch_rows_exact(p, tile_ko, st, ex);
 }
 
 }  // namespace attwarp
+
+using namespace attwarp;
+
+extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
+                                       int W_out, const float* map_x, const float* map_y, int mode,
+                                       const float* steps_in, int T, int g, const double* inv_x, const double* inv_y,
+                                       float* map_x_next, float* map_y_next,
+                                       const float* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
+                                       int starts_mod, int ntok, float* steps_out, void* stream) {
+  ATTWARP_REQUIRE(src && dst && map_x && map_y, "warp_step_fused: null image / map pointer");
+  ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0, "warp_step_fused: non-positive size");
+  ATTWARP_REQUIRE(layout == ATTWARP_HWC || layout == ATTWARP_CHW, "warp_step_fused: unknown layout %d", layout);
+  ATTWARP_REQUIRE(mode == ATTWARP_EXACT || mode == ATTWARP_CV2, "warp_step_fused: unknown mode %d", mode);
+  if (C > 4 || B > 65535 || H_out > 65535 || (long long)W_out * C > 2147483647LL / 2 ||
+      (long long)H * W * C > 2147483647LL)
+    return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: image shape outside the staged resample's limits");
+  StepExtra ex;
+  memset(&ex, 0, sizeof(ex));
+  if (steps_in) {      // M: per-step maps of the NEXT batch -> its inverse maps
+    ATTWARP_REQUIRE(inv_x && inv_y && map_x_next && map_y_next, "warp_step_fused: null map-construction pointer");
+    ATTWARP_REQUIRE(T > 0 && g > 0, "warp_step_fused: non-positive T / g");
+    ATTWARP_REQUIRE(map_x_next != map_x && map_y_next != map_y, "warp_step_fused: the next maps must not alias the current ones");
+    if (g > 32 || std::max(W, H) > 8192) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: g > 32 or max(W,H) > 8192");
+    ex.maps.steps = steps_in; ex.maps.T = T; ex.maps.B = B; ex.maps.g = g; ex.maps.W = W; ex.maps.H = H;
+    ex.maps.W_out = W_out; ex.maps.H_out = H_out; ex.maps.inv_x = inv_x; ex.maps.inv_y = inv_y;
+    ex.maps.map_x = map_x_next; ex.maps.map_y = map_y_next; ex.maps.att_out = nullptr;
+    ex.nM8 = (2 * B + 7) / 8;
+  }
+  if (rows) {          // A: attention rows of the batch after next -> its per-step maps
+    ATTWARP_REQUIRE(starts && steps_out, "warp_step_fused: null attention pointer");
+    ATTWARP_REQUIRE(n_rows > 0 && heads > 0 && kv_len > 0 && ntok > 0 && starts_mod > 0, "warp_step_fused: non-positive attention size");
+    ATTWARP_REQUIRE(ntok <= kv_len, "warp_step_fused: ntok=%d > kv_len=%d", ntok, kv_len);
+    ATTWARP_REQUIRE(steps_out != steps_in, "warp_step_fused: steps_out must not alias steps_in");
+    if (ntok % 4 != 0 || ntok > 3 * 4 * WAVE)
+      return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok must be a multiple of 4 and <= 768");
+    ex.attn.attn = rows; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
+    ex.attn.row_off = 0; ex.attn.starts = starts; ex.attn.starts_mod = starts_mod; ex.attn.max_start = kv_len - ntok;
+    ex.attn.ntok = ntok; ex.attn.out = steps_out;
+    ex.nA = n_rows;
+    ex.nA8 = (n_rows + 7) / 8;
+  }
+  bool handled = false;
+  const int rc = launch_remap_rows(src, dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, as_stream(stream),
+                                   &handled, &ex);
+  if (!handled && rc == ATTWARP_OK)
+    return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: this image shape / alignment takes the generic resample; use the three separate launches");
+  return rc;
+}
+

@@ -27,6 +27,9 @@
 // Arithmetic is identical to remap_gather_kernel / the oracle in both modes.
 #pragma once
 #include "common.hpp"
+#include "axis_blocks.hpp"
+#include "attn_f32v.hpp"
+#include <algorithm>
 
 // Measurement build only (-DATTWARP_EXPERIMENT): lds_pad bit 0 = no global loads (registers keep their old
 // contents), bit 1 = stores only for values that never occur.  Splits the kernel time into its read and write sides.
@@ -152,10 +155,9 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // to direct global taps for that tile only.
 // SINGLE (CV2, rows wider than 8 KB): one [top | bottom] buffer and two barriers per row instead of two
 // buffers and one barrier (half the LDS, more resident workgroups).
-template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>
-__global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE>
+__device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int block_index, float* smem) {
   constexpr bool CV = MODE == ATTWARP_CV2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_my = smem;                                   // RMAX floats
   constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
   constexpr int BUF = CV ? 2 * ROWF : ROWF;             // floats per LDS buffer (CV2: top row, then bottom row)
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
 
   // XCD-aware block order: blocks bid, bid+8, ... share an XCD (and its L2); hand each XCD a
   // contiguous range of (image, row-block) pairs so neighbouring row blocks hit the same L2.
-  int bid = blockIdx.x;
+  int bid = block_index;
   {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
     if (p.no_swz == 0) {
@@ -432,15 +434,79 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
 #undef ATTWARP_LOAD_ROW
 }
 
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>
+__global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  remap_rows_block<NT, KI, KO, HWC, AFF, TILED, MODE, SINGLE>(p, blockIdx.x, smem);
+}
+
+// ---- the fused step: ONE launch = the resample of batch k + the map construction of batch k+1 + the attention
+// reduce of batch k+2 (three independent pieces of work on different buffers; attwarp_warp_step_fused).  The three
+// kernels of a step are 41 / 14 / 22 us at B=64 336x336: launched one behind the other -- on one stream or as graph
+// branches -- every boundary costs a drain, a dispatch ramp and a few microseconds of queue hand-off; as block ranges of
+// one grid there is one ramp and one tail per step, and the reduce blocks (bound by their own latency chain, not by
+// HBM) drain beside the first resample blocks.  Block order: the 2B map blocks first (the longest dependent chain
+// starts at once), then the reduce blocks, then the resample blocks; each range is padded to a multiple of 8 blocks so
+// that block % 8 keeps naming the XCD for the resample's XCD-aware order.  Measured, 336x336x3 float32, ring of
+// batches larger than the Infinity Cache (tools/ab_step.py, same-box alternating builds): B=64 0.059 ms per step
+// against 0.076 (three graph branches) and 0.089 (three eager launches); B=256 0.209 against 0.228 / 0.233; reduce and
+// resample chunks interleaved evenly instead: 0.064 / 0.216; 4 heads in flight per reduce wave: 0.069 / 0.233.
+struct StepExtra {
+  StepsMapsArgs maps;      // nM8 * 8 >= 2 * maps.B blocks (0: no map work)
+  AttnStepArgs attn;       // nA reduce blocks (0: none)
+  int nM8, nA, nA8, nR8;   // blocks / 8 of the three ranges: ceil(2B / 8), ceil(nA / 8), ceil(nR / 8)
+};
+
+// Waves per SIMD the register allocation must leave room for: the appended map / reduce blocks must not cost the
+// resample blocks their occupancy (bytes in flight per CU, not ALU, bound them).  336x336x3 rows (KI = 1, KO = 4: 58
+// VGPRs on its own) keep 6 waves, 1024x1024x3 (KI = 3, KO = 12: 128 VGPRs) its 4; other shapes take what comes.
+constexpr int step_min_waves(int KI, int KO, bool AFF) {
+  return (KI == 1 && KO == 4) ? 6 : (KI <= 2 && KO <= 8) ? 4 : (KI == 3 && KO == 12 && AFF) ? 4 : 1;
+}
+
+template <int NT, int KI, int KO, bool HWC, bool AFF, int MODE, bool SINGLE>
+__global__ __launch_bounds__(NT, step_min_waves(KI, KO, AFF)) void warp_step_kernel(const RowsParams p, const StepExtra ex) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_tmp[64], s_pm[64];
+  const int blk = blockIdx.x;
+  if (blk < ex.nM8 * 8) {
+    if (blk < 2 * ex.maps.B)
+      axis_maps_from_steps_block<8>(ex.maps, blk >> 1, blk & 1, reinterpret_cast<double*>(smem), s_tmp, s_pm);
+    return;
+  }
+  const int j = blk - ex.nM8 * 8;
+  if (j < ex.nA8 * 8) {
+    if (j < ex.nA) attn_reduce_v4_block<float, 3, 2>(ex.attn, j, smem);
+    return;
+  }
+  const int rb = j - ex.nA8 * 8;       // a multiple of 8 blocks precede: block % 8 still names the XCD
+  if (rb < p.nblocks) remap_rows_block<NT, KI, KO, HWC, AFF, false, MODE, SINGLE>(p, rb, smem);
+}
+
 template <int MODE, bool SINGLE>
 constexpr size_t rows_lds_bytes(int KI, int NT) {
   return (size_t)(RMAX + (SINGLE ? 1 : 2) * (MODE == ATTWARP_CV2 ? 2 : 1) * KI * NT * 4) * sizeof(float);
 }
 
 template <int NT, int KI, int KO, int MODE, bool SINGLE>
-static int launch_rows_t(const RowsParams& p, hipStream_t st) {
-  const size_t lds = rows_lds_bytes<MODE, SINGLE>(KI, NT) + (size_t)p.lds_pad;
-  const dim3 g(p.nblocks), t(NT);
+static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* ex) {
+  size_t lds = rows_lds_bytes<MODE, SINGLE>(KI, NT) + (size_t)p.lds_pad;
+  const dim3 t(NT);
+  if (ex) {        // the fused step (warp_step_kernel): map blocks, then chunks of 8 reduce / resample blocks
+    if (ex->nA > 0) lds = std::max(lds, attn_v4_lds_bytes<3>());
+    if (ex->nM8 > 0) lds = std::max(lds, steps_maps_lds_bytes(std::max(ex->maps.W, ex->maps.H), ex->maps.g));
+    const dim3 g((unsigned)((ex->nM8 + ex->nA8 + ex->nR8) * 8));
+    if (p.NP == 1 && p.OVL == KO * NT)
+      hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, true, true, MODE, SINGLE>), g, t, lds, st, p, *ex);
+    else if (p.NP == 1)
+      hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, true, false, MODE, SINGLE>), g, t, lds, st, p, *ex);
+    else if (p.OVL == KO * NT && p.orow_len % NT == 0)
+      hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, false, true, MODE, SINGLE>), g, t, lds, st, p, *ex);
+    else
+      hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, false, false, MODE, SINGLE>), g, t, lds, st, p, *ex);
+    return check_launch("warp_step_kernel");
+  }
+  const dim3 g(p.nblocks);
   if (p.NP == 1 && p.OVL == KO * NT)   // every (lane, k) is a distinct in-row element: affine store offsets
     hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, true, false, MODE, SINGLE>), g, t, lds, st, p);
   else if (p.NP == 1)
@@ -453,20 +519,21 @@ static int launch_rows_t(const RowsParams& p, hipStream_t st) {
 }
 
 template <int NT, int KI, int MODE, bool SINGLE>
-static int launch_rows_ki(const RowsParams& p, int ko, hipStream_t st) {
-  if (ko <= 4) return launch_rows_t<NT, KI, 4, MODE, SINGLE>(p, st);
-  if (ko <= 8) return launch_rows_t<NT, KI, 8, MODE, SINGLE>(p, st);
-  if (ko <= 12) return launch_rows_t<NT, KI, 12, MODE, SINGLE>(p, st);
-  return launch_rows_t<NT, KI, 16, MODE, SINGLE>(p, st);
+static int launch_rows_ki(const RowsParams& p, int ko, hipStream_t st, const StepExtra* ex) {
+  if (ko <= 4) return launch_rows_t<NT, KI, 4, MODE, SINGLE>(p, st, ex);
+  if (ko <= 8) return launch_rows_t<NT, KI, 8, MODE, SINGLE>(p, st, ex);
+  if (ko <= 12) return launch_rows_t<NT, KI, 12, MODE, SINGLE>(p, st, ex);
+  return launch_rows_t<NT, KI, 16, MODE, SINGLE>(p, st, ex);
 }
 
 // all staged variants of one arithmetic mode; tile_ko != 0 selects the column-tiled kernel.
 // KIMIN..KIMAX bounds the float4-per-thread counts this instantiation serves (the CV2 kernel with two
 // [top | bottom] buffers needs 64 KB + of LDS at KI = 4, above the 64 KB a launch gets by default: KI = 4 runs
-// the SINGLE-buffer form there).
+// the SINGLE-buffer form there).  ex != nullptr: the fused step (not built for the column-tiled kernel).
 template <int MODE, bool SINGLE, int KIMIN, int KIMAX>
-static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st) {
+static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex) {
   constexpr int NT = NT_BIG;
+  if (tile_ko != 0 && ex) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: rows wider than 4096 floats are not fused");
   if (tile_ko == 8) {
     if constexpr (KIMIN <= 3 && 3 <= KIMAX) {
       const size_t lds = rows_lds_bytes<MODE, SINGLE>(3, NT) + (size_t)p.lds_pad;
@@ -484,15 +551,15 @@ static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st) {
     return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
   }
   const int ki = (p.VLV + NT - 1) / NT, ko = (p.OVL + NT - 1) / NT;
-  if constexpr (KIMIN <= 1 && 1 <= KIMAX) if (ki <= 1) return launch_rows_ki<NT, 1, MODE, SINGLE>(p, ko, st);
-  if constexpr (KIMIN <= 2 && 2 <= KIMAX) if (ki == 2) return launch_rows_ki<NT, 2, MODE, SINGLE>(p, ko, st);
-  if constexpr (KIMIN <= 3 && 3 <= KIMAX) if (ki == 3) return launch_rows_ki<NT, 3, MODE, SINGLE>(p, ko, st);
-  if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE>(p, ko, st);
+  if constexpr (KIMIN <= 1 && 1 <= KIMAX) if (ki <= 1) return launch_rows_ki<NT, 1, MODE, SINGLE>(p, ko, st, ex);
+  if constexpr (KIMIN <= 2 && 2 <= KIMAX) if (ki == 2) return launch_rows_ki<NT, 2, MODE, SINGLE>(p, ko, st, ex);
+  if constexpr (KIMIN <= 3 && 3 <= KIMAX) if (ki == 3) return launch_rows_ki<NT, 3, MODE, SINGLE>(p, ko, st, ex);
+  if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE>(p, ko, st, ex);
   return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: variant for %d float4 per thread not built", ki);
 }
 
 // defined in remap_rows.hip / remap_rows_cv2.hip
-int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st);
-int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st);
+int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
+int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
 
 }  // namespace attwarp

@@ -105,6 +105,9 @@ def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int]
         mx, my = maps_out
         if tuple(mx.shape) != (B, W_out) or tuple(my.shape) != (B, H_out) or mx.dtype != torch.float32 or my.dtype != torch.float32:
             raise ValueError("axis_maps_from_attention_steps: maps_out must be float32 [B,W_out], [B,H_out]")
+        if not (mx.is_contiguous() and my.is_contiguous()) or mx.device != dev or my.device != dev:
+            raise ValueError("axis_maps_from_attention_steps: maps_out must be dense tensors on the device of `steps` "
+                             "(the kernel writes dense [B,W_out] / [B,H_out] rows through the raw pointers)")
     att = torch.empty(B, ntok, device=dev, dtype=torch.float32) if return_attention else None
     with torch.cuda.device(dev):
         call("attwarp_axis_maps_from_steps", ptr(s), T, B, g, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y), ptr(mx),
@@ -259,110 +262,217 @@ class OverlappedWarp:
     -- instead of reduce -> maps -> resample back to back for every batch.  Buffers are static (graph replay); the
     per-step maps and the per-step attention maps are double buffered.
 
-        ow = OverlappedWarp(images, rows, starts)      # captures; images / rows are the static input buffers
-        rows <- attention of batch 0;  ow.prime()      # reduce + maps of batch 0 (serial)
-        rows <- attention of batch 1;  ow.prime2()     # reduce of batch 1 (serial)
-        for k in 0 .. n-1:
-            images <- batch k;  rows <- attention of batch k+2 (if any)
-            out = ow.step()                            # R(k) || M(k+1) || A(k+2)
-    i.e. the attention buffer runs two batches ahead of the image buffer (``ow.flush()`` = R alone, for a tail).
-    With static inputs every step is bit-identical to ``warp_from_attention_stack`` (same kernels, same arguments)."""
+    ``images`` / ``rows`` are either one static buffer each (the caller copies every batch in) or RINGS of n buffers
+    (lists of equal length): batch k lives in ``images[k % n]`` / ``rows[k % n]`` and is warped into ``outs[k % n]``,
+    so a producer can fill slot (k+1) % n while slot k % n is being read, and a measurement over a ring larger than the
+    Infinity Cache streams every batch from HBM.
 
-    def __init__(self, images: torch.Tensor, rows: torch.Tensor, starts: torch.Tensor, out_size=None,
-                 channels_last: bool = False, mode: str = "cv2"):
-        dev = require_gpu(images, rows, starts)
-        if rows.dtype != torch.float32:
-            raise TypeError("OverlappedWarp: float32 attention rows expected")
-        self.images, self.rows, self.starts = images, rows, starts
+        ow = OverlappedWarp(images, rows, starts)      # allocates outs, captures lazily
+        rows[0] <- attention of batch 0;  ow.prime()   # reduce + maps of batch 0 (serial)
+        rows[1 % n] <- attention of batch 1;  ow.prime2()   # reduce of batch 1 (serial)
+        for k in 0 .. N-1:
+            images[k % n] <- batch k;  rows[(k+2) % n] <- attention of batch k+2 (if any)
+            out = ow.step()                            # R(k) || M(k+1) || A(k+2)   -> outs[k % n]
+    i.e. the attention runs two batches ahead of the images (``ow.flush()`` = R alone, for a tail).  Every step is
+    bit-identical to ``warp_from_attention_stack`` on its batch (same kernels, same arguments)."""
+
+    def __init__(self, images, rows, starts: torch.Tensor, out_size=None, channels_last: bool = False,
+                 mode: str = "cv2", pattern: str = "auto"):
+        if pattern not in ("auto", "fused", "dag", "join"):
+            raise ValueError("OverlappedWarp: pattern must be 'auto', 'fused', 'dag' or 'join'")
+        self.pattern = pattern
+        self.images = list(images) if isinstance(images, (list, tuple)) else [images]
+        self.rows = list(rows) if isinstance(rows, (list, tuple)) else [rows]
+        if len(self.images) != len(self.rows) or not self.images:
+            raise ValueError("OverlappedWarp: images and rows must be rings of the same length")
+        dev = require_gpu(*self.images, *self.rows, starts)
+        if not all(t.is_contiguous() for t in self.images + self.rows + [starts]):
+            raise ValueError("OverlappedWarp: static input buffers must be contiguous (the graph holds raw pointers)")
+        if any(r.dtype != torch.float32 or r.dim() != 4 or r.shape != self.rows[0].shape for r in self.rows):
+            raise TypeError("OverlappedWarp: float32 attention rows [T,B,heads,kv] of one shape expected")
+        if any(i.shape != self.images[0].shape or i.dtype != self.images[0].dtype for i in self.images):
+            raise ValueError("OverlappedWarp: every image buffer of the ring must have the same shape and dtype")
+        self.n = len(self.images)
+        self.starts = starts
         self.channels_last, self.mode = channels_last, mode
-        H, W = (images.shape[1], images.shape[2]) if channels_last else (images.shape[2], images.shape[3])
+        img0 = self.images[0]
+        H, W = (img0.shape[1], img0.shape[2]) if channels_last else (img0.shape[2], img0.shape[3])
         self.size_hw = (H, W)
         self.out_size = out_size
-        T = rows.shape[0]
-        self.starts_tiled = starts.repeat(T)
-        B = images.shape[0]
+        T = self.rows[0].shape[0]
+        self.starts_tiled = starts.repeat(T).contiguous()
+        B = img0.shape[0]
         Ho, Wo = (H, W) if out_size is None else out_size
-        shape = (B, Ho, Wo, images.shape[3]) if channels_last else (B, images.shape[1], Ho, Wo)
-        self.out = torch.empty(shape, device=dev, dtype=images.dtype)
-        self.cur = 0
+        shape = (B, Ho, Wo, img0.shape[3]) if channels_last else (B, img0.shape[1], Ho, Wo)
+        self.outs = [torch.empty(shape, device=dev, dtype=img0.dtype) for _ in range(self.n)]
+        self.cur = 0                 # which (steps, maps) buffer set the next resample reads
+        self.k = 0                   # ring position of the next resample
+        self._dev = dev
         self._sideM = torch.cuda.Stream(device=dev)
         self._sideA = torch.cuda.Stream(device=dev)
-        self._graphs = [None, None]
-        self._many = {}
+        self._graphs = {}
         # both buffer sets, filled once outside capture (allocations, lazily built tables)
-        self.steps = [attention_step_maps(self.rows, self.starts, ae.NUM_IMAGE_TOKENS, self.starts_tiled) for _ in (0, 1)]
+        self.steps = [attention_step_maps(self.rows[0], self.starts, ae.NUM_IMAGE_TOKENS, self.starts_tiled) for _ in (0, 1)]
         self.maps = [axis_maps_from_attention_steps(self.steps[i], self.size_hw, self.out_size) for i in (0, 1)]
-        cu.remap_separable(self.images, *self.maps[0], mode=self.mode, channels_last=self.channels_last, out=self.out)
+        cu.remap_separable(self.images[0], *self.maps[0], mode=self.mode, channels_last=self.channels_last, out=self.outs[0])
         torch.cuda.synchronize(dev)
-        for i in (0, 1):
-            self._graphs[i] = self._capture(i)
+        g = int(round(ae.NUM_IMAGE_TOKENS ** 0.5))
+        self._inv = (_tables.right_inverse_inv(g, W, 1e-8, dev), _tables.right_inverse_inv(g, H, 1e-8, dev))
+        if self.pattern in ("auto", "fused"):
+            # one launch per step (attwarp_warp_step_fused) when the shapes are eligible: float32 images on the staged
+            # resample, float32 rows
+            try:
+                if img0.dtype != torch.float32:
+                    raise _lib.AttWarpError("fused step: float32 images only")
+                self._fused_step(0, 0)
+                torch.cuda.synchronize(dev)
+                self.pattern = "fused"
+            except _lib.AttWarpError:
+                if self.pattern == "fused":
+                    raise
+                self.pattern = "dag"
+            # the trial step overwrote maps[1] / steps[1] with what they held anyway (same inputs)
 
-    def _reduce(self, i):
-        """A: rows -> steps[i]"""
-        T, B, heads, kv = self.rows.shape
-        ae.attn_reduce_step(self.rows.view(T * B, heads, 1, kv), self.starts_tiled, ae.NUM_IMAGE_TOKENS,
+    def _fused_step(self, c, k):
+        """R(k) | M(k+1) | A(k+2) as ONE launch (block ranges of one grid)."""
+        img, out = self.images[k % self.n], self.outs[k % self.n]
+        rows = self.rows[(k + 2) % self.n]
+        T, B, heads, kv = rows.shape
+        if self.channels_last:
+            _, H, W, C = img.shape
+            _, Ho, Wo, _ = out.shape
+        else:
+            _, C, H, W = img.shape
+            _, _, Ho, Wo = out.shape
+        mx, my = self.maps[c]
+        nx, ny = self.maps[1 - c]
+        g = int(round(ae.NUM_IMAGE_TOKENS ** 0.5))
+        with torch.cuda.device(self._dev):
+            call("attwarp_warp_step_fused", ptr(img), ptr(out), _lib.HWC if self.channels_last else _lib.CHW, B, C, H, W,
+                 Ho, Wo, ptr(mx), ptr(my), _lib.MODE_IDS[self.mode],
+                 ptr(self.steps[c]), T, g, ptr(self._inv[0]), ptr(self._inv[1]), ptr(nx), ptr(ny),
+                 ptr(rows), T * B, heads, kv, ptr(self.starts_tiled), T * B, ae.NUM_IMAGE_TOKENS, ptr(self.steps[1 - c]),
+                 stream_ptr(self._dev))
+
+    @property
+    def out(self) -> torch.Tensor:
+        """Output buffer of the most recent step."""
+        return self.outs[(self.k - 1) % self.n]
+
+    def _reduce(self, i, r):
+        """A: rows[r] -> steps[i]"""
+        T, B, heads, kv = self.rows[r].shape
+        ae.attn_reduce_step(self.rows[r].view(T * B, heads, 1, kv), self.starts_tiled, ae.NUM_IMAGE_TOKENS,
                             out=self.steps[i].view(T * B, ae.NUM_IMAGE_TOKENS))
 
     def _maps(self, i_steps, i_maps):
         """M: steps[i_steps] -> maps[i_maps]"""
         axis_maps_from_attention_steps(self.steps[i_steps], self.size_hw, self.out_size, maps_out=self.maps[i_maps])
 
-    def _resample(self, i):
-        cu.remap_separable(self.images, *self.maps[i], mode=self.mode, channels_last=self.channels_last, out=self.out)
+    def _resample(self, i, r):
+        cu.remap_separable(self.images[r], *self.maps[i], mode=self.mode, channels_last=self.channels_last,
+                           out=self.outs[r])
 
-    def _capture(self, i, unroll: int = 1):
-        """graph: ``unroll`` consecutive steps starting with buffer set c = i; step u is
-        R: resample with maps[c]  ||  M: steps[c] -> maps[1-c]  ||  A: rows -> steps[1-c],   joined before step u+1."""
+    def _capture(self, c, k, unroll: int = 1):
+        """graph: ``unroll`` consecutive steps starting with buffer set c at ring position k.  Step u launches
+        R(k): resample images[k] with maps[c] | M(k+1): steps[c] -> maps[1-c] | A(k+2): rows[k+2] -> steps[1-c].
+        pattern "dag": R and A alternate on ONE stream (both are bandwidth-bound: side by side they would only share
+        the same HBM), the latency-bound M runs on a side stream with exactly the edges the buffers need -- M(k+1) after
+        A(k+1) and R(k-1) (which read maps[1-c]), R(k+1) after M(k+1), A(k+3) after M(k+1) (which read steps[c]) -- so the
+        main stream never waits for a kernel that has not long finished.  pattern "join": three branches forked and
+        joined in every step."""
         g = torch.cuda.CUDAGraph()
-        main = torch.cuda.Stream(device=self.out.device)
+        main = torch.cuda.Stream(device=self._dev)
         main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main):
             with torch.cuda.graph(g, stream=main):
-                c = i
-                for _ in range(unroll):
-                    self._sideM.wait_stream(main)                    # fork
-                    self._sideA.wait_stream(main)
-                    with torch.cuda.stream(self._sideA):
-                        self._reduce(1 - c)
-                    with torch.cuda.stream(self._sideM):
-                        self._maps(c, 1 - c)
-                    self._resample(c)
-                    main.wait_stream(self._sideM)                    # join
-                    main.wait_stream(self._sideA)
-                    c ^= 1
+                if self.pattern == "fused":
+                    for u in range(unroll):
+                        self._fused_step(c, k)
+                        c ^= 1
+                        k += 1
+                elif self.pattern == "dag":
+                    for u in range(unroll):
+                        # main so far: ..., A(k+1), R(k-1) [previous step: R then A]; side: ..., M(k)
+                        self._sideM.wait_stream(main)                # M(k+1) after A(k+1) and R(k-1)
+                        with torch.cuda.stream(self._sideM):
+                            self._maps(c, 1 - c)
+                        self._resample(c, k % self.n)                # R(k) needs M(k): joined at the end of step u-1
+                        self._reduce(1 - c, (k + 2) % self.n)        # A(k+2) overwrites steps[1-c], read by M(k): done
+                        main.wait_stream(self._sideM)                # next R needs M(k+1); next A overwrites steps[c]
+                        c ^= 1
+                        k += 1
+                else:
+                    for u in range(unroll):
+                        self._sideM.wait_stream(main)                # fork
+                        self._sideA.wait_stream(main)
+                        with torch.cuda.stream(self._sideA):
+                            self._reduce(1 - c, (k + 2) % self.n)
+                        with torch.cuda.stream(self._sideM):
+                            self._maps(c, 1 - c)
+                        self._resample(c, k % self.n)
+                        main.wait_stream(self._sideM)                # join
+                        main.wait_stream(self._sideA)
+                        c ^= 1
+                        k += 1
         torch.cuda.current_stream().wait_stream(main)
         return g
 
+    def _graph(self, unroll):
+        key = (self.cur, self.k % self.n, unroll)
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(self.cur, self.k % self.n, unroll)
+        return self._graphs[key]
+
     def run(self, n: int, unroll: int = 8) -> torch.Tensor:
-        """n steps on the buffers as they are (steady-state measurement / identical consecutive batches): graphs of
-        ``unroll`` steps (one host call per ``unroll`` steps), then single steps for the remainder."""
-        unroll -= unroll % 2                                         # an even number of steps returns to the same buffer set
-        if unroll >= 2 and n >= unroll:
-            key = (self.cur, unroll)
-            if key not in self._many:
-                self._many[key] = self._capture(self.cur, unroll)
-            while n >= unroll:
-                self._many[key].replay()
-                n -= unroll
+        """n steps on the buffers as they are (steady-state measurement / a producer that stays ahead of the ring):
+        graphs of ``unroll`` steps (one host call per ``unroll`` steps), then single steps for the remainder.  With a
+        ring of n buffers a graph of lcm(2, n)-multiple length returns to the state it started from and is re-used."""
+        unroll -= unroll % 2
+        if unroll >= 2 and self.n > 1:
+            import math
+            period = math.lcm(2, self.n)
+            unroll = max(period, unroll - unroll % period)
+        while unroll >= 2 and n >= unroll:
+            self._graph(unroll).replay()
+            self.cur ^= unroll & 1
+            self.k += unroll
+            n -= unroll
         for _ in range(n):
             self.step()
         return self.out
 
+    def reset(self):
+        """Back to ring position 0 / buffer set 0 (a new stream on the same static buffers; prime() again)."""
+        self.cur = 0
+        self.k = 0
+
     def prime(self):
-        """Reduce + maps of batch 0 into the current buffer set (serial, outside the graph)."""
-        self._reduce(self.cur)
+        """Reduce + maps of the batch at the current ring position into the current buffer set (serial, no graph)."""
+        self._reduce(self.cur, self.k % self.n)
         self._maps(self.cur, self.cur)
 
     def prime2(self):
-        """Reduce of batch 1 into the current steps buffer (its maps are built by the first step)."""
-        self._reduce(self.cur)
+        """Reduce of the batch after it into the current steps buffer (its maps are built by the first step)."""
+        self._reduce(self.cur, (self.k + 1) % self.n)
 
     def step(self) -> torch.Tensor:
-        self._graphs[self.cur].replay()
+        self._graph(1).replay()
         self.cur ^= 1
+        self.k += 1
         return self.out
 
     def flush(self) -> torch.Tensor:
-        """Resample with the current maps alone."""
-        self._resample(self.cur)
+        """Resample of the batch at the current ring position with the current maps alone, then advance (tail of a
+        stream: no further attention to reduce)."""
+        self._resample(self.cur, self.k % self.n)
+        self.k += 1
         return self.out
+
+    def tail(self) -> torch.Tensor:
+        """The last two batches of a stream that ends: R(N-2) + M(N-1), then R(N-1)."""
+        self._resample(self.cur, self.k % self.n)
+        self._maps(self.cur, 1 - self.cur)
+        self.cur ^= 1
+        self.k += 1
+        return self.flush()

@@ -62,34 +62,96 @@ def _free_port() -> int:
 
 
 def launch_ranks(n: int, argv) -> int:
+    """Start n ranks, watch ALL of them: the first rank that exits non-zero (or the time limit) ends the job at once --
+    the others are killed (the exact PIDs this parent started) instead of waiting in a rendezvous or a barrier for a
+    peer that will never arrive -- and the parent returns 1."""
+    import tempfile
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, ATTWARP_BENCH_CHILD="1")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        out = out0 if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=out))
-    try:
-        line0, _ = procs[0].communicate(timeout=float(os.environ.get("ATTWARP_BENCH_TIMEOUT_S", "3000")))
-        rcs = [procs[0].returncode] + [p.wait(timeout=120) for p in procs[1:]]
-    except subprocess.TimeoutExpired:
-        print("[bench] ranks did not finish in time; terminating them", file=sys.stderr)
-        for p in procs:
-            if p.poll() is None:
-                p.kill()                         # the exact PIDs this parent started
-        return 1
-    if any(rcs):
-        print(f"[bench] rank exit codes {rcs}: at least one rank failed", file=sys.stderr)
+
+    def kill_all():
         for p in procs:
             if p.poll() is None:
                 p.kill()
-        return 1
-    lines = [l for l in line0.decode().splitlines() if l.startswith("{")]
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    deadline = time.monotonic() + float(os.environ.get("ATTWARP_BENCH_TIMEOUT_S", "3000"))
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            print(f"[bench] rank(s) failed (rank, exit code): {bad}; terminating the others", file=sys.stderr)
+            kill_all()
+            return 1
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.monotonic() > deadline:
+            print("[bench] ranks did not finish in time; terminating them", file=sys.stderr)
+            kill_all()
+            return 1
+        time.sleep(0.05)
+    out0.seek(0)
+    lines = [l for l in out0.read().decode().splitlines() if l.startswith("{")]
     if not lines:
         print("[bench] rank 0 printed no JSON line", file=sys.stderr)
         return 1
     print(lines[-1], flush=True)
     return 0
+
+
+def pin_to_local_cores(local_rank: int, world: int):
+    """Pin this rank to the host cores next to ITS GPU before torch is imported (launch threads, the RCCL proxy and the
+    caching allocator then stay on that socket).  The GPU's NUMA-local cpulist is read from sysfs through the KFD
+    topology (no HIP call: GPU nodes in KFD order = HIP device order without HIP_VISIBLE_DEVICES); ranks that share a
+    cpulist split it evenly.  Falls back to an even split of the allowed cores.  Returns a short description."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    cpus, how = None, "even split of the allowed cores"
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        gpus = []
+        for node in sorted(os.listdir(base), key=int):
+            props = dict(l.split(None, 1) for l in open(f"{base}/{node}/properties").read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props["drm_render_minor"]))
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            gpus = [gpus[int(v)] for v in vis.split(",") if v.strip().isdigit() and int(v) < len(gpus)]
+        minor = gpus[local_rank]
+        txt = open(f"/sys/class/drm/renderD{minor}/device/local_cpulist").read().strip()
+        local = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            local.update(range(int(a), int(b or a) + 1))
+        local = sorted(local & set(allowed))
+        if local:
+            sharers = [g for g in gpus[:world] if open(f"/sys/class/drm/renderD{g}/device/local_cpulist").read().strip() == txt]
+            idx, cnt = sharers.index(minor), len(sharers)
+            per = max(1, len(local) // cnt)
+            cpus = local[idx * per:(idx + 1) * per] or local
+            how = f"NUMA-local cores of renderD{minor} ({txt}), share {idx + 1}/{cnt}"
+    except Exception:
+        cpus = None
+    if not cpus:
+        per = max(1, len(allowed) // max(world, 1))
+        cpus = allowed[(local_rank % max(world, 1)) * per:(local_rank % max(world, 1) + 1) * per] or allowed
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return f"{len(cpus)} cores [{cpus[0]}..{cpus[-1]}]: {how}"
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -293,6 +355,89 @@ def load_pmc_traffic(workload: str, mode: str):
         return None
 
 
+def peaked_rows(step, torch):
+    """Attention rows whose image tokens carry one 3x3 hot spot x100 per image, normalised per row."""
+    T, B, Hh, kv = step.rows.shape
+    rows = torch.full((T, B, Hh, kv), 1.0, device=step.rows.device)
+    g = torch.Generator(device=step.rows.device).manual_seed(7)
+    cy = torch.randint(1, 23, (B,), device=step.rows.device, generator=g)
+    cx = torch.randint(1, 23, (B,), device=step.rows.device, generator=g)
+    for b in range(B):
+        st = int(step.starts[b])
+        for dy in (-1, 0, 1):
+            i0 = st + (int(cy[b]) + dy) * 24 + int(cx[b]) - 1
+            rows[:, b, :, i0:i0 + 3] = 100.0
+    return rows / rows.sum(-1, keepdim=True)
+
+
+def overlapped_run(ow, K: int):
+    """Exactly K of each kernel: reduce + maps of batch 0 and reduce of batch 1 serially, K-2 overlapped steps
+    R(k) || M(k+1) || A(k+2) as HIP-graph replays (graphs of 8 steps + single steps), then the two tail resamples."""
+    ow.reset()
+    ow.prime()
+    ow.prime2()
+    ow.run(K - 2)
+    ow.tail()
+
+
+def time_overlapped(ow, K: int, W: int, D):
+    """Graph path: one untimed pass of the same K steps (captures every graph the timed pass replays) + W further
+    untimed steps, then exactly K steps between barrier + synchronize; no host call per kernel, no event records."""
+    import torch
+    overlapped_run(ow, K)
+    if W > 0:
+        ow.reset(); ow.prime(); ow.prime2(); ow.run(W); ow.tail()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    overlapped_run(ow, K)
+    torch.cuda.synchronize()
+    D.barrier()
+    wall = time.perf_counter() - t0
+    return D.max_over_ranks(wall), wall
+
+
+def step_bytes(B: int, S: int) -> float:
+    """Algorithmic bytes of one step: the resample's 2*S*S*3*4 per image + the attention rows the reduce
+    reads, T*heads*576*4 per image."""
+    return float(B) * (2.0 * S * S * 3 * 4 + T_STEPS * HEADS * NTOK * 4)
+
+
+def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline):
+    """configs[1] / configs[3]'s per-rank batch: the overlapped graph path over a ring of independent batches (>= 2 GiB,
+    every step streams from HBM) as the headline, the eager three-launch step with HIP events beside it."""
+    st = Step(B, S, dev, seed=seed, mode=mode, layout=layout)
+    for _ in range(5):
+        st()
+    ow = pipeline.OverlappedWarp([x[0] for x in st.sets], [x[1] for x in st.sets], st.starts,
+                                 channels_last=(layout == "hwc"), mode=mode)
+    wall, wall_local = time_overlapped(ow, K, W, D)
+    # serial reference of every ring slot, AFTER the timed region: the overlapped outputs must equal it bit for bit
+    same = True
+    for r in range(min(ow.n, K)):                  # the slots the K timed steps wrote
+        ref = pipeline.warp_from_attention_stack(st.sets[r][0], st.sets[r][1], st.starts, channels_last=(layout == "hwc"),
+                                                 mode=mode)
+        same = same and bool(torch.equal(ow.outs[r], ref))
+        del ref
+    w_e, _ = time_steps(st, K, W, D)
+    sb = step_bytes(B, S)
+    ms = wall / K * 1e3
+    res = {"ms_per_step": round(ms, 4), "images_per_s": round(B * K / wall, 1),
+           "step_algorithmic_bytes": sb, "step_TBps": round(sb / (ms * 1e-3) / 1e12, 3),
+           "step_frac_of_hbm_peak": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "rotating_batches": ow.n, "bit_identical_to_serial": same,
+           "path": "pipeline.OverlappedWarp: resample(k) || maps(k+1) || reduce(k+2) as three branches of one HIP graph, "
+                   f"graphs of 8 steps, ring of {ow.n} independent batches (>= 2 GiB: every step streams from HBM), exactly "
+                   f"{K} of each kernel in the timed region, no host call per kernel",
+           "eager": {"ms_per_step": round(w_e / K * 1e3, 4), "images_per_s": round(B * K / w_e, 1),
+                     "step_TBps": round(sb / (w_e / K) / 1e12, 3),
+                     "stages_ms": [round(v, 4) for v in st.stage_ms()],
+                     "roofline": roofline_of(st),
+                     "path": "three eager launches per step with HIP events between them (the events are where the "
+                             "per-kernel durations come from)"}}
+    return res, wall, wall_local, st, ow
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,12 +464,17 @@ def main():
     if world_env != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}; start it as "
                          f"`python bench.py --gpus {args.gpus}` or under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if os.environ.get("ATTWARP_BENCH_FAIL_RANK") == str(rank_env):   # test hook of the launcher (tests/test_dist_gloo.py)
+        raise SystemExit(3)
 
     # all-core CPU baseline: forked workers, so it runs BEFORE anything initialises the GPU in this process
     cpu_all = None
     want_cpu = rank_env == 0 and world_env == 1 and not args.no_cpu_baseline and not args.dry_run
     if want_cpu:
         cpu_all = cpu_baseline_all_cores(S, args.mode)
+    # one rank per GPU: stay on the cores next to that GPU (before torch starts its threads)
+    affinity = pin_to_local_cores(int(os.environ.get("LOCAL_RANK", "0")) if args.device is None else args.device,
+                                  world_env) if world_env > 1 else None
 
     import numpy as np
     import torch
@@ -334,6 +484,7 @@ def main():
     if args.device is not None:
         local = args.device
     _lib.load()
+    ranks_seen = [int(v) for v in D.all_gather_counters({"rank": float(rank)})["rank"]]
 
     if args.dry_run:
         from attwarp_amd.model import MarginalNet
@@ -349,6 +500,7 @@ def main():
             print(json.dumps({"metric": "warped images/sec", "value": None, "unit": "images/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
                               "weights_broadcast": {"bytes": nbytes}, "per_rank_images": per["images"],
+                              "ranks_seen": ranks_seen, "cpu_affinity_rank0": affinity,
                               "max_wall_s": wall, "config": {"workload": args.workload, "batch_per_gpu": B}}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -358,6 +510,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from attwarp_amd import pipeline
 
     # start-up collective of the multi-GPU path: one RCCL broadcast of MarginalNet weights (untimed)
     bcast = None
@@ -371,21 +524,42 @@ def main():
         bcast = {"bytes": nbytes, "ms": round((time.perf_counter() - t0) * 1e3, 3)}
         del net
 
-    step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
-    # device pre-conditioning, untimed and outside the contract's W warm-up steps: the first ~20 launches after start-up
-    # run 1-2 % slower (clock ramp; rocprofv3 shows their maxima 15 % above the mean), which would only penalise whichever
-    # measurement comes first.  The timed region below is still W warm-up steps + exactly K timed steps.
-    for _ in range(PREWARM_STEPS):
-        step()
-    torch.cuda.synchronize()
-    wall, wall_local = time_steps(step, args.steps, args.warmup, D)
+    mode_txt = ("cv2.remap arithmetic: 1/32-px coordinates, 4 table weights" if args.mode == "cv2"
+                else "unquantised bilinear = grid_sample")
+    workload_txt = (f"batch-{B} {S}x{S}x3 float32 {args.layout.upper()} images per GPU + attention rows "
+                    f"[T={T_STEPS},B,{HEADS},{KV}] float32 -> reduce -> 24x24 -> marginals -> CDF -> inverse maps -> "
+                    f"bilinear warp, mode={args.mode} ({mode_txt}) (BASELINE configs[{cfg_idx}])")
+    small = args.workload != "1024"
+    extra = {}
+    if small:
+        # configs[1] / configs[3]: the step is ~0.09-0.25 ms, so the timed loop is a HIP-graph replay with no host call
+        # per kernel (the eager three-launch line with HIP events is attached as "also_eager")
+        res, wall, wall_local, step, ow = small_workload(B, S, dev, 1234 + rank, args.mode, args.layout, args.steps,
+                                                         args.warmup, D, torch, pipeline)
+        roof = res["eager"]["roofline"]
+        roof["measured_in"] = "the eager pass right after the timed graph region (a graph replay has no per-kernel events)"
+        extra = {"step_algorithmic_bytes": res["step_algorithmic_bytes"], "step_TBps": res["step_TBps"],
+                 "step_frac_of_hbm_peak": res["step_frac_of_hbm_peak"], "bit_identical_to_serial": res["bit_identical_to_serial"],
+                 "path": res["path"], "also_eager": res["eager"]}
+        nrot = res["rotating_batches"]
+        del ow
+    else:
+        step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
+        # device pre-conditioning, untimed and outside the contract's W warm-up steps: the first ~20 launches after
+        # start-up run 1-2 % slower (clock ramp), which would only penalise whichever measurement comes first.
+        for _ in range(PREWARM_STEPS):
+            step()
+        torch.cuda.synchronize()
+        wall, wall_local = time_steps(step, args.steps, args.warmup, D)
+        roof = roofline_of(step, load_pmc_traffic(args.workload, args.mode))
+        if roof["traffic"] is not None:                 # a committed constant, not a counter read in this run
+            roof["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command on an earlier lease)")
+        nrot = step.nrot
+    roof["calibration"] = calibration_of(step)
     per_rank = D.all_gather_counters({"images_per_s": B * args.steps / wall_local})
     ms_per_step = wall / args.steps * 1e3
     value = world * B * args.steps / wall
-    roof = roofline_of(step, load_pmc_traffic(args.workload, args.mode))
-    if roof["traffic"] is not None:                 # a committed constant, not a counter read in this run
-        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on an earlier lease)"
-    roof["calibration"] = calibration_of(step)
 
     result = {
         "metric": "warped images/sec",
@@ -400,22 +574,20 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "prewarm_steps": PREWARM_STEPS,
-        "config": {"workload": f"batch-{B} {S}x{S}x3 float32 {args.layout.upper()} images per GPU + attention rows "
-                               f"[T={T_STEPS},B,{HEADS},{KV}] float32 -> reduce -> 24x24 -> marginals -> CDF -> "
-                               f"inverse maps -> bilinear warp, mode={args.mode} "
-                               f"({'cv2.remap arithmetic: 1/32-px coordinates, 4 table weights' if args.mode == 'cv2' else 'unquantised bilinear = grid_sample'}) "
-                               f"(BASELINE configs[{cfg_idx}])",
-                   "mode": args.mode, "batch_per_gpu": B, "image_size": S, "layout": args.layout.upper(),
-                   "global_batch": world * B, "rotating_batches": step.nrot,
+        "prewarm_steps": 0 if small else PREWARM_STEPS,
+        "config": {"workload": workload_txt, "mode": args.mode, "batch_per_gpu": B, "image_size": S,
+                   "layout": args.layout.upper(), "global_batch": world * B, "rotating_batches": nrot,
                    "sharding": "contiguous image blocks per rank, no data-path collective"},
         "roofline": roof,
     }
+    result.update(extra)
     st_ms = step.stage_ms()
     result["stages_ms"] = {"attn_reduce_step_kernel": round(st_ms[0], 4), "axis_maps_from_steps_kernel": round(st_ms[1], 4),
                            "remap_rows_kernel": round(st_ms[2], 4)}
     if world > 1:
         result["per_rank_images_per_s"] = [round(v, 1) for v in per_rank["images_per_s"]]
+        result["rccl_ranks_seen"] = ranks_seen
+        result["cpu_affinity_rank0"] = affinity
     if bcast:
         result["weights_broadcast"] = bcast
 
@@ -425,7 +597,8 @@ def main():
         if args.layout == "chw":
             img = np.ascontiguousarray(img.transpose(0, 2, 3, 1))
         n, dt, out0 = _cpu_loop(img, step.rows[:, :n_max].cpu().numpy(), step.starts[:n_max].cpu().numpy(), S, args.mode, 10.0)
-        g0 = step.out[0].cpu().numpy()
+        g0 = pipeline.warp_from_attention_stack(step.img[:1], step.rows[:, :1].contiguous(), step.starts[:1],
+                                                channels_last=(args.layout == "hwc"), mode=args.mode)[0].cpu().numpy()
         if args.layout == "chw":
             g0 = g0.transpose(1, 2, 0)
         result["cpu_baseline"] = {
@@ -438,7 +611,7 @@ def main():
                                      f"{S}x{S} images for ~10 s; sum of per-process rates"),
         }
 
-    if world == 1 and not args.no_also:
+    if world == 1 and not args.no_also and not small:
         other = "exact" if args.mode == "cv2" else "cv2"
         step.mode = other                                     # same buffers, the other arithmetic
         w2, _ = time_steps(step, args.steps, args.warmup, D)
@@ -454,42 +627,32 @@ def main():
                                   else f"same batch as [B,S,S,3], mode={args.mode}",
                                   "value": round(B * args.steps / w3, 1), "unit": "images/s",
                                   "ms_per_step": round(w3 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+        # SURVEY 8d "value distributions to also run": peaked attention (one 3x3 hot spot x100: strong magnification
+        # there, minification elsewhere) and all-zero attention (the uniform fallback, AGW/new_method.py:231-239 /
+        # clamp_min(1e-6) in MN/checkpoint_utils.py:36) on the same images
+        step.set_layout(args.layout)
+        for name, rows in (("peaked", peaked_rows(step, torch)), ("zero_attention", torch.zeros_like(step.rows))):
+            keep = step.sets
+            step.sets = [(img, rows, out) for (img, _, out) in keep]
+            w4, _ = time_steps(step, args.steps, args.warmup, D)
+            result[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}",
+                                      "value": round(B * args.steps / w4, 1), "unit": "images/s",
+                                      "ms_per_step": round(w4 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+            step.sets = keep
+            del rows
     del step
     torch.cuda.empty_cache()
 
     if world == 1 and args.workload == "1024" and not args.no_also:
-        B2, S2, _ = WORKLOADS["336"]
-        n2 = max(args.steps, 50)
-        step2 = Step(B2, S2, dev, seed=99, mode=args.mode, layout=args.layout)
-        w4, _ = time_steps(step2, n2, args.warmup, D)
-        st2 = step2.stage_ms()
-        result["also"] = {"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[1]), mode={args.mode}, eager launches, rotating over "
-                                      f"{step2.nrot} independent batches (a single 279 MB batch would sit in the 256 MB Infinity Cache)",
-                          "rotating_batches": step2.nrot,
-                          "value": round(B2 * n2 / w4, 1), "unit": "images/s", "ms_per_step": round(w4 / n2 * 1e3, 4),
-                          "stages_ms": [round(v, 4) for v in st2], "roofline": roofline_of(step2)}
-        # the same workload with the resample of batch k overlapped with reduce + maps of batch k+1 (one HIP graph with
-        # two branches, attwarp_amd.pipeline.OverlappedWarp): exactly n2 of each kernel inside the timed region
-        from attwarp_amd import pipeline as _pl
-        ow = _pl.OverlappedWarp(step2.img, step2.rows, step2.starts, channels_last=(args.layout == "hwc"), mode=args.mode)
-        for _ in range(args.warmup):
-            ow.prime(); ow.prime2(); ow.run(8); ow.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ow.prime()                               # reduce + maps of batch 0
-        ow.prime2()                              # reduce of batch 1
-        ow.run(n2 - 2)                           # R(k) || M(k+1) || A(k+2): graphs of 8 steps + single steps
-        ow._maps(ow.cur, 1 - ow.cur); ow.flush(); ow.cur ^= 1; ow.flush()     # tail: R(n-2), M(n-1), R(n-1)
-        torch.cuda.synchronize()
-        w5 = time.perf_counter() - t0
-        same = bool(torch.equal(ow.out, step2.out))
-        result["also_overlapped"] = {"workload": f"batch-{B2} {S2}x{S2}, resample(k) || maps(k+1) || reduce(k+2) as three branches of "
-                                                 f"one HIP graph (pipeline.OverlappedWarp), exactly {n2} of each kernel timed; ONE batch "
-                                                 f"re-used by every step (static graph buffers): its 279 MB largely stay in the Infinity Cache",
-                                     "value": round(B2 * n2 / w5, 1),
-                                     "unit": "images/s", "ms_per_step": round(w5 / n2 * 1e3, 4),
-                                     "bit_identical_to_serial": same}
-        del step2, ow
+        n2 = max(args.steps, 48)
+        for key, wl in (("also", "336"), ("also_336x256", "336x256")):
+            B2, S2, cfg2 = WORKLOADS[wl]
+            res2, _, _, st2, ow2 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline)
+            res2 = dict({"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[{cfg2}]), mode={args.mode}",
+                         "value": res2["images_per_s"], "unit": "images/s", "steps": n2}, **res2)
+            result[key] = res2
+            del st2, ow2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)

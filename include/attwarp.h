@@ -200,6 +200,25 @@ ATTWARP_API int attwarp_axis_maps_from_steps(const float* steps, int T, int B, i
                                  const double* inv_x, const double* inv_y, float* map_x, float* map_y,
                                  float* att_out, void* stream);
 
+/* ---- one step of a STREAM of equally shaped batches in ONE launch (pipeline.OverlappedWarp; replaces the three
+ * launches reduce -> maps -> resample of AGW/main_batched.py's per-batch chain when batches follow each other):
+ *   R  the A12 resample of batch k      src [B,...] float32 + map_x/map_y (built by the previous step)  -> dst
+ *   M  the maps of batch k+1            steps_in [T,B,g*g] (previous step's reduce) -> map_x_next / map_y_next
+ *   A  the A1 reduce of batch k+2       rows [n_rows = T*B, heads, kv_len] float32, row j uses starts[j % starts_mod]
+ *                                       -> steps_out [T*B, ntok]
+ * as block ranges of one grid (map blocks first, then reduce and resample blocks interleaved in chunks of 8): no
+ * launch boundary, no queue hand-off inside a step.  The three pieces work on different batches and must not alias
+ * (steps_out != steps_in, map_*_next != map_*).  M (steps_in == NULL) and A (rows == NULL) are optional.  Same
+ * arithmetic, bit for bit, as attwarp_remap_bilinear / attwarp_axis_maps_from_steps / attwarp_attn_reduce_step.
+ * ATTWARP_E_UNSUPPORTED when the image shape takes the generic resample (rows wider than 4096 floats, unaligned
+ * rows), ntok is not a multiple of 4 or > 768, or g > 32: use the three separate entry points then. */
+ATTWARP_API int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
+                            int W_out, const float* map_x, const float* map_y, int mode,
+                            const float* steps_in, int T, int g, const double* inv_x, const double* inv_y,
+                            float* map_x_next, float* map_y_next,
+                            const float* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
+                            int starts_mod, int ntok, float* steps_out, void* stream);
+
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.
  * ws: workspace of attwarp_axis_sums_workspace_bytes(B,h,w) bytes. */

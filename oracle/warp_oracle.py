@@ -30,7 +30,11 @@ Reduction-order convention: wherever the reference calls a library reduction
 whose association order is implementation defined (torch ``sum``/``mean`` on
 float32), the oracle accumulates in float64 and rounds once.  The HIP kernels
 do the same, so HIP == oracle bit-for-bit there, and both sit within a couple
-of float32 ulps of what torch produced for the goldens.
+of float32 ulps of what torch produced for the goldens.  One exception: the
+attention aggregation A1 (the only reduction that reads a bandwidth-relevant
+amount of data, in the model's float16 on the model's GPU) accumulates in
+float32 like torch's GPU reductions, in a fixed order written down in
+``_row_sums_f32_tree`` / ``_head_sums_f32``.
 """
 from __future__ import annotations
 
@@ -54,14 +58,54 @@ def _round_to(x: np.ndarray, dtype) -> np.ndarray:
     return np.asarray(x).astype(dtype)
 
 
+_XOR = {o: np.arange(64) ^ o for o in (32, 16, 8, 4, 2, 1)}
+
+
+def _row_sums_f32_tree(x: np.ndarray) -> np.ndarray:
+    """Sum over the last axis of a float32 array in the path's FIXED float32 order (every add rounded to float32):
+    token t belongs to lane l = (t mod 256) // 4 of 64 lanes; a lane adds its tokens four at a time,
+    ``(x[t] + x[t+1]) + (x[t+2] + x[t+3])``, the quads of successive 256-token blocks one after the other onto a
+    running sum that starts at +0; the 64 lane sums are then combined by a butterfly, ``s[l] += s[l ^ o]`` for
+    o = 32, 16, 8, 4, 2, 1.  Tokens past the end count as +0.  (This is what a 64-lane wavefront computes when every
+    lane loads four consecutive elements; it is a legitimate instance of the implementation-defined order of the
+    reference's ``a.sum(-1)`` on the GPU, AGW/attention_extraction/llava.py:392, which accumulates in float32.)"""
+    x = np.asarray(x, dtype=F32)
+    n = x.shape[-1]
+    nb = max(1, -(-n // 256))
+    xp = np.zeros(x.shape[:-1] + (nb * 256,), dtype=F32)
+    xp[..., :n] = x
+    q = xp.reshape(x.shape[:-1] + (nb, 64, 4))
+    quad = (q[..., 0] + q[..., 1]) + (q[..., 2] + q[..., 3])          # float32 adds
+    s = np.zeros(x.shape[:-1] + (64,), dtype=F32)
+    for i in range(nb):
+        s = s + quad[..., i, :]
+    for o in (32, 16, 8, 4, 2, 1):
+        s = s + s[..., _XOR[o]]
+    return s[..., 0]
+
+
+def _head_sums_f32(r: np.ndarray) -> np.ndarray:
+    """Sum over heads (axis 0) of float32 [heads, ntok] in the path's fixed order: four partial sums P_w over the heads
+    h = w, w+4, w+8, ... (ascending, starting at +0), combined as ((0 + P_0) + P_1) + P_2) + P_3."""
+    r = np.asarray(r, dtype=F32)
+    m = np.zeros(r.shape[1:], dtype=F32)
+    for w in range(4):
+        pw = np.zeros(r.shape[1:], dtype=F32)
+        for h in range(w, r.shape[0], 4):
+            pw = pw + r[h]
+        m = m + pw
+    return m
+
+
 def attn_reduce_step(attn: np.ndarray, starts: Sequence[int], ends: Sequence[int]) -> np.ndarray:
     """One generation step of ``BatchMaskHookLogger._process_attention``.
 
     Follows AGW/attention_extraction/llava.py:385-396: for each sample ``b``
     take the last query row ``attn[b, :, -1, st:ed]`` (``ed`` clipped to the kv
     length), divide every head by ``(row sum + 1e-12)`` and average over heads.
-    Arithmetic dtype = dtype of ``attn`` (float32 or float16), reductions
-    accumulated wide and rounded once (see module docstring).
+    Arithmetic dtype = dtype of ``attn`` (float32 or float16): every reference op boundary rounds to it.  The two
+    reductions accumulate in FLOAT32 -- as torch's GPU ``sum`` / ``mean`` do for float16 and float32 inputs alike
+    (llava.py:392-394 run on the model's device) -- in the fixed orders of ``_row_sums_f32_tree`` / ``_head_sums_f32``.
 
     attn: [B, heads, q, kv]  ->  [B, ntok]
     """
@@ -73,11 +117,12 @@ def attn_reduce_step(attn: np.ndarray, starts: Sequence[int], ends: Sequence[int
         st = int(starts[b])
         ed = min(int(ends[b]), kv)
         a = attn[b, :, -1, st:ed]                                   # [heads, ntok]
-        s = a.astype(F64).sum(axis=-1, keepdims=True).astype(dt)    # row sum, rounded to dt
+        s = _row_sums_f32_tree(a.astype(F32))[:, None].astype(dt)   # row sum (float32 accumulate), rounded to dt
         s = (s + dt.type(1e-12)).astype(dt)                         # 1e-12 underflows to 0 in fp16
-        r = (a / s).astype(dt)
-        m = r.astype(F64).sum(axis=0).astype(dt)                    # torch mean = sum / N
-        out.append((m / dt.type(heads)).astype(dt))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = (a.astype(F32) / s.astype(F32)).astype(dt)
+        m = _head_sums_f32(r.astype(F32)).astype(dt)                # torch mean = sum / N
+        out.append((m.astype(F32) / F32(dt.type(heads))).astype(dt))
     return np.stack(out, axis=0)
 
 

@@ -26,28 +26,54 @@
 
 #define API __attribute__((visibility("default")))
 
-/* ---- A1 + A2 (float32) ------------------------------------------------------------------ */
+/* ---- A1 + A2 (float32) ------------------------------------------------------------------
+ * A1 accumulates in float32 in the path's fixed order (oracle/warp_oracle.py::_row_sums_f32_tree, _head_sums_f32):
+ * row sum = 64 lane sums (lane = (t mod 256) / 4, quads (x0 + x1) + (x2 + x3), 256-token blocks in order) combined by
+ * the butterfly s[l] += s[l ^ o], o = 32 .. 1; head sum = ((0 + P_0) + P_1) + P_2) + P_3, P_w over heads w, w+4, ...
+ * A2 (mean over steps) accumulates in double and rounds once. */
+static float row_sum_tree(const float* r, int ntok) {
+  float s[64], t[64];
+  for (int l = 0; l < 64; ++l) s[l] = 0.0f;
+  for (int blk = 0; blk * 256 < ntok; ++blk)
+    for (int l = 0; l < 64; ++l) {
+      const int t0 = blk * 256 + 4 * l;
+      const float x0 = t0 < ntok ? r[t0] : 0.0f, x1 = t0 + 1 < ntok ? r[t0 + 1] : 0.0f;
+      const float x2 = t0 + 2 < ntok ? r[t0 + 2] : 0.0f, x3 = t0 + 3 < ntok ? r[t0 + 3] : 0.0f;
+      const float a = x0 + x1, b = x2 + x3;
+      const float q = a + b;
+      s[l] = s[l] + q;
+    }
+  for (int o = 32; o >= 1; o >>= 1) {
+    for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ o];
+    memcpy(s, t, sizeof(s));
+  }
+  return s[0];
+}
+
 API void oracle_attn_reduce_stack_f32(const float* rows, int T, int B, int heads, int kv, const int32_t* starts,
                                       int ntok, float* out /* [B,ntok] */) {
   double* acc_steps = (double*)calloc((size_t)ntok, sizeof(double));
-  double* acc_heads = (double*)calloc((size_t)ntok, sizeof(double));
+  float* pw = (float*)calloc((size_t)4 * ntok, sizeof(float));
   for (int b = 0; b < B; ++b) {
     memset(acc_steps, 0, sizeof(double) * ntok);
     for (int t = 0; t < T; ++t) {
-      memset(acc_heads, 0, sizeof(double) * ntok);
+      memset(pw, 0, sizeof(float) * 4 * ntok);
       for (int h = 0; h < heads; ++h) {
         const float* r = rows + (((size_t)t * B + b) * heads + h) * kv + starts[b];
-        double s = 0.0;
-        for (int i = 0; i < ntok; ++i) s += (double)r[i];
-        const float den = (float)s + 1e-12f;
-        for (int i = 0; i < ntok; ++i) acc_heads[i] += (double)(r[i] / den);
+        const float den = row_sum_tree(r, ntok) + 1e-12f;
+        float* p = pw + (size_t)(h & 3) * ntok;
+        for (int i = 0; i < ntok; ++i) { const float q = r[i] / den; p[i] = p[i] + q; }
       }
-      for (int i = 0; i < ntok; ++i) acc_steps[i] += (double)((float)acc_heads[i] / (float)heads);
+      for (int i = 0; i < ntok; ++i) {
+        float m = 0.0f;
+        for (int w = 0; w < 4; ++w) m = m + pw[(size_t)w * ntok + i];
+        acc_steps[i] += (double)(m / (float)heads);
+      }
     }
     for (int i = 0; i < ntok; ++i) out[(size_t)b * ntok + i] = (float)acc_steps[i] / (float)T;
   }
   free(acc_steps);
-  free(acc_heads);
+  free(pw);
 }
 
 /* ---- A6 on an [n,n] map: px over columns, py over rows ----------------------------------- */

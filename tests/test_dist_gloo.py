@@ -84,3 +84,52 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+
+
+@pytest.mark.timeout(400)
+def test_bench_self_launches_eight_ranks():
+    """The shape the driver's scaling run has: `bench.py --gpus 8` brings up 8 ranks that all see each other
+    (all_gather of the ranks), each pinned to its own share of the host cores before torch is imported."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo",
+                        "--dry-run", "--steps", "2", "--workload", "336x256"], env=_clean_env(), capture_output=True,
+                       text=True, timeout=380)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == list(range(8))
+    assert d["per_rank_images"] == [512.0] * 8
+    assert d["config"]["batch_per_gpu"] == 256
+    assert d["cpu_affinity_rank0"] is None or "cores" in d["cpu_affinity_rank0"]
+
+
+@pytest.mark.timeout(200)
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """Rank 3 exits at start-up: the parent must notice (it polls every child, not only rank 0), kill the ranks that
+    are now stuck in the rendezvous and return non-zero within seconds -- not after torch's collective timeout."""
+    import subprocess
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dist-backend", "gloo",
+                        "--dry-run", "--steps", "2"], env=dict(_clean_env(), ATTWARP_BENCH_FAIL_RANK="3"),
+                       capture_output=True, text=True, timeout=180)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0
+    assert "rank(s) failed" in r.stderr and "(3, 3)" in r.stderr, r.stderr[-1500:]
+    assert dt < 30.0, dt
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_pin_to_local_cores_is_harmless_without_a_gpu():
+    """No KFD topology here: the even split of the allowed cores is used; the process keeps a non-empty affinity."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; before = os.sched_getaffinity(0); "
+            "d = bench.pin_to_local_cores(1, 4); after = os.sched_getaffinity(0); "
+            "assert after and after <= before, (before, after); print(d)") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "cores" in r.stdout

@@ -15,6 +15,9 @@ for B in (256, 64):
     starts = (35 + torch.arange(B, device=dev) % 8).int()
     st = starts.repeat(20)
     for name, r in (("fp32", rows), ("fp16", rows.half()), ("bf16", rows.bfloat16())):
-        ms = timeit(lambda: pipeline.attention_step_maps(r, starts, 576, st))
-        nb = 20 * B * 32 * 576 * r.element_size()
-        print(f"attn step maps {name} T=20 B={B}: {ms:.4f} ms  {nb/ms/1e9:.2f} TB/s")
+        for hu in (4, 1, 2, 8):
+            from attwarp_amd import _lib
+            with _lib.debug_override(attn_hu=hu):
+                ms = timeit(lambda: pipeline.attention_step_maps(r, starts, 576, st))
+            nb = 20 * B * 32 * 576 * r.element_size()
+            print(f"attn step maps {name} T=20 B={B} HU={hu}: {ms:.4f} ms  {nb/ms/1e9:.2f} TB/s")
