@@ -76,6 +76,17 @@ def remap_bilinear(src, mx, my, layout="hwc", mode="cv2"):
     return out
 
 
+def remap_bilinear_u8(src, mx, my, mode="cv2"):
+    """uint8 [H,W,C] -> [H_out,W_out,C] (the arithmetic of warp_oracle.remap_bilinear on uint8 sources)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    mx = np.ascontiguousarray(mx, np.float32); my = np.ascontiguousarray(my, np.float32)
+    H, W, C = src.shape
+    out = np.empty((my.shape[0], mx.shape[0], C), np.uint8)
+    load().oracle_remap_bilinear_u8(_p(src), _p(out), c_int(C), c_int(H), c_int(W), c_int(my.shape[0]), c_int(mx.shape[0]),
+                                    _p(mx), _p(my), c_int(int(mode == "cv2")))
+    return out
+
+
 def warp_from_attention_stack(img, rows, start, inv_x, inv_y, layout="hwc", mode="cv2"):
     """One image through the whole path.  rows [T,heads,kv]."""
     img = np.ascontiguousarray(img, np.float32); rows = np.ascontiguousarray(rows, np.float32)

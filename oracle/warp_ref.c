@@ -254,6 +254,49 @@ API void oracle_remap_bilinear_f32(const float* src, float* dst, int layout, int
   free(fx);
 }
 
+/* ---- uint8 sources, interleaved [H,W,C] (what cv2.remap receives in AGW/new_method.py:268-271) -------------------
+ * mode 1 (cv2): int16 weights scaled by 2^15 -- round(w * 32768) saturated to int16, exact integers -- and
+ * (sum + 2^14) >> 15; mode 0 (exact): the float32 lerps of the float path, rounded half to even, saturated. */
+API void oracle_remap_bilinear_u8(const uint8_t* src, uint8_t* dst, int C, int H, int W, int Ho, int Wo, const float* mx,
+                                  const float* my, int mode) {
+  int* x0 = (int*)malloc(sizeof(int) * ((size_t)Wo * 2 + (size_t)Ho * 2));
+  int* x1 = x0 + Wo; int* y0s = x1 + Wo; int* y1s = y0s + Ho;
+  float* fx = (float*)malloc(sizeof(float) * ((size_t)Wo + Ho));
+  float* fys = fx + Wo;
+  axis_taps(mx, Wo, W, mode, x0, x1, fx);
+  axis_taps(my, Ho, H, mode, y0s, y1s, fys);
+  for (int y = 0; y < Ho; ++y) {
+    const float fy = fys[y];
+    const uint8_t* r0 = src + (size_t)y0s[y] * W * C;
+    const uint8_t* r1 = src + (size_t)y1s[y] * W * C;
+    uint8_t* o = dst + (size_t)y * Wo * C;
+    for (int x = 0; x < Wo; ++x) {
+      long w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+      if (mode == 1) {
+        const float ox = 1.0f - fx[x], oy = 1.0f - fy;
+        w00 = lrintf(oy * ox * 32768.0f); w01 = lrintf(oy * fx[x] * 32768.0f);
+        w10 = lrintf(fy * ox * 32768.0f); w11 = lrintf(fy * fx[x] * 32768.0f);
+        if (w00 > 32767) w00 = 32767;                        /* saturate_cast<short> of 1.0 * 2^15 */
+      }
+      for (int k = 0; k < C; ++k) {
+        const int p00 = r0[(size_t)x0[x] * C + k], p01 = r0[(size_t)x1[x] * C + k];
+        const int p10 = r1[(size_t)x0[x] * C + k], p11 = r1[(size_t)x1[x] * C + k];
+        long v;
+        if (mode == 1) {
+          v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1L << 14)) >> 15;
+        } else {
+          const float v0 = lerp_rn((float)p00, (float)p10, fy);
+          const float v1 = lerp_rn((float)p01, (float)p11, fy);
+          v = lrintf(lerp_rn(v0, v1, fx[x]));
+        }
+        o[(size_t)x * C + k] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
+    }
+  }
+  free(x0);
+  free(fx);
+}
+
 /* ---- whole hot path for one image (float32): attention stack -> warped image ------------------- */
 API void oracle_warp_from_attention_stack_f32(const float* img, float* out, int layout, int C, int H, int W,
                                               const float* rows /* [T,1,heads,kv] */, int T, int heads, int kv,

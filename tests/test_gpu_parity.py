@@ -1303,7 +1303,8 @@ def test_full_size_properties(dev, cfg, mode):
     (1) identity maps reproduce the input bit-for-bit; (2) the streaming kernel and the independent
     gather kernel agree bit-for-bit on attention-driven maps (HWC and CHW, float32 and uint8); (3) a constant image
     stays constant (partition of unity; in cv2 mode the four table weights sum to 1 exactly); (4) every output lies
-    within the input's range; (5) first and last image equal the CPU oracle bit-for-bit."""
+    within the input's range; (5) first and last image equal the CPU oracle bit-for-bit (every image / a stratified
+    32: test_whole_batch_vs_c_oracle)."""
     from attwarp_amd import checkpoint_utils as cu, pipeline
     B, S = cfg
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -1344,6 +1345,73 @@ def test_full_size_properties(dev, cfg, mode):
         assert np.array_equal(N(a8[bi]), O.remap_bilinear(N(img8[bi]), N(mx[bi]), N(my[bi]), mode))
     c8 = cu.remap_separable(img8.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
     assert torch.equal(c8.permute(0, 2, 3, 1), a8)
+
+
+def _attention24(B, kind, dev, gen):
+    """[B,24,24] attention maps of SURVEY 8d's value distributions."""
+    if kind == "random":
+        return torch.softmax(torch.randn(B, 576, device=dev, generator=gen) * 2, 1).view(B, 24, 24)
+    if kind == "zero":                                 # the fallback branch (AGW/new_method.py:231-239 / clamp_min(1e-6))
+        return torch.zeros(B, 24, 24, device=dev)
+    att = torch.full((B, 24, 24), 1.0, device=dev)     # peaked: one 3x3 hot spot x100
+    cy = torch.randint(1, 23, (B,), device=dev, generator=gen).tolist()
+    cx = torch.randint(1, 23, (B,), device=dev, generator=gen).tolist()
+    for b in range(B):
+        att[b, cy[b] - 1:cy[b] + 2, cx[b] - 1:cx[b] + 2] = 100.0
+    return att / att.sum((1, 2), keepdim=True)
+
+
+@pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
+@pytest.mark.parametrize("mode", ["cv2", "exact"])
+@pytest.mark.parametrize("kind", ["random", "peaked", "zero", "smooth"])
+def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
+    """BASELINE configs[1] and [2] at full size against the ORACLE (oracle/warp_ref.c, itself pinned to the numpy oracle
+    and through it to the reference fixtures) -- not against a sibling kernel: EVERY image of B=64 @ 336x336 and a
+    stratified 32 of B=256 @ 1024x1024 (first, every 8th, last), both arithmetic modes, HWC and CHW, float32 and uint8,
+    maps and pixels bit for bit; on SURVEY 8d's value distributions: random-softmax attention on white noise, one 3x3 hot
+    spot x100 (strong magnification / minification), all-zero attention (the fallback branch), and a smooth image."""
+    import subprocess
+    from attwarp_amd import checkpoint_utils as cu, pipeline
+    from oracle import c_oracle as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    B, S = cfg
+    gen = torch.Generator(device=dev).manual_seed(17 + S)
+    if kind == "smooth":
+        yy = torch.linspace(0, 1, S, device=dev)[None, :, None, None]
+        xx = torch.linspace(0, 1, S, device=dev)[None, None, :, None]
+        ph = torch.rand((B, 1, 1, 3), device=dev, generator=gen) * 6.28
+        img = 0.5 + 0.25 * torch.sin(7.0 * xx + ph) * torch.cos(5.0 * yy - ph) + 0.2 * xx * yy
+        att = _attention24(B, "random", dev, gen)
+    else:
+        img = torch.rand((B, S, S, 3), device=dev, generator=gen)
+        att = _attention24(B, kind, dev, gen)
+    img = img.contiguous()
+    px, py = cu.gt_marginals(att.view(B, 1, 24, 24))
+    mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
+    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
+    assert len(sel) == (64 if S <= 512 else 33)
+    # maps of the selected images: the C oracle's own chain from the 24 x 24 map
+    inv = O.right_inverse_core(24, S)
+    att_h, mx_h, my_h = N(att), N(mx), N(my)
+    for b in sel:
+        opx, opy = C.marginals(att_h[b])
+        omx = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opx, S, inv, clamp0=True)), S)
+        omy = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opy, S, inv, clamp0=True)), S)
+        assert np.array_equal(mx_h[b], omx) and np.array_equal(my_h[b], omy), b
+    if kind == "zero":
+        assert float(mx.max()) <= S and bool(torch.isfinite(mx).all())
+    img8 = (img * 255).to(torch.uint8)
+    a = cu.remap_separable(img, mx, my, mode=mode, channels_last=True)
+    a8 = cu.remap_separable(img8, mx, my, mode=mode, channels_last=True)
+    c = cu.remap_separable(img.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
+    c8 = cu.remap_separable(img8.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
+    assert torch.equal(c.permute(0, 2, 3, 1), a) and torch.equal(c8.permute(0, 2, 3, 1), a8)     # all B images
+    idx = torch.tensor(sel, device=dev)
+    img_h, img8_h, a_h, a8_h = N(img[idx]), N(img8[idx]), N(a[idx]), N(a8[idx])
+    for i, b in enumerate(sel):
+        assert np.array_equal(a_h[i], C.remap_bilinear(img_h[i], mx_h[b], my_h[b], "hwc", mode)), (b, "float32")
+        assert np.array_equal(a8_h[i], C.remap_bilinear_u8(img8_h[i], mx_h[b], my_h[b], mode)), (b, "uint8")
 
 
 @pytest.mark.parametrize("cfg", [(64, 336), (8, 1024)])

@@ -71,6 +71,26 @@ def test_c_remap(C, layout, mode):
 
 
 @pytest.mark.parametrize("mode", ["exact", "cv2"])
+@pytest.mark.parametrize("chan", [1, 3, 4])
+def test_c_remap_uint8(C, mode, chan):
+    """The C uint8 resample (the whole-batch checker of the GPU tests) == the numpy oracle: monotone, wild, out-of-range
+    and non-finite coordinates, cvRound ties, extreme pixel values."""
+    rng = np.random.default_rng(40 + chan)
+    img = rng.integers(0, 256, (37, 53, chan), dtype=np.uint8)
+    img[:3] = 255; img[3:5] = 0
+    for kind in ("sorted", "wild"):
+        mx = rng.random(64).astype(np.float32) * 57 - 2
+        my = rng.random(41).astype(np.float32) * 41 - 2
+        if kind == "sorted":
+            mx, my = np.sort(mx), np.sort(my)
+        mx[:6] = [-3.0, 0.015625, 0.046875, 2.5, np.nan, 1e30]
+        my[:3] = [0.484375, 36.0, np.inf]
+        with np.errstate(all="ignore"):
+            ref = O.remap_bilinear(img, mx, my, mode)
+        assert np.array_equal(C.remap_bilinear_u8(img, mx, my, mode), ref), kind
+
+
+@pytest.mark.parametrize("mode", ["exact", "cv2"])
 def test_non_finite_and_huge_coordinates(C, mode):
     """Coordinates no image has: the conventions both oracles (and the kernels) follow.  cv2: cvRound as OpenCV's x86
     builds compute it -- NaN, +-Inf and products outside int32 give INT_MIN, i.e. pixel 0 with a zero fraction, for
