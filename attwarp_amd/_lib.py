@@ -16,6 +16,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libattwarp_hip.so")
+# the same sources built with -DATTWARP_TUNING: attwarp_debug_set() can force kernel variants.  Loaded only by
+# debug_override() (parity tests, A/B tools); the product never touches it.
+TUNING_LIB_PATH = os.path.join(_HERE, "csrc", "libattwarp_hip_tuning.so")
 
 # enums of include/attwarp.h
 F32, F16, BF16, U8, F64 = 0, 1, 2, 3, 4
@@ -30,7 +33,6 @@ _DTYPE_IDS = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16, torc
 SIGNATURES = {
     "attwarp_version": (c_int, []),
     "attwarp_last_error": (c_char_p, []),
-    "attwarp_debug_set": (c_int, [c_char_p, c_int]),
     "attwarp_attn_reduce_step": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                           c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "attwarp_attn_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -72,29 +74,48 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int, c_void_p]),
 }
 
-_lib = None
+_lib = None            # the library every call goes to: the product, or the tuning flavour inside debug_override()
+_product = None
+_tuning = None
 
 
 class AttWarpError(RuntimeError):
     """A libattwarp_hip.so entry point returned a negative status."""
 
 
+def _open(path):
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
 def load():
     """Load (once) and return the ctypes handle.  Fails loudly if the library is missing."""
-    global _lib
+    global _lib, _product
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"attwarp_amd: HIP library not built ({LIB_PATH} missing). Run `python __graft_entry__.py` or "
             f"`make -C attwarp_amd/csrc`. There is no CPU fallback.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError = header / library mismatch
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _product = _open(LIB_PATH)
+    _lib = _product
+    return _lib
+
+
+def load_tuning():
+    """The tuning flavour (test / measurement only): same kernels, plus attwarp_debug_set()."""
+    global _tuning
+    if _tuning is None:
+        if not os.path.exists(TUNING_LIB_PATH):
+            raise ImportError(f"attwarp_amd: tuning library not built ({TUNING_LIB_PATH} missing); run `make -C attwarp_amd/csrc`")
+        _tuning = _open(TUNING_LIB_PATH)
+        _tuning.attwarp_debug_set.restype = c_int
+        _tuning.attwarp_debug_set.argtypes = [c_char_p, c_int, ctypes.POINTER(c_int)]
+    return _tuning
 
 
 def call(name: str, *args):
@@ -108,16 +129,27 @@ def call(name: str, *args):
 
 @contextlib.contextmanager
 def debug_override(**settings: int):
-    """Test / measurement hook: force kernel variants (``attwarp_debug_set``), restored to "automatic" on exit.
-    e.g. ``with debug_override(remap_variant=1): ...`` runs the generic gather kernel."""
-    lib = load()
+    """Test / measurement hook: run the calls inside the context on the TUNING flavour of the library with kernel
+    variants forced through ``attwarp_debug_set`` -- e.g. ``with debug_override(remap_variant=1): ...`` runs the generic
+    gather kernel.  On exit every key gets back the value it had before (nesting works) and calls go to the product
+    library again.  Process wide and single threaded: do not use it while other threads launch kernels."""
+    global _lib
+    load()
+    tl = load_tuning()
+    outer, _lib = _lib, tl
+    prev = {}
     try:
         for k, v in settings.items():
-            call("attwarp_debug_set", k.encode(), int(v))
+            old = c_int(-1)
+            rc = tl.attwarp_debug_set(k.encode(), int(v), ctypes.byref(old))
+            if rc != 0:
+                raise AttWarpError(f"attwarp_debug_set failed ({rc}): {tl.attwarp_last_error().decode('utf-8', 'replace')}")
+            prev[k] = old.value
         yield
     finally:
-        for k in settings:
-            lib.attwarp_debug_set(k.encode(), -1)
+        for k, v in prev.items():
+            tl.attwarp_debug_set(k.encode(), int(v), None)
+        _lib = outer
 
 
 def ptr(t: torch.Tensor | None):

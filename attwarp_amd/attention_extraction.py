@@ -18,6 +18,17 @@ from ._lib import call, ptr, require_gpu, stream_ptr
 NUM_IMAGE_TOKENS = 576  # 24 x 24 patches for LLaVA-1.5 (reference :350)
 
 
+def _check_slices(starts, ntok: int, kv: int, who: str):
+    """The kernels clamp an out-of-range slice start on the device (memory safety); a range that does not lie inside
+    the attention row is a bookkeeping bug of the caller and must not turn into plausible-looking attention for other
+    tokens.  (The reference would fail differently: a negative start wraps from the end, a truncated slice cannot be
+    stacked, llava.py:390-395.)"""
+    for b, st in enumerate(starts):
+        if st < 0 or st + ntok > kv:
+            raise ValueError(f"{who}: image-token range [{st}, {st + ntok}) of sample {b} is outside the attention row "
+                             f"of {kv} keys")
+
+
 def attn_reduce_step(attn_weights: torch.Tensor, starts: torch.Tensor, ntok: int,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One step of attention aggregation: [B,heads,q,kv] -> [B,ntok] (same dtype).
@@ -144,6 +155,7 @@ class BatchMaskHookLogger(object):
             # the reference's torch.stack raises the same way when the slices differ in length
             raise RuntimeError(f"stack expects each tensor to be equal size, got image-token slice lengths {sorted(lens)}")
         ntok = lens.pop()
+        _check_slices(self.image_token_starts[:bsz], ntok, kv, "BatchMaskHookLogger._process_attention")
         if self._starts_dev is None or self._starts_dev.device != attn_weights.device:
             self._starts_dev = torch.tensor(self.image_token_starts, dtype=torch.int32, device=attn_weights.device)
         self.step_attentions.append(attn_reduce_step(attn_weights, self._starts_dev[:bsz], ntok))
@@ -186,6 +198,7 @@ class BatchMaskHookLogger(object):
         if len(lens) != 1:
             raise RuntimeError(f"stack expects each tensor to be equal size, got image-token slice lengths {sorted(lens)}")
         ntok = lens.pop()
+        _check_slices(self.image_token_starts[:bsz], ntok, kv, "BatchMaskHookLogger._probe_attention")
         if self._starts_dev is None or self._starts_dev.device != key.device:
             self._starts_dev = torch.tensor(self.image_token_starts, dtype=torch.int32, device=key.device)
         kv_begin = None
@@ -232,7 +245,8 @@ class BatchMaskHookLogger(object):
         """``register_probe`` for transformers 4.36 - 4.47 (the reference pins 4.37.2, which predates
         ``AttentionInterface``): a forward hook (``with_kwargs``) on the target ``LlamaAttention`` that, after the layer
         ran on its own fast kernel, rebuilds the post-RoPE query of the LAST token the way that version's forward does
-        (``q_proj`` -> heads -> ``rotary_emb(x, seq_len)`` tables gathered at ``position_ids`` -> ``q*cos +
+        (``q_proj`` -> heads -> ``rotary_emb(x, seq_len)`` tables gathered at ``position_ids`` (4.36 / 4.37; from 4.38 on
+        ``rotary_emb(x, position_ids)``, told apart by the signature) -> ``q*cos +
         rotate_half(q)*sin``, modeling_llama.py of 4.37.2) and reads the layer's post-RoPE keys from
         ``past_key_value.key_cache[layer_idx]`` -- the one projection of one token instead of eager attention over the
         whole prompt.  Needs ``use_cache=True`` (what ``generate`` does)."""
@@ -257,8 +271,15 @@ class BatchMaskHookLogger(object):
             q = module.q_proj(hidden[:, -1:, :]).view(B, 1, heads, D).transpose(1, 2)            # [B, heads, 1, D]
             if pos is None:
                 pos = torch.full((B, 1), kv - 1, dtype=torch.long, device=hidden.device)
-            cos, sin = module.rotary_emb(q, seq_len=kv)
-            cos, sin = cos[pos[:, -1:]].unsqueeze(1), sin[pos[:, -1:]].unsqueeze(1)           # [B, 1, 1, D]
+            import inspect
+            if "seq_len" in inspect.signature(module.rotary_emb.forward).parameters:
+                # 4.36 / 4.37: rotary_emb(x, seq_len) -> tables [seq, D], gathered at position_ids
+                cos, sin = module.rotary_emb(q, seq_len=kv)
+                cos, sin = cos[pos[:, -1:]].unsqueeze(1), sin[pos[:, -1:]].unsqueeze(1)       # [B, 1, 1, D]
+            else:
+                # 4.38 - 4.47: rotary_emb(x, position_ids) -> (cos, sin) [B, 1, D] for the given positions
+                cos, sin = module.rotary_emb(q, pos[:, -1:])
+                cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)                                   # [B, 1, 1, D]
             half = D // 2
             rot = torch.cat((-q[..., half:], q[..., :half]), dim=-1)
             q = (q * cos) + (rot * sin)
@@ -359,6 +380,7 @@ class MaskHookLogger(object):
             st, ed = 1, min(1 + self.num_image_tokens, kv)
         else:
             st, ed = self.image_token_start, min(self.image_token_end, kv)
+        _check_slices([st], ed - st, kv, "MaskHookLogger._process_attention")
         starts = torch.full((attn_weights.shape[0],), st, dtype=torch.int32, device=attn_weights.device)
         self.attns.append(attn_reduce_step(attn_weights, starts, ed - st))
 

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
   // + clip / pack / one store.  The window slides by one tile row every out_h / h output rows (42 for 24 -> 1024).
   // Work items = (64-dword column chunk, chunk of the block's rows), dealt to the 4 waves.
   const int nq = out_w >> 2;
-  if (ksize_y == 8) {       // rows of exactly 8 zero-padded coefficients (attwarp.h): unconditional 32-byte scalar loads
+  if (ksize_y == 8) {       // rows of exactly 8 coefficients: 32-byte scalar loads, masked by the row's tap count
     const int lane = tid & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int QW = (nq + WAVE - 1) / WAVE;
@@ -340,11 +340,13 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
         dst[0] = (int)(wv & 0xffu); dst[1] = (int)((wv >> 8) & 0xffu); dst[2] = (int)((wv >> 16) & 0xffu); dst[3] = (int)(wv >> 24);
       };
       // the NEXT row's bounds and coefficients are fetched while the current row is computed
+      // (coefficients past the row's tap count are masked here, so the caller's table need not be zero-padded)
       int kc[8], ymin_c = 0;
       if (r_beg < r_end) {
         ymin_c = bounds_y[2 * (yy0 + r_beg)];
+        const int cnt_c = bounds_y[2 * (yy0 + r_beg) + 1];
 #pragma unroll
-        for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)(yy0 + r_beg) * 8 + y];
+        for (int y = 0; y < 8; ++y) kc[y] = y < cnt_c ? kk_y[(size_t)(yy0 + r_beg) * 8 + y] : 0;
       }
       for (int ry = r_beg; ry < r_end; ++ry) {
         const int yy = yy0 + ry;
@@ -354,8 +356,9 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
         for (int y = 0; y < 8; ++y) kv[y] = kc[y];
         const int yn = min(yy + 1, out_h - 1);
         ymin_c = bounds_y[2 * yn];
+        const int cnt_n = bounds_y[2 * yn + 1];
 #pragma unroll
-        for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)yn * 8 + y];
+        for (int y = 0; y < 8; ++y) kc[y] = y < cnt_n ? kk_y[(size_t)yn * 8 + y] : 0;
         if (ymin != base) {                                      // wave uniform
           if (ymin == base + 1) {
 #pragma unroll

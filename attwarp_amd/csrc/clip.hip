@@ -182,12 +182,12 @@ __global__ __launch_bounds__(NT) void clip_v_rows_kernel(const uint8_t* __restri
       if (q < nq) {
         int a0 = 1 << (PIL_PRECISION_BITS - 1), a1 = a0, a2 = a0, a3 = a0;
         if (ksize == 8) {
-          // rows of exactly 8 coefficients, zero past the count (attwarp.h): one 32-byte scalar load and 8 row loads
-          // without a branch (row indices clamped to the image; the coefficient of a clamped row is zero)
+          // rows of exactly 8 coefficients: one 32-byte scalar load, masked by the row's tap count (the caller's table
+          // need not be zero-padded), and 8 row loads without a branch (row indices clamped to the image)
           uint32_t wv[8];
           int kv[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) kv[i] = __builtin_amdgcn_readfirstlane(k[i]);
+          for (int i = 0; i < 8; ++i) kv[i] = i < cnt ? __builtin_amdgcn_readfirstlane(k[i]) : 0;
 #pragma unroll
           for (int i = 0; i < 8; ++i) wv[i] = reinterpret_cast<const uint32_t*>(col + (unsigned)(min(i, hlast - ymin) * oc))[q];
 #pragma unroll

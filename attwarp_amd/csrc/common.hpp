@@ -117,9 +117,10 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // ---- test / measurement overrides -----------------------------------------------
 // Kernel selection is automatic.  The A/B tools and the parity tests need to force a particular variant
-// (e.g. "the generic gather kernel") to check the variants against each other; that goes through
-// attwarp_debug_set() (include/attwarp.h), which stores into this table of relaxed atomics.  -1 = automatic.
-// No environment variable is ever read by the library.
+// (e.g. "the generic gather kernel") to check the variants against each other.  That exists ONLY in the tuning flavour
+// of the library (libattwarp_hip_tuning.so, built with -DATTWARP_TUNING): attwarp_debug_set() stores into a table of
+// relaxed atomics that tune() reads, -1 = automatic.  In the product library tune() is the constant -1, the symbol
+// does not exist and every `tune(...)` branch folds away.  No environment variable is ever read by either.
 enum TuneKey {
   TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only; 2: uint8 cv2 on the float-pipeline rows kernel (not the integer form)
   TUNE_REMAP_ROWS,          // output rows per workgroup (1..64)
@@ -139,6 +140,10 @@ enum TuneKey {
   TUNE_ATTN_HU,             // heads in flight per wave of the four-tokens-per-lane attention reduce (1, 2, 4, 8)
   TUNE_COUNT
 };
+#ifdef ATTWARP_TUNING
 int tune(TuneKey k);        // current override or -1
+#else
+constexpr int tune(TuneKey) { return -1; }
+#endif
 
 }  // namespace attwarp

@@ -19,6 +19,7 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+#ifdef ATTWARP_TUNING
 // stored as value + 1 so that the zero-initialised table means "automatic" everywhere
 static std::atomic<int> g_tune[TUNE_COUNT];
 int tune(TuneKey k) { return g_tune[k].load(std::memory_order_relaxed) - 1; }
@@ -27,9 +28,12 @@ static const char* const kTuneNames[TUNE_COUNT] = {
     "remap_variant", "remap_rows", "remap_chw_split", "remap_tiled", "remap_tile_ko", "remap_alt", "remap_noswz",
     "remap_ldspad", "remap_nt", "lanczos_variant", "lanczos_rows", "clip_variant", "profiles_variant", "remap_cpw", "remap_skew", "attn_hu"};
 
+#endif
+
 }  // namespace attwarp
 
-extern "C" int attwarp_debug_set(const char* key, int value) {
+#ifdef ATTWARP_TUNING
+extern "C" int attwarp_debug_set(const char* key, int value, int* previous) {
   using namespace attwarp;
   ATTWARP_REQUIRE(key, "debug_set: null key");
   if (strcmp(key, "reset") == 0) {
@@ -38,11 +42,13 @@ extern "C" int attwarp_debug_set(const char* key, int value) {
   }
   for (int i = 0; i < TUNE_COUNT; ++i)
     if (strcmp(key, kTuneNames[i]) == 0) {
-      g_tune[i].store(value < 0 ? 0 : value + 1, std::memory_order_relaxed);
+      const int old = g_tune[i].exchange(value < 0 ? 0 : value + 1, std::memory_order_relaxed);
+      if (previous) *previous = old - 1;
       return ATTWARP_OK;
     }
   return fail(ATTWARP_E_ARG, "debug_set: unknown key '%s'", key);
 }
+#endif
 
 extern "C" int attwarp_version(void) { return ATTWARP_VERSION; }
 extern "C" const char* attwarp_last_error(void) { return attwarp::error_buffer(); }

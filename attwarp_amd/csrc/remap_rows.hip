@@ -95,14 +95,14 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   const long long nb = (long long)p.wpi * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
-  p.alt_dir = tune(TUNE_REMAP_ALT) != 0;
   p.no_swz = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : group;
-  p.skew = 0;
-  if (const int v = tune(TUNE_REMAP_SKEW); v >= 0) p.skew = v;
+#ifdef ATTWARP_TUNING
+  p.alt_dir = tune(TUNE_REMAP_ALT) != 0;
+  p.skew = tune(TUNE_REMAP_SKEW) >= 0 ? tune(TUNE_REMAP_SKEW) : 0;
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
-  // nontemporal loads for block-private rows: measurement option only (see remap_rows_kernel.hpp)
   p.nt_loads = tune(TUNE_REMAP_NT) == 1;
+#endif
   *handled = true;
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)

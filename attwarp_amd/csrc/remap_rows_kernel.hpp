@@ -31,23 +31,14 @@
 #include "attn_f32v.hpp"
 #include <algorithm>
 
-// Measurement build only (-DATTWARP_EXPERIMENT): lds_pad bit 0 = no global loads (registers keep their old
-// contents), bit 1 = stores only for values that never occur.  Splits the kernel time into its read and write sides.
-#ifdef ATTWARP_EXPERIMENT
-#define ATTWARP_EXP_LOAD(X, rp_)                                                                                   \
-  if (!(p.lds_pad & 1)) { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
-#define ATTWARP_EXP_STORE(ptr_, v_)                                                                                \
-  if (!(p.lds_pad & 2) || (v_) == -12345.678f) *reinterpret_cast<float*>(ptr_) = (v_)
-#define ATTWARP_EXP_FLAG(b) (p.lds_pad & (b))
-#else
-#define ATTWARP_EXP_FLAG(b) false
-// Measurement option (p.nt_loads, test hook "remap_nt"): source rows a block shares with a neighbour (its first and
-// last needed row: the neighbour's halo) are read with plain loads, rows only this block reads NONTEMPORAL.  Same-box
-// alternating runs, 1024x1024x3 float32 B=256: on boxes in the fast state EXACT 1.073 -> 1.040 ms, CV2 1.088 -> 1.060,
-// CV2 CHW 1.102 -> 1.051; on boxes in the slow state +1-2 % slower at every batch size, and -15 % on a batch that fits
-// the Infinity Cache (B=64 336x336).  Nontemporal loads for ALL rows (the halo then misses): never a gain.  Off by default.
+// Source-row loads.  Tuning flavour only (test hook "remap_nt"): rows a block shares with a neighbour (its first and last
+// needed row: the neighbour's halo) are read with plain loads, rows only this block reads NONTEMPORAL -- measured on
+// MI355X, 1024x1024x3 float32 B=256: 3 % faster on leases in the fast state, 1-2 % slower in the slow state, -15 % on a
+// batch that fits the Infinity Cache; nontemporal loads for ALL rows (the halo then misses): never a gain.  The
+// product library always issues plain loads.
+#ifdef ATTWARP_TUNING
 typedef float rows_v4f __attribute__((ext_vector_type(4)));
-#define ATTWARP_EXP_LOAD(X, rp_)                                                                                    \
+#define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
   if (p.nt_loads && srow_ != row_lo && srow_ != row_hi) {                                                           \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                                 \
       const rows_v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k]));             \
@@ -56,7 +47,9 @@ typedef float rows_v4f __attribute__((ext_vector_type(4)));
   } else {                                                                                                          \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);           \
   }
-#define ATTWARP_EXP_STORE(ptr_, v_) *reinterpret_cast<float*>(ptr_) = (v_)
+#else
+#define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
+  { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
 #endif
 
 namespace attwarp {
@@ -122,13 +115,17 @@ struct RowsParams {
   int nblk;          // row blocks per image
   int wpi;           // workgroups per image (and column tile): workgroup j owns row blocks j, j + wpi, j + 2 wpi, ...
   int nblocks;       // total
-  int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
   int no_swz;        // block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g blocks
+#ifdef ATTWARP_TUNING  // measurement knobs of the tuning flavour (attwarp_debug_set); constants in the product library
+  int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int skew;          // block order 0: XCD x starts x * skew blocks into its contiguous range
+  int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads
+#else
+  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0;
+#endif
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
-  int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads (large streaming batches)
 };
 
 constexpr int RMAX = 64;
@@ -304,15 +301,17 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 
   float4 X0[KI], X1[KI];
   int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
+#ifdef ATTWARP_TUNING
   // the two rows this block shares with its neighbours (valid for the monotone maps of the path; for arbitrary maps
-  // they are just two rows that stay cacheable)
+  // they are just two rows that stay cacheable): only the "remap_nt" measurement option looks at them
   const int row_lo = rtaps<MODE>(s_my[0], p.H).i0, row_hi = rtaps<MODE>(s_my[nrows - 1], p.H).i1;
+#endif
   // (macros, not lambdas: the register sets must stay scalar-replaced, never addressed through a pointer)
 #define ATTWARP_LOAD_ROW(X, srow)                                                                   \
   do {                                                                                              \
     const int srow_ = (srow);                                                                       \
     const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)srow_ * p.row_len);          \
-    ATTWARP_EXP_LOAD(X, rp_)                                                                        \
+    ATTWARP_ROW_LOAD(X, rp_)                                                                        \
   } while (0)
   // EXACT: the vertical lerp of (XA, XC) into the row buffer; CV2: XA, then XC one row further
 #define ATTWARP_BLEND(rowbuf, XA, XC, fy)                                                           \
@@ -324,7 +323,6 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
         rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                                     \
       } else {                                                                                      \
         float4 v_;                                                                                  \
-        if (ATTWARP_EXP_FLAG(8)) { rowv_[tid + NT * k] = XA[k]; continue; }                         \
         v_.x = lerp_rn(XA[k].x, XC[k].x, fy);                                                       \
         v_.y = lerp_rn(XA[k].y, XC[k].y, fy);                                                       \
         v_.z = lerp_rn(XA[k].z, XC[k].z, fy);                                                       \
@@ -399,9 +397,9 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
             const float fx_ = fxr[k], ox_ = fsub(1.0f, fx_);                                        \
             o_ = cv2_sum_pk(v2f{v0[kk], u0[kk]}, v2f{v1[kk], u1[kk]}, v2f{oy_, fy_}, ox_, fx_);     \
           } else {                                                                                  \
-            o_ = ATTWARP_EXP_FLAG(4) ? v0[kk] : lerp_rn(v0[kk], v1[kk], fxr[k]);                    \
+            o_ = lerp_rn(v0[kk], v1[kk], fxr[k]);                                                   \
           }                                                                                         \
-          ATTWARP_EXP_STORE(orow + off, o_);                                                        \
+          *reinterpret_cast<float*>(orow + off) = o_;                                               \
         }                                                                                           \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
@@ -421,7 +419,6 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   // rows alternate between the two LDS buffers (one barrier per row is enough: a thread can only be
   // one row ahead of the slowest reader, and then it writes the OTHER buffer)
   int q = 0;
-  if (ATTWARP_EXP_FLAG(16)) { if (pk[0] == 0xdeadbeef) dst_b[tid] = fxr[1] + X0[0].x; return; }
   for (; q + 1 < nrows; q += 2) {
     ATTWARP_DO_ROW(q, rows0);
     ATTWARP_DO_ROW(q + 1, rows1);

@@ -64,12 +64,16 @@ enum {
 ATTWARP_API int attwarp_version(void);
 ATTWARP_API const char* attwarp_last_error(void);
 
-/* ---- test / measurement hook, NOT part of the drop-in surface.  Kernel variants are chosen automatically from
- * the shapes; the parity tests and the A/B tools force a particular one to check the variants against each other
- * (e.g. key "remap_variant" = 1: generic gather kernel only; "remap_rows" = R).  value < 0 restores "automatic",
- * key "reset" restores every key.  Keys: see kTuneNames in csrc/error.hip.  The setting is process wide (relaxed
- * atomics); the library never reads environment variables. */
-ATTWARP_API int attwarp_debug_set(const char* key, int value);
+/* ---- test / measurement hook: exists ONLY in the tuning flavour of the library (libattwarp_hip_tuning.so, built with
+ * -DATTWARP_TUNING; the product library libattwarp_hip.so does not export it and contains no override table).
+ * Kernel variants are chosen automatically from the shapes; the parity tests and the A/B tools force a particular one
+ * to check the variants against each other (e.g. key "remap_variant" = 1: generic gather kernel only; "remap_rows" =
+ * R).  value < 0 restores "automatic", key "reset" restores every key; the previous value of the key is returned
+ * through *previous when it is not NULL.  Keys: see kTuneNames in csrc/error.hip.  Process wide, single threaded,
+ * test only. */
+#ifdef ATTWARP_TUNING
+ATTWARP_API int attwarp_debug_set(const char* key, int value, int* previous);
+#endif
 
 /* ---- A1: BatchMaskHookLogger._process_attention, AGW/attention_extraction/llava.py:385-396
  * attn [B,heads,q,kv] with element strides; for sample b uses row q-1, columns
@@ -120,8 +124,8 @@ ATTWARP_API int attwarp_mask_postproc(const float* mask, int B, int n, int kerne
  * mask_f32 [B,h,w] float32 in [0,1]  (or mask_u8 [B,h,w] if mask_f32 is NULL)
  * -> out [B,out_h,out_w] uint8.  Coefficients: host-computed Pillow tables uploaded by the
  * caller: bounds_* int32[out,2] = (first tap, tap count), kk_* int32[out,ksize] (22-bit fixed point; entries at
- * index >= tap count must be 0, as Pillow leaves them; a row stride of exactly 8 -- zero-pad narrower tables --
- * selects the fastest vertical pass).
+ * index >= tap count are never used: every kernel form masks them by the row's tap count; a row stride of exactly 8
+ * -- pad narrower tables to 8 columns with anything -- selects the fastest vertical pass).
  * tmp: uint8 [B,h,out_w] workspace (horizontal pass output). */
 ATTWARP_API int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_t* mask_u8, int B, int h, int w,
                                   int out_h, int out_w,

@@ -324,6 +324,16 @@ def test_attn_out_of_range_starts_are_clamped(dev):
     assert np.array_equal(s1, N(ae.attn_reduce_step(T(rows[0][:, :, None, :], dev), T(ok, dev), 576)))
     with pytest.raises(_lib.AttWarpError, match="ntok"):
         ae.attn_reduce_stack(T(rows[..., :500], dev), T(ok, dev))
+    # the hook loggers hold the ranges as Python lists: a range outside the attention row is the caller's bookkeeping
+    # bug and raises on the host instead of being clamped into attention for other tokens
+    hl = ae.BatchMaskHookLogger(model=None, device=dev)
+    hl.set_batch_image_token_ranges([0, -5], [576, 571])
+    with pytest.raises(ValueError, match="outside the attention row"):
+        hl._process_attention(T(rows[0][:2, :, None, :], dev))
+    ml = ae.MaskHookLogger(None, dev)
+    ml.image_token_start, ml.image_token_end = -3, 573
+    with pytest.raises(ValueError, match="outside the attention row"):
+        ml._process_attention(T(rows[0][:1, :, None, :], dev))
 
 
 def test_attn_stack_fused_and_single_logger(dev):
@@ -1581,7 +1591,8 @@ def test_single_sample_hook_logger_with_dummy_decoder(dev):
     assert float(ae.MaskHookLogger(model, dev).finalize().sum()) == pytest.approx(1.0)     # empty -> uniform [576]
 
 
-def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev):
+@pytest.mark.parametrize("rotary_style", ["seq_len (4.36-4.37)", "position_ids (4.38-4.47)"])
+def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev, rotary_style):
     """INTEGRATION.md section 2, the recipe for the reference's pinned transformers 4.37.2 (no AttentionInterface):
     ``register_probe_legacy`` = forward hook that re-applies q_proj + rotary to the last token and reads the layer's
     key cache.  Checked on a stand-in module with 4.37.2's LlamaAttention interface (q_proj / k_proj /
@@ -1600,6 +1611,15 @@ def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev):
             emb = torch.cat((fr, fr), dim=-1)
             return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
 
+    class RotaryPos(torch.nn.Module):                # 4.38 - 4.47: forward(x, position_ids) -> (cos, sin) [B, seq, D]
+        def forward(self, x, position_ids):
+            inv = 1.0 / (10000 ** (torch.arange(0, D, 2, device=x.device).float() / D))
+            fr = position_ids[:, :, None].float() * inv[None, None, :]
+            emb = torch.cat((fr, fr), dim=-1)
+            return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+
+    new_style = rotary_style.startswith("position_ids")
+
     class Cache:                                     # DynamicCache of 4.36+: key_cache[layer] grows along the kv axis
         def __init__(self, n):
             self.key_cache = [None] * n
@@ -1614,7 +1634,7 @@ def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev):
             self.layer_idx, self.num_heads = layer_idx, heads
             self.q_proj = torch.nn.Linear(hid, heads * D, bias=False)
             self.k_proj = torch.nn.Linear(hid, heads * D, bias=False)
-            self.rotary_emb = Rotary()
+            self.rotary_emb = RotaryPos() if new_style else Rotary()
 
         def forward(self, hidden_states=None, attention_mask=None, position_ids=None, past_key_value=None,
                     output_attentions=False, use_cache=True):
@@ -1622,8 +1642,12 @@ def test_probe_legacy_hook_on_transformers_4_37_style_attention(dev):
             q = self.q_proj(hidden_states).view(B, q_len, heads, D).transpose(1, 2)
             k = self.k_proj(hidden_states).view(B, q_len, heads, D).transpose(1, 2)
             kv = q_len + (0 if past_key_value.key_cache[self.layer_idx] is None else past_key_value.key_cache[self.layer_idx].shape[2])
-            cos, sin = self.rotary_emb(k, seq_len=kv)
-            cos, sin = cos[position_ids].unsqueeze(1), sin[position_ids].unsqueeze(1)
+            if new_style:
+                cos, sin = self.rotary_emb(k, position_ids)
+                cos, sin = cos.unsqueeze(1), sin.unsqueeze(1)
+            else:
+                cos, sin = self.rotary_emb(k, seq_len=kv)
+                cos, sin = cos[position_ids].unsqueeze(1), sin[position_ids].unsqueeze(1)
             rh = lambda x: torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1)
             q, k = (q * cos) + (rh(q) * sin), (k * cos) + (rh(k) * sin)
             k = past_key_value.update(k, self.layer_idx)

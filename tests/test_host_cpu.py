@@ -25,12 +25,42 @@ def lib():
 def test_library_exports_every_declared_symbol(lib):
     from attwarp_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "attwarp.h")).read()
-    declared = set(re.findall(r"ATTWARP_API\s+[\w\s\*]+?\b(attwarp_\w+)\s*\(", hdr))
-    assert len(declared) >= 20
+    tuning_only = set(re.findall(r"(attwarp_\w+)\s*\(", "".join(re.findall(r"#ifdef ATTWARP_TUNING(.*?)#endif", hdr, re.S))))
+    declared = set(re.findall(r"ATTWARP_API\s+[\w\s\*]+?\b(attwarp_\w+)\s*\(", hdr)) - tuning_only
+    assert len(declared) >= 20 and tuning_only == {"attwarp_debug_set"}
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/attwarp.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.attwarp_version() == 100
+    # the product library carries NO test / measurement hook: exactly the declared entry points are exported
+    import subprocess
+    def exports(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("attwarp_")}
+    assert exports(_lib.LIB_PATH) == declared
+    assert exports(_lib.TUNING_LIB_PATH) == declared | tuning_only
+
+
+def test_debug_override_swaps_to_the_tuning_library_and_restores(lib):
+    """debug_override runs on the tuning flavour, restores the previous value of every key (nesting) and hands calls
+    back to the product library afterwards (resetting to -1 clobbered an outer override)."""
+    import ctypes
+    from attwarp_amd import _lib
+    assert _lib.load() is lib
+    with _lib.debug_override(remap_rows=5):
+        tl = _lib.load()
+        assert tl is not lib and hasattr(tl, "attwarp_debug_set")
+        with _lib.debug_override(remap_rows=7, remap_variant=1):
+            pass
+        old = ctypes.c_int(-99)
+        assert tl.attwarp_debug_set(b"remap_rows", 5, ctypes.byref(old)) == 0 and old.value == 5      # inner exit restored 5
+        assert tl.attwarp_debug_set(b"remap_variant", -1, ctypes.byref(old)) == 0 and old.value == -1
+    assert _lib.load() is lib
+    old = ctypes.c_int(-99)
+    assert _lib.load_tuning().attwarp_debug_set(b"remap_rows", -1, ctypes.byref(old)) == 0 and old.value == -1
+    with pytest.raises(_lib.AttWarpError):
+        with _lib.debug_override(no_such_key=1):
+            pass
 
 
 def test_c_abi_argument_validation_without_gpu(lib):
