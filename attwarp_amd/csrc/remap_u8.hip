@@ -81,6 +81,7 @@ struct Params {
   int VL, OVL;             // bytes per virtual row (all planes)
   long long img_stride, plane_stride, oimg_stride, oplane_stride;
   int R, nblk, nblocks;
+  int wpi;   // integer cv2 kernel: workgroups per image; workgroup j owns row blocks j, j + wpi, ... (else == nblk)
   int ntiles;              // TILED: column tiles per row (each KO*NT output bytes), else 1
   int map_div;             // maps belong to image b / map_div (planes of a planar image dispatched as images)
 };
@@ -349,15 +350,13 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
   }
-  const int b = bid / p.nblk, rb = bid - b * p.nblk;
-  const int y0 = rb * p.R;
-  const int nrows = min(y0 + p.R, p.Ho) - y0;
+  const int b = bid / p.wpi, rb0 = bid - b * p.wpi;
   const uint8_t* src_b = p.src + (long long)b * p.img_stride;
   uint8_t* dst_b = p.dst + (long long)b * p.oimg_stride;
-  if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
 
   // source dwords this thread owns (clamped: padding lanes repeat the last dword)
   int goff[KI], voff[KI];           // byte offset inside the image (row 0) / u16 index in the LDS row
+  bool vswap[KI];                   // this dword's two LDS dwords are stored swapped (bank swizzle, see lds_off)
   {
     const int dpr = p.row_len >> 2, nd = p.VL >> 2;
 #pragma unroll
@@ -366,6 +365,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       const int pl = HWC ? 0 : d / dpr;
       goff[k] = (int)(pl * p.plane_stride) + 4 * (d - pl * dpr);
       voff[k] = 4 * d;
+      vswap[k] = (d >> 5) & 1;
     }
   }
   // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
@@ -374,7 +374,13 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   int soff[KD];
   {
     const int dpo = p.orow_len >> 2, ndo = p.OVL >> 2;
-    auto lds_off = [](unsigned e) -> unsigned { return 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
+    // u16 element e of the row lives in dword 2*(e/4) + (e & 1), half (e >> 1) & 1 -- with the two dwords of a group
+    // SWAPPED in every other window of 64 dwords: a lane gathers 4 consecutive output bytes, i.e. for slopes near 1
+    // lanes l and l + 32 read dwords 128 bytes * 2 apart -- the same bank; the swap moves the upper half-wave onto the
+    // other 32 banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.27 -> see profiles/round3_chain_pmc.txt)
+    auto lds_off = [](unsigned e) -> unsigned {
+      return 2u * ((e & ~3u) | ((((e & 1u) ^ ((e >> 7) & 1u)) << 1) | ((e >> 1) & 1u)));
+    };
 #pragma unroll
     for (int k = 0; k < KD; ++k) {
       const int d = min(tid + NT * k, ndo - 1);
@@ -399,7 +405,6 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       kxp[k] = kp;
     }
   }
-  __syncthreads();
 
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
   auto row_taps = [&](float m, int& i0, int& i1, unsigned& ky) {
@@ -411,8 +416,8 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   };
   int ci0, ci1;
   unsigned cky;
-  row_taps(s_my[0], ci0, ci1, cky);
   uint32_t A[KI], C[KI];
+  int y0 = 0, nrows = 0;
 #define ATTWARP_U8I_FETCH()                                                                            \
   _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                      \
     A[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)ci0 * p.row_len + goff[k]);            \
@@ -428,8 +433,8 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
       const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
       uint2 st_;                                                                                       \
-      st_.x = __builtin_bit_cast(uint32_t, v02_);                                                      \
-      st_.y = __builtin_bit_cast(uint32_t, v13_);                                                      \
+      st_.x = __builtin_bit_cast(uint32_t, vswap[k] ? v13_ : v02_);                                    \
+      st_.y = __builtin_bit_cast(uint32_t, vswap[k] ? v02_ : v13_);                                    \
       *reinterpret_cast<uint2*>((vbuf) + voff[k]) = st_;                                               \
     }                                                                                                  \
     if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
@@ -454,13 +459,24 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       if (tid + NT * k < (p.OVL >> 2)) *reinterpret_cast<uint32_t*>(orow_ + soff[k]) = o_;             \
     }                                                                                                  \
   }
-  ATTWARP_U8I_FETCH()
-  int q = 0;
-  for (; q + 1 < nrows; q += 2) {
-    ATTWARP_U8I_ROW(q, vrow0)
-    ATTWARP_U8I_ROW(q + 1, vrow1)
+  // Row blocks of this workgroup: rb0, rb0 + wpi, ... -- the column-tap prologue above (a cvRound and two integer
+  // divisions per output byte) is paid once for all of them, while the workgroups of an image sweep it together as
+  // one compact window of rows (DRAM page locality), as in remap_rows_kernel.hpp.
+  for (int rb = rb0; rb < p.nblk; rb += p.wpi) {
+    y0 = rb * p.R;
+    nrows = min(y0 + p.R, p.Ho) - y0;
+    if (rb != rb0) __syncthreads();          // the previous block's last gather is done with s_my and the row buffers
+    if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
+    __syncthreads();
+    row_taps(s_my[0], ci0, ci1, cky);
+    ATTWARP_U8I_FETCH()
+    int q = 0;
+    for (; q + 1 < nrows; q += 2) {
+      ATTWARP_U8I_ROW(q, vrow0)
+      ATTWARP_U8I_ROW(q + 1, vrow1)
+    }
+    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0)
   }
-  if (q < nrows) ATTWARP_U8I_ROW(q, vrow0)
 #undef ATTWARP_U8I_ROW
 #undef ATTWARP_U8I_FETCH
 }
@@ -557,11 +573,28 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   if (R > Ho) R = Ho;
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
-  const long long nb = (long long)p.nblk * B * p.ntiles;
+  p.wpi = p.nblk;
+  const bool integer_form = mode == ATTWARP_CV2 && !tiled && tune(TUNE_REMAP_VARIANT) != 2;
+  if (integer_form) {
+    // Large rows that are not strongly minified: smaller row blocks, several per workgroup (the column-tap prologue is
+    // still paid once per 64 rows, the rows in flight form a compact window).  Measured on MI355X, B=256 1024 -> 1024
+    // x3 uint8 (tools/u8_sweep.py): near-identity maps R=32 x 1: 425 us, R=16 x 4: 370; peaked maps 383 -> 358;
+    // 1024 -> 500 and 336 -> 500 are fastest as they were (R=32 / 16, one block per workgroup).
+    int cpw = 1;                                      // row blocks per workgroup (strided inside the image)
+    if (OVL >= 2048 && 2LL * H <= 3LL * Ho && tune(TUNE_REMAP_ROWS) < 1) {
+      p.R = R = Ho < 16 ? Ho : 16;
+      p.nblk = (Ho + R - 1) / R;
+      cpw = 4;
+    }
+    if (const int v = tune(TUNE_REMAP_CPW); v >= 1) cpw = v;
+    while (cpw > 1 && (long long)((p.nblk + cpw - 1) / cpw) * B < 4096) cpw >>= 1;       // keep the chip filled
+    p.wpi = (p.nblk + cpw - 1) / cpw;
+  }
+  const long long nb = (long long)p.wpi * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
   p.nblocks = (int)nb;
   *handled = true;
-  if (mode == ATTWARP_CV2 && !tiled && tune(TUNE_REMAP_VARIANT) != 2) return u8k::launch_u8i(p, st);   // integer form
+  if (integer_form) return u8k::launch_u8i(p, st);
   if (mode == ATTWARP_CV2) return u8k::launch_mode<ATTWARP_CV2>(p, tiled, st);
   return u8k::launch_mode<ATTWARP_EXACT>(p, tiled, st);
 }
