@@ -158,10 +158,12 @@ def axis_maps_from_cdf(Fx_img: torch.Tensor, Fy_img: torch.Tensor, out_size: Tup
 def remap_separable(img: torch.Tensor, map_x: torch.Tensor, map_y: torch.Tensor, mode: str = "cv2",
                     channels_last: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps on a batch.
-    img (B,C,H,W) [or (B,H,W,C) if channels_last] uint8/float32; maps (B,W_out), (B,H_out)."""
+    img (B,C,H,W) [or (B,H,W,C) if channels_last] uint8 / float32 / float64; maps (B,W_out), (B,H_out).
+    (float64: OpenCV's CV_64F arithmetic on the generic gather kernel -- the dtype pass-through of
+    ``warp_from_cdf_torch``; the roofline kernels are float32 / uint8.)"""
     dev = require_gpu(img, map_x, map_y)
-    if img.dtype not in (torch.float32, torch.uint8):
-        raise TypeError(f"remap_separable: float32 or uint8 image expected, got {img.dtype}")
+    if img.dtype not in (torch.float32, torch.uint8, torch.float64):
+        raise TypeError(f"remap_separable: float32, uint8 or float64 image expected, got {img.dtype}")
     x = img.detach().contiguous()
     if channels_last:
         B, H, W, C = x.shape
@@ -199,7 +201,9 @@ def warp_from_cdf_torch(img: torch.Tensor, Fx_img: torch.Tensor, Fy_img: torch.T
     if Fy_img.shape[-1] != H:
         raise ValueError(f"Fy_img[0] length {Fy_img.shape[-1]} != image height H={H}")
     mx, my = axis_maps_from_cdf(Fx_img.reshape(B, W), Fy_img.reshape(B, H), (H_out, W_out))
-    if img.dtype == torch.uint8:
+    # the reference hands the image to cv2.remap in its own dtype (:152, :195-203): uint8, float32 and float64 are
+    # resampled as such; float16 / bfloat16 (which cv2.remap cannot take) go through float32 and are rounded back
+    if img.dtype in (torch.uint8, torch.float32, torch.float64):
         return remap_separable(img, mx, my, mode)
     out = remap_separable(img.to(torch.float32), mx, my, mode)
     return out.to(img.dtype)

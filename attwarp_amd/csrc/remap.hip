@@ -92,6 +92,24 @@ __device__ __forceinline__ uint8_t blend<uint8_t, ATTWARP_CV2>(uint8_t p00, uint
   return (uint8_t)min(max((acc + (1 << 14)) >> 15, 0), 255);
 }
 
+// float64 images (warp_from_cdf_torch hands the image to cv2.remap in its own dtype, MN/checkpoint_utils.py:152,195):
+// OpenCV's CV_64F path keeps the float32 table weights and accumulates the four products in double, left to right;
+// exact mode: the three lerps in double with the float32 coordinate fractions.
+template <>
+__device__ __forceinline__ double blend<double, ATTWARP_EXACT>(double p00, double p01, double p10, double p11, float fx,
+                                                               float fy) {
+  const double v0 = __dadd_rn(p00, __dmul_rn((double)fy, __dsub_rn(p10, p00)));
+  const double v1 = __dadd_rn(p01, __dmul_rn((double)fy, __dsub_rn(p11, p01)));
+  return __dadd_rn(v0, __dmul_rn((double)fx, __dsub_rn(v1, v0)));
+}
+template <>
+__device__ __forceinline__ double blend<double, ATTWARP_CV2>(double p00, double p01, double p10, double p11, float fx,
+                                                             float fy) {
+  const float ox = fsub(1.0f, fx), oy = fsub(1.0f, fy);
+  const double w00 = fmul(oy, ox), w01 = fmul(oy, fx), w10 = fmul(fy, ox), w11 = fmul(fy, fx);
+  return __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(p00, w00), __dmul_rn(p01, w01)), __dmul_rn(p10, w10)), __dmul_rn(p11, w11));
+}
+
 // ------------------------------------------------------------------------------
 // Generic gather kernel.  grid = (ceil(Wo*CS / 256), Ho, B)
 //   HWC: one thread per interleaved output element e = x*C + c        (CS = C, planes = 1)
@@ -142,16 +160,102 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
 int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                          const float* mx, const float* my, int mode, hipStream_t st, bool* handled);
 
+// ------------------------------------------------------------------------------
+// cv2.resize(image, (W_out, H_out), interpolation=INTER_LINEAR)  (AGW/new_method.py:369, reached from :478 when the
+// attention map's size differs from the image's -- a no-op in both reference drivers).  OpenCV's published algorithm
+// (modules/imgproc/src/resize.cpp), parity unpinned like cv2.remap:
+//   fx = float((dx + 0.5) * scale_x - 0.5), sx = floor(fx), fx -= sx; sx < 0 -> (0, fx = 0); sx >= W-1 -> (W-1, fx = 0)
+//   rows likewise without the fx reset, indices clipped to the image;
+//   uint8: coefficients saturate_cast<short>(c * 2048); horizontal pass D = S[sx]*a0 + S[sx+1]*a1 (int32), vertical
+//          uchar((((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2);
+//   float32: D = S[sx]*a0 + S[sx+1]*a1, out = D0*b0 + D1*b1 (each operation rounded);
+//   an exact 2 x 2 decimation is INTER_AREA: (s00 + s01 + s10 + s11 + 2) >> 2 (float: sum * 0.25).
+// One thread per output element of an interleaved [B,H,W,C] image; a gather kernel, this is not a hot path.
+struct ResizeAxis {
+  int s0, s1;
+  float f;
+};
+__device__ __forceinline__ ResizeAxis resize_axis(int d, double scale, int size, bool reset_f) {
+  float f = (float)(((double)d + 0.5) * scale - 0.5);
+  int s = (int)floorf(f);
+  f = fsub(f, (float)s);
+  if (reset_f) {
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= size - 1) { f = 0.0f; s = size - 1; }
+  }
+  ResizeAxis a;
+  a.f = f;
+  a.s0 = min(max(s, 0), size - 1);
+  a.s1 = min(max(s + 1, 0), size - 1);
+  return a;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_linear_kernel(const T* __restrict__ src, T* __restrict__ dst, int C, int H,
+                                                            int W, int Ho, int Wo, double scale_x, double scale_y,
+                                                            int area2) {
+  const int b = blockIdx.z, y = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Wo * C) return;
+  const int x = e / C, c = e - x * C;
+  const T* s = src + (size_t)b * H * W * C;
+  T* o = dst + ((size_t)b * Ho + y) * Wo * C + e;
+  if (area2) {
+    const T* p = s + ((size_t)(2 * y) * W + 2 * x) * C + c;
+    if (sizeof(T) == 1) {
+      *o = (T)(((int)p[0] + (int)p[C] + (int)p[(size_t)W * C] + (int)p[(size_t)W * C + C] + 2) >> 2);
+    } else {
+      *o = (T)fmul(fadd(fadd(fadd((float)p[0], (float)p[C]), (float)p[(size_t)W * C]), (float)p[(size_t)W * C + C]), 0.25f);
+    }
+    return;
+  }
+  const ResizeAxis ax = resize_axis(x, scale_x, W, true), ay = resize_axis(y, scale_y, H, false);
+  const T* r0 = s + (size_t)ay.s0 * W * C;
+  const T* r1 = s + (size_t)ay.s1 * W * C;
+  const int i0 = ax.s0 * C + c, i1 = ax.s1 * C + c;
+  if (sizeof(T) == 1) {
+    const int a0 = __float2int_rn(fmul(fsub(1.0f, ax.f), 2048.0f)), a1 = __float2int_rn(fmul(ax.f, 2048.0f));
+    const int b0 = __float2int_rn(fmul(fsub(1.0f, ay.f), 2048.0f)), b1 = __float2int_rn(fmul(ay.f, 2048.0f));
+    const int d0 = (int)r0[i0] * a0 + (int)r0[i1] * a1, d1 = (int)r1[i0] * a0 + (int)r1[i1] * a1;
+    const int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+    *o = (T)min(max(v, 0), 255);
+  } else {
+    const float a0 = fsub(1.0f, ax.f), a1 = ax.f, b0 = fsub(1.0f, ay.f), b1 = ay.f;
+    const float d0 = fadd(fmul((float)r0[i0], a0), fmul((float)r0[i1], a1));
+    const float d1 = fadd(fmul((float)r1[i0], a0), fmul((float)r1[i1], a1));
+    *o = (T)fadd(fmul(d0, b0), fmul(d1, b1));
+  }
+}
+
 }  // namespace attwarp
 
 using namespace attwarp;
+
+extern "C" int attwarp_resize_linear(const void* src, void* dst, int dtype, int B, int C, int H, int W, int H_out,
+                                     int W_out, void* stream) {
+  ATTWARP_REQUIRE(src && dst, "resize_linear: null pointer");
+  ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0, "resize_linear: non-positive size");
+  ATTWARP_REQUIRE(dtype == ATTWARP_F32 || dtype == ATTWARP_U8, "resize_linear: dtype must be F32 or U8 (got %d)", dtype);
+  if (B > 65535 || H_out > 65535 || (long long)W_out * C > 2147483647LL / 2 || (long long)H * W * C > 2147483647LL)
+    return fail(ATTWARP_E_UNSUPPORTED, "resize_linear: image too large");
+  const double sx = 1.0 / ((double)W_out / (double)W), sy = 1.0 / ((double)H_out / (double)H);   // 1 / inv_scale, as OpenCV
+  const int area2 = (W == 2 * W_out && H == 2 * H_out) ? 1 : 0;
+  dim3 grid((W_out * C + 255) / 256, H_out, B);
+  if (dtype == ATTWARP_F32)
+    hipLaunchKernelGGL(resize_linear_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)src,
+                       (float*)dst, C, H, W, H_out, W_out, sx, sy, area2);
+  else
+    hipLaunchKernelGGL(resize_linear_kernel<uint8_t>, grid, dim3(256), 0, as_stream(stream), (const uint8_t*)src,
+                       (uint8_t*)dst, C, H, W, H_out, W_out, sx, sy, area2);
+  return check_launch("resize_linear_kernel");
+}
 
 extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int layout, int B, int C, int H, int W,
                                       int H_out, int W_out, const float* map_x, const float* map_y, int mode,
                                       void* stream) {
   ATTWARP_REQUIRE(src && dst && map_x && map_y, "remap_bilinear: null pointer");
   ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0, "remap_bilinear: non-positive size");
-  ATTWARP_REQUIRE(dtype == ATTWARP_F32 || dtype == ATTWARP_U8, "remap_bilinear: dtype must be F32 or U8 (got %d)", dtype);
+  ATTWARP_REQUIRE(dtype == ATTWARP_F32 || dtype == ATTWARP_U8 || dtype == ATTWARP_F64,
+                  "remap_bilinear: dtype must be F32, U8 or F64 (got %d)", dtype);
   ATTWARP_REQUIRE(layout == ATTWARP_HWC || layout == ATTWARP_CHW, "remap_bilinear: unknown layout %d", layout);
   ATTWARP_REQUIRE(mode == ATTWARP_EXACT || mode == ATTWARP_CV2, "remap_bilinear: unknown mode %d", mode);
   if (C > 4) return fail(ATTWARP_E_UNSUPPORTED, "remap_bilinear: C=%d > 4", C);
@@ -165,7 +269,7 @@ extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int
     int rc = launch_remap_rows((const float*)src, (float*)dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, st,
                                &handled, nullptr);
     if (handled) return rc;
-  } else {
+  } else if (dtype == ATTWARP_U8) {
     bool handled = false;
     int rc = launch_remap_rows_u8((const uint8_t*)src, (uint8_t*)dst, layout, B, C, H, W, H_out, W_out, map_x, map_y,
                                   mode, st, &handled);
@@ -183,6 +287,8 @@ extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int
 
   if (dtype == ATTWARP_F32) {
     ATTWARP_DISPATCH(float)
+  } else if (dtype == ATTWARP_F64) {
+    ATTWARP_DISPATCH(double)
   } else {
     ATTWARP_DISPATCH(uint8_t)
   }

@@ -108,10 +108,12 @@ def warp_image_by_attention(image: np.ndarray, att_map: np.ndarray, new_width: i
     return res[:, :, 0] if squeeze else res
 
 
-def resize_image_to_match_attmap(image: Optional[np.ndarray], att_map: Optional[np.ndarray]):
-    """Reference :355-376.  Same size -> copy.  Otherwise bilinear resize to the attention map's
-    size (pixel-centre aligned like ``cv2.resize(INTER_LINEAR)``, computed with the exact bilinear
-    resampler; OpenCV's 11-bit fixed-point variant is not reproduced -- unpinned)."""
+def resize_image_to_match_attmap(image: Optional[np.ndarray], att_map: Optional[np.ndarray], mode: str = "cv2"):
+    """Reference :355-376.  Same size -> copy.  Otherwise ``cv2.resize(image, (w, h), interpolation=INTER_LINEAR)`` to
+    the attention map's size.  ``mode="cv2"`` (default): OpenCV's published arithmetic -- half-pixel centres, 11-bit
+    fixed-point coefficients for uint8, an exact 2 x 2 decimation as INTER_AREA (``attwarp_resize_linear``; parity
+    unpinned like the resample, OpenCV is absent here); ``mode="exact"``: unquantised bilinear at the same centres.
+    uint8 and float32 images; other dtypes raise."""
     if image is None or att_map is None:
         return None
     th, tw = att_map.shape[:2]
@@ -120,12 +122,24 @@ def resize_image_to_match_attmap(image: Optional[np.ndarray], att_map: Optional[
         return image.copy()
     dev = _lib.default_device()
     img = np.asarray(image)
+    if img.dtype not in (np.uint8, np.float32):
+        raise TypeError(f"resize_image_to_match_attmap: uint8 or float32 image expected, got {img.dtype}")
     squeeze = img.ndim == 2
     if squeeze:
         img = img[:, :, None]
-    mx = ((torch.arange(tw, dtype=torch.float64) + 0.5) * (cw / tw) - 0.5).clamp(0, cw - 1).float().to(dev)[None]
-    my = ((torch.arange(th, dtype=torch.float64) + 0.5) * (ch / th) - 0.5).clamp(0, ch - 1).float().to(dev)[None]
-    out = remap_hwc(torch.from_numpy(np.ascontiguousarray(img)).to(dev).unsqueeze(0), mx, my, "exact")[0].cpu().numpy()
+    src = torch.from_numpy(np.ascontiguousarray(img)).to(dev).unsqueeze(0)
+    if mode == "cv2":
+        out_t = torch.empty((1, th, tw, img.shape[2]), device=dev, dtype=src.dtype)
+        with torch.cuda.device(dev):
+            _lib.call("attwarp_resize_linear", _lib.ptr(src), _lib.ptr(out_t), _lib.dtype_id(src), 1, img.shape[2], ch, cw,
+                      th, tw, _lib.stream_ptr(dev))
+        out = out_t[0].cpu().numpy()
+    elif mode == "exact":
+        mx = ((torch.arange(tw, dtype=torch.float64) + 0.5) * (cw / tw) - 0.5).clamp(0, cw - 1).float().to(dev)[None]
+        my = ((torch.arange(th, dtype=torch.float64) + 0.5) * (ch / th) - 0.5).clamp(0, ch - 1).float().to(dev)[None]
+        out = remap_hwc(src, mx, my, "exact")[0].cpu().numpy()
+    else:
+        raise ValueError(f"resize_image_to_match_attmap: unknown mode {mode!r}")
     return out[:, :, 0] if squeeze else out
 
 
@@ -173,7 +187,7 @@ def save_warped_image(image_path, att_map, original_image_save_path, masked_over
         if original_image_save_path:
             _imwrite(original_image_save_path, image)
         att_map = _coerce_att_map(att_map, width, height)
-        image_for_warping = resize_image_to_match_attmap(image, att_map)
+        image_for_warping = resize_image_to_match_attmap(image, att_map, mode)
         if image_for_warping is None:
             raise ValueError("Failed to resize image to match attention map dimensions for warping")
         name = set_transform_function(transform, exp_scale, exp_divisor, apply_inverse)

@@ -230,10 +230,20 @@ ATTWARP_API int attwarp_axis_maps_from_attention(const void* att, int dtype, int
                                      int transform, double exp_scale, double exp_divisor, int apply_inverse,
                                      float* map_x, float* map_y, void* ws, void* stream);
 
+/* ---- cv2.resize(image, (W_out, H_out), interpolation=cv2.INTER_LINEAR), AGW/new_method.py:369 (reached from :478
+ * when the attention map's size differs from the image's; a no-op in both reference drivers).
+ * src [B,H,W,C] interleaved, F32 or U8 -> dst [B,H_out,W_out,C].  OpenCV's published algorithm (resize.cpp): half-pixel
+ * centres, uint8 with 11-bit fixed-point coefficients and its (b * (D >> 4)) >> 16 vertical pass, an exact 2 x 2
+ * decimation as INTER_AREA; parity unpinned like attwarp_remap_bilinear's cv2 mode (OpenCV is absent here). */
+ATTWARP_API int attwarp_resize_linear(const void* src, void* dst, int dtype, int B, int C, int H, int W, int H_out,
+                          int W_out, void* stream);
+
 /* ---- A12 / A13 tail: cv2.remap(INTER_LINEAR, BORDER_REPLICATE) with separable maps,
  * AGW/new_method.py:268-271, MN/checkpoint_utils.py:195-198.
- * src [B,H,W,C] (HWC) or [B,C,H,W] (CHW), dtype F32 or U8 -> dst same layout with (H_out,W_out).
- * map_x [B,W_out], map_y [B,H_out] float32 source coordinates.  C <= 4.
+ * src [B,H,W,C] (HWC) or [B,C,H,W] (CHW), dtype F32, U8 or F64 -> dst same layout with (H_out,W_out).
+ * map_x [B,W_out], map_y [B,H_out] float32 source coordinates.  C <= 4.  (F64: the dtype pass-through of
+ * warp_from_cdf_torch, MN/checkpoint_utils.py:152,203 -- OpenCV's CV_64F arithmetic: float32 table weights, the four
+ * products accumulated in double; generic gather kernel only.)
  * Coordinates outside the image take the replicate border.  Non-finite / huge coordinates: mode CV2 follows
  * cvRound(32 * m) of OpenCV's x86 builds (NaN, +-Inf and products outside int32 -> INT_MIN -> pixel 0, zero fraction,
  * for either sign); mode EXACT clamps the coordinate to [-1, size] first (NaN counts as -1).  No output is NaN

@@ -813,6 +813,8 @@ def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: 
         src = src[:, :, None]
     H, W, C = src.shape
     is_u8 = src.dtype == np.uint8
+    if src.dtype == np.float64:
+        return _remap_f64(src, np.asarray(map_x, F32), np.asarray(map_y, F32), mode)[:, :, 0 if squeeze else slice(None)]
     if mode == "exact":
         x0, x1, fx = _axis_taps(map_x, W)
         y0, y1, fy = _axis_taps(map_y, H)
@@ -827,6 +829,92 @@ def remap_bilinear(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: 
         out = _remap_cv2_compat(src, np.asarray(map_x, F32), np.asarray(map_y, F32))
     else:
         raise ValueError(mode)
+    return out[:, :, 0] if squeeze else out
+
+
+def _remap_f64(src: np.ndarray, map_x: np.ndarray, map_y: np.ndarray, mode: str) -> np.ndarray:
+    """float64 images (``warp_from_cdf_torch`` hands the image to ``cv2.remap`` in its own dtype,
+    MN/checkpoint_utils.py:152,195-203): OpenCV's CV_64F path keeps the float32 table weights and accumulates the four
+    products in double, left to right; ``exact``: the three lerps in double with the float32 coordinate fractions."""
+    H, W, C = src.shape
+    if mode == "exact":
+        x0, x1, fx = _axis_taps(map_x, W)
+        y0, y1, fy = _axis_taps(map_y, H)
+        top, bot = src[y0], src[y1]
+        v = top + fy.astype(F64)[:, None, None] * (bot - top)
+        a, b = v[:, x0], v[:, x1]
+        return a + fx.astype(F64)[None, :, None] * (b - a)
+    sx = _cv_round(map_x * F32(32)); sy = _cv_round(map_y * F32(32))
+    ix, kx = sx >> 5, sx & 31
+    iy, ky = sy >> 5, sy & 31
+    x0 = np.clip(ix, 0, W - 1); x1 = np.clip(ix + 1, 0, W - 1)
+    y0 = np.clip(iy, 0, H - 1); y1 = np.clip(iy + 1, 0, H - 1)
+    tx = (kx.astype(F32) * F32(1 / 32)).astype(F32); ty = (ky.astype(F32) * F32(1 / 32)).astype(F32)
+    ox = (F32(1) - tx).astype(F32); oy = (F32(1) - ty).astype(F32)
+    w00 = (oy[:, None] * ox[None, :]).astype(F32).astype(F64)[..., None]
+    w01 = (oy[:, None] * tx[None, :]).astype(F32).astype(F64)[..., None]
+    w10 = (ty[:, None] * ox[None, :]).astype(F32).astype(F64)[..., None]
+    w11 = (ty[:, None] * tx[None, :]).astype(F32).astype(F64)[..., None]
+    p00 = src[y0][:, x0]; p01 = src[y0][:, x1]; p10 = src[y1][:, x0]; p11 = src[y1][:, x1]
+    return ((p00 * w00 + p01 * w01) + p10 * w10) + p11 * w11
+
+
+def resize_linear_cv2(img: np.ndarray, size_wh: Tuple[int, int]) -> np.ndarray:
+    """``cv2.resize(img, (W_out, H_out), interpolation=cv2.INTER_LINEAR)`` (AGW/new_method.py:369) restated from
+    OpenCV's published algorithm (modules/imgproc/src/resize.cpp).  PARITY UNPINNED (OpenCV is absent here).
+
+    * ``scale = 1 / (dst / src)`` (double); ``f = float32((d + 0.5) * scale - 0.5)``, ``s = floor(f)``, ``f -= s``;
+      columns: ``s < 0 -> (0, f = 0)``, ``s >= W - 1 -> (W - 1, f = 0)``; rows: indices clipped, f kept;
+    * uint8: coefficients ``saturate_cast<short>(c * 2048)`` (round half to even); horizontal pass
+      ``D = S[s] * a0 + S[s + 1] * a1`` in int32; vertical ``(((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2``;
+    * float32: ``D = S[s] * a0 + S[s + 1] * a1``, ``out = D0 * b0 + D1 * b1``, every operation rounded to float32;
+    * an exact 2 x 2 decimation is INTER_AREA: ``(s00 + s01 + s10 + s11 + 2) >> 2`` (float32: ``sum * 0.25``).
+    img [H,W] or [H,W,C] uint8 / float32."""
+    img = np.asarray(img)
+    squeeze = img.ndim == 2
+    if squeeze:
+        img = img[:, :, None]
+    if img.dtype not in (np.uint8, F32):
+        raise TypeError("resize_linear_cv2: uint8 or float32")
+    H, W, C = img.shape
+    Wo, Ho = int(size_wh[0]), int(size_wh[1])
+    is_u8 = img.dtype == np.uint8
+    if W == 2 * Wo and H == 2 * Ho:
+        a, b, c, d = img[0::2, 0::2], img[0::2, 1::2], img[1::2, 0::2], img[1::2, 1::2]
+        if is_u8:
+            out = ((a.astype(np.int64) + b + c + d + 2) >> 2).astype(np.uint8)
+        else:
+            out = ((((a + b).astype(F32) + c).astype(F32) + d).astype(F32) * F32(0.25)).astype(F32)
+        return out[:, :, 0] if squeeze else out
+
+    def axis(n_out, n_in, reset):
+        scale = 1.0 / (float(n_out) / float(n_in))
+        f = ((np.arange(n_out, dtype=F64) + 0.5) * scale - 0.5).astype(F32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(F32)).astype(F32)
+        if reset:
+            lo, hi = s < 0, s >= n_in - 1
+            f = np.where(lo | hi, F32(0), f).astype(F32)
+            s = np.where(lo, 0, np.where(hi, n_in - 1, s))
+        return np.clip(s, 0, n_in - 1), np.clip(s + 1, 0, n_in - 1), f
+
+    x0, x1, fx = axis(Wo, W, True)
+    y0, y1, fy = axis(Ho, H, False)
+    if is_u8:
+        a0 = np.rint(((F32(1) - fx).astype(F32) * F32(2048)).astype(F32)).astype(np.int64)[None, :, None]
+        a1 = np.rint((fx * F32(2048)).astype(F32)).astype(np.int64)[None, :, None]
+        b0 = np.rint(((F32(1) - fy).astype(F32) * F32(2048)).astype(F32)).astype(np.int64)[:, None, None]
+        b1 = np.rint((fy * F32(2048)).astype(F32)).astype(np.int64)[:, None, None]
+        s = img.astype(np.int64)
+        d0 = s[y0][:, x0] * a0 + s[y0][:, x1] * a1
+        d1 = s[y1][:, x0] * a0 + s[y1][:, x1] * a1
+        out = np.clip((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2, 0, 255).astype(np.uint8)
+    else:
+        a0 = (F32(1) - fx).astype(F32)[None, :, None]; a1 = fx[None, :, None]
+        b0 = (F32(1) - fy).astype(F32)[:, None, None]; b1 = fy[:, None, None]
+        d0 = ((img[y0][:, x0] * a0).astype(F32) + (img[y0][:, x1] * a1).astype(F32)).astype(F32)
+        d1 = ((img[y1][:, x0] * a0).astype(F32) + (img[y1][:, x1] * a1).astype(F32)).astype(F32)
+        out = ((d0 * b0).astype(F32) + (d1 * b1).astype(F32)).astype(F32)
     return out[:, :, 0] if squeeze else out
 
 

@@ -2015,6 +2015,50 @@ def test_fused_step_equals_three_launches(dev, S, B, layout, mode):
             assert torch.equal(ow.outs[r], refs[r]), (K, r)
 
 
+@pytest.mark.parametrize("dt", [np.uint8, np.float32])
+def test_resize_linear_cv2_vs_oracle(dev, dt):
+    """cv2.resize(INTER_LINEAR) (AGW/new_method.py:369): attwarp_resize_linear == the oracle's restatement of OpenCV's
+    published arithmetic, bit for bit: up- and down-scaling, the exact 2 x 2 decimation (INTER_AREA), non-integer
+    factors, thin images, 1 / 3 / 4 channels and the 2-D form; the exact mode stays available."""
+    from attwarp_amd import new_method as nm
+    rng = np.random.default_rng(77)
+    for (H, W, C, th, tw) in [(37, 53, 3, 74, 106), (64, 48, 3, 32, 24), (37, 53, 1, 20, 30), (50, 70, 4, 18, 26),
+                              (9, 200, 3, 90, 7), (336, 336, 3, 500, 500), (24, 24, 0, 336, 336), (31, 17, 3, 31, 18)]:
+        shape = (H, W) if C == 0 else (H, W, C)
+        img = rng.integers(0, 256, shape, dtype=np.uint8) if dt == np.uint8 else rng.random(shape, dtype=np.float32)
+        att = np.zeros((th, tw), np.float32)
+        got = nm.resize_image_to_match_attmap(img, att)
+        assert got.dtype == dt and got.shape[:2] == (th, tw)
+        assert np.array_equal(got, O.resize_linear_cv2(img, (tw, th))), (H, W, C, th, tw)
+        ex = nm.resize_image_to_match_attmap(img, att, mode="exact")
+        assert np.abs(ex.astype(np.float64) - got.astype(np.float64)).max() <= (1.0 if dt == np.uint8 else 1e-5)
+    assert np.array_equal(nm.resize_image_to_match_attmap(img, np.zeros(img.shape[:2])), img)
+    with pytest.raises(TypeError):
+        nm.resize_image_to_match_attmap(img.astype(np.float64), att)
+
+
+@pytest.mark.parametrize("mode", ["cv2", "exact"])
+def test_remap_float64_pass_through(dev, mode):
+    """warp_from_cdf_torch keeps the image dtype into cv2.remap (MN/checkpoint_utils.py:152,203): a float64 image is
+    resampled in double (OpenCV's CV_64F arithmetic: float32 table weights, products accumulated in double), not
+    narrowed to float32 -- kernel == oracle bit for bit, both layouts; and it differs from the float32 result."""
+    from attwarp_amd import checkpoint_utils as cu
+    rng = np.random.default_rng(5)
+    B, C, H, W, Ho, Wo = 2, 3, 33, 47, 40, 52
+    img = rng.random((B, C, H, W))
+    Fx = np.cumsum(rng.random((B, W)).astype(np.float32) + 0.05, 1); Fx = (Fx / Fx[:, -1:]).astype(np.float32)
+    Fy = np.cumsum(rng.random((B, H)).astype(np.float32) + 0.05, 1); Fy = (Fy / Fy[:, -1:]).astype(np.float32)
+    got = cu.warp_from_cdf_torch(T(img, dev), T(Fx, dev), T(Fy, dev), (Ho, Wo), mode=mode)
+    assert got.dtype == torch.float64
+    ref = O.warp_from_cdf(img, Fx, Fy, (Ho, Wo), mode)
+    assert ref.dtype == np.float64 and np.array_equal(N(got), ref)
+    narrow = N(cu.warp_from_cdf_torch(T(img.astype(np.float32), dev), T(Fx, dev), T(Fy, dev), (Ho, Wo), mode=mode))
+    assert 0 < np.abs(narrow - ref).max() < 1e-6
+    mx, my = cu.axis_maps_from_cdf(T(Fx, dev), T(Fy, dev), (Ho, Wo))
+    hwc = cu.remap_separable(T(np.ascontiguousarray(img.transpose(0, 2, 3, 1)), dev), mx, my, mode=mode, channels_last=True)
+    assert np.array_equal(N(hwc).transpose(0, 3, 1, 2), ref)
+
+
 def test_fused_step_argument_checks(dev):
     from attwarp_amd._lib import call, ptr, AttWarpError
     z = torch.zeros(64, device=dev)

@@ -90,3 +90,35 @@ def test_attn_reduce_rows_sum_to_one():
     e = np.exp(lg - lg.max(-1, keepdims=True)); rows = (e / e.sum(-1, keepdims=True)).astype(np.float32)
     m = O.attn_reduce_stack(rows, [30, 50])
     np.testing.assert_allclose(m.sum(1), 1.0, atol=2e-6)       # every head renormalised over the image tokens
+
+
+def test_resize_linear_cv2_properties():
+    """The restatement of cv2.resize(INTER_LINEAR) (AGW/new_method.py:369; parity unpinned, OpenCV is absent): same size
+    = copy, an exact 2 x 2 decimation = the rounded 2 x 2 mean (INTER_AREA), otherwise within one grey level (uint8: the
+    11-bit coefficients and the >> 4 / >> 16 truncations) of float64 bilinear interpolation at half-pixel centres."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    assert np.array_equal(O.resize_linear_cv2(img, (53, 37)), img)
+    even = img[:36, :52]
+    s = even.astype(np.int64)
+    assert np.array_equal(O.resize_linear_cv2(even, (26, 18)), ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2))
+    for (wo, ho) in [(106, 74), (30, 20), (100, 11), (7, 90), (54, 37)]:
+        fx = np.clip((np.arange(wo) + 0.5) * 53 / wo - 0.5, 0, 52); fy = np.clip((np.arange(ho) + 0.5) * 37 / ho - 0.5, 0, 36)
+        x0 = np.floor(fx).astype(int); x1 = np.minimum(x0 + 1, 52); y0 = np.floor(fy).astype(int); y1 = np.minimum(y0 + 1, 36)
+        tx = (fx - x0)[None, :, None]; ty = (fy - y0)[:, None, None]; f = img.astype(np.float64)
+        ref = (f[y0][:, x0] * (1 - tx) + f[y0][:, x1] * tx) * (1 - ty) + (f[y1][:, x0] * (1 - tx) + f[y1][:, x1] * tx) * ty
+        assert np.abs(O.resize_linear_cv2(img, (wo, ho)).astype(np.float64) - ref).max() < 1.0
+        g = O.resize_linear_cv2((img / 255).astype(np.float32), (wo, ho))
+        assert g.dtype == np.float32 and np.abs(g - ref / 255).max() < 1e-6
+
+
+def test_remap_float64_keeps_double_precision():
+    """float64 images are resampled in double (warp_from_cdf_torch's dtype pass-through, MN/checkpoint_utils.py:152,203)."""
+    rng = np.random.default_rng(4)
+    d = rng.random((9, 11, 2))
+    mx = np.sort(rng.random(14).astype(np.float32) * 12 - 1); my = np.sort(rng.random(10).astype(np.float32) * 10 - 1)
+    for mode in ("exact", "cv2"):
+        a = O.remap_bilinear(d, mx, my, mode)
+        b = O.remap_bilinear(d.astype(np.float32), mx, my, mode)
+        assert a.dtype == np.float64 and b.dtype == np.float32 and 0 < np.abs(a - b).max() < 1e-6
+    assert np.array_equal(O.remap_bilinear(d, np.arange(11, dtype=np.float32), np.arange(9, dtype=np.float32), "cv2"), d)
