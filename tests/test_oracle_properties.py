@@ -109,7 +109,7 @@ def test_resize_linear_cv2_properties():
         ref = (f[y0][:, x0] * (1 - tx) + f[y0][:, x1] * tx) * (1 - ty) + (f[y1][:, x0] * (1 - tx) + f[y1][:, x1] * tx) * ty
         assert np.abs(O.resize_linear_cv2(img, (wo, ho)).astype(np.float64) - ref).max() < 1.0
         g = O.resize_linear_cv2((img / 255).astype(np.float32), (wo, ho))
-        assert g.dtype == np.float32 and np.abs(g - ref / 255).max() < 1e-6
+        assert g.dtype == np.float32 and np.abs(g - ref / 255).max() < 5e-6      # float32 coordinates and weights
 
 
 def test_remap_float64_keeps_double_precision():
