@@ -627,6 +627,21 @@ def main():
                                   else f"same batch as [B,S,S,3], mode={args.mode}",
                                   "value": round(B * args.steps / w3, 1), "unit": "images/s",
                                   "ms_per_step": round(w3 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+        # the same step as ONE launch (attwarp_warp_step_fused through pipeline.OverlappedWarp): at this size it only
+        # hides the map construction and two launch boundaries behind the resample
+        step.set_layout(args.layout)
+        ow = pipeline.OverlappedWarp([x[0] for x in step.sets], [x[1] for x in step.sets], step.starts,
+                                     channels_last=(args.layout == "hwc"), mode=args.mode)
+        w5, _ = time_overlapped(ow, args.steps, args.warmup, D)
+        same = bool(torch.equal(ow.outs[0], pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
+                                                                            channels_last=(args.layout == "hwc"), mode=args.mode)))
+        result["also_fused"] = {"workload": "same batch; reduce + maps + resample of a step as one launch (pattern "
+                                            f"'{ow.pattern}'), HIP-graph replay, exactly {args.steps} of each kernel",
+                                "value": round(B * args.steps / w5, 1), "unit": "images/s",
+                                "ms_per_step": round(w5 / args.steps * 1e3, 4), "bit_identical_to_serial": same,
+                                "step_TBps": round(step_bytes(B, S) / (w5 / args.steps) / 1e12, 3)}
+        del ow
+        torch.cuda.empty_cache()
         # SURVEY 8d "value distributions to also run": peaked attention (one 3x3 hot spot x100: strong magnification
         # there, minification elsewhere) and all-zero attention (the uniform fallback, AGW/new_method.py:231-239 /
         # clamp_min(1e-6) in MN/checkpoint_utils.py:36) on the same images

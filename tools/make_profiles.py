@@ -3,8 +3,8 @@ under profiles/: kernel-stats table, HBM traffic of the resample kernel from the
 bench lines, stage / chain benches.   usage: make_profiles.py [src_tag] [name]   (default r2 round2)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src_tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
-tag = sys.argv[2] if len(sys.argv) > 2 else "round2"
+src_tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[2] if len(sys.argv) > 2 else "round3"
 SRC = os.path.join(ROOT, "gpurun_out", src_tag)
 DST = os.path.join(ROOT, "profiles")
 
@@ -21,7 +21,8 @@ with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({tag})\n\n")
     f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
             "--no-cpu-baseline` (tools/refresh_profiles.sh).  The run measures, in this order: mode=cv2 HWC (main line), "
-            "mode=exact HWC, mode=cv2 CHW at B=256 1024x1024, then mode=cv2 at B=64 336x336; `remap_rows_kernel` rows are "
+            "mode=exact HWC, mode=cv2 CHW, the fused one-launch step (`warp_step_kernel`), peaked and all-zero attention at "
+            "B=256 1024x1024, then B=64 and B=256 at 336x336 (fused graph path + eager); `remap_rows_kernel` rows are "
             "per template instance (last template arguments: MODE 1 = cv2 / 0 = exact, SINGLE).\n\n")
     f.write("| kernel | calls | avg us | min us | max us | total ms | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
     for r in rows:
@@ -54,6 +55,9 @@ for mode in ("cv2", "exact"):
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 bench_line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, f"{tag}_bench.json"), "w").write(bench_line)
-for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats"):
+for name in ("bench_336", "bench_336x256"):
+    if os.path.exists(os.path.join(SRC, f"{name}.json")):
+        open(os.path.join(DST, f"{tag}_{name}.json"), "w").write([l for l in open(os.path.join(SRC, f"{name}.json")) if l.startswith("{")][-1])
+for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench"):
     shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)

@@ -3,7 +3,7 @@
 # under gpurun_out/<tag>/.  tools/make_profiles.py turns it into the committed summaries.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r2}
+TAG=${1:-r3}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
@@ -13,6 +13,10 @@ for MODE in cv2 exact; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
 done
+python3 $ROOT/bench.py --workload 336 --no-cpu-baseline > $OUT/bench_336.json 2> $OUT/bench_336.err
+python3 $ROOT/bench.py --workload 336x256 --no-cpu-baseline > $OUT/bench_336x256.json 2> $OUT/bench_336x256.err
+python3 $ROOT/tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/attn_bench.txt
+python3 $ROOT/tools/u8_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/u8_bench.txt
 python3 $ROOT/tools/stage_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/stage_bench.txt
 python3 $ROOT/tools/chain_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
 python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.txt
