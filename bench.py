@@ -426,9 +426,11 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline):
            "step_algorithmic_bytes": sb, "step_TBps": round(sb / (ms * 1e-3) / 1e12, 3),
            "step_frac_of_hbm_peak": round(sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "rotating_batches": ow.n, "bit_identical_to_serial": same,
-           "path": "pipeline.OverlappedWarp: resample(k) || maps(k+1) || reduce(k+2) as three branches of one HIP graph, "
-                   f"graphs of 8 steps, ring of {ow.n} independent batches (>= 2 GiB: every step streams from HBM), exactly "
-                   f"{K} of each kernel in the timed region, no host call per kernel",
+           "path": "pipeline.OverlappedWarp, pattern '" + ow.pattern + "': resample(k) + maps(k+1) + reduce(k+2) "
+                   + ("as block ranges of ONE launch per step (attwarp_warp_step_fused)" if ow.pattern == "fused"
+                      else "as branches of one HIP graph") +
+                   f", graphs of 8 steps, ring of {ow.n} independent batches (>= 2 GiB: every step streams from HBM), exactly "
+                   f"{K} of each piece of work in the timed region, one host call per 8 steps",
            "eager": {"ms_per_step": round(w_e / K * 1e3, 4), "images_per_s": round(B * K / w_e, 1),
                      "step_TBps": round(sb / (w_e / K) / 1e12, 3),
                      "stages_ms": [round(v, 4) for v in st.stage_ms()],
@@ -650,7 +652,11 @@ def main():
             keep = step.sets
             step.sets = [(img, rows, out) for (img, _, out) in keep]
             w4, _ = time_steps(step, args.steps, args.warmup, D)
-            result[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}",
+            note = ("all-zero attention collapses the CDF (clamp_min(1e-6), MN/checkpoint_utils.py:36): every output pixel "
+                    "maps to the last source rows, the kernel reads almost nothing and is bound by its writes alone -- "
+                    "`frac` is against the nominal 2*S*S*3*4 bytes and exceeds what was moved") if name == "zero_attention" else \
+                   "one 3x3 hot spot x100 per image: magnified there, minified elsewhere (two source rows per output row)"
+            result[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}", "note": note,
                                       "value": round(B * args.steps / w4, 1), "unit": "images/s",
                                       "ms_per_step": round(w4 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
             step.sets = keep
