@@ -333,17 +333,21 @@ static int launch_ko(const Params& p, hipStream_t st) {
 //     16-bit values (half the LDS bytes), in the order [e0, e2, e1, e3] per group of 4 (no re-interleaving: the tap
 //     offsets know the order);
 //   * horizontal: a lane produces 4 CONSECUTIVE output bytes: 8 ds_read_u16, per byte
-//     ((v0 << 5) + 512 + kx*(v1 - v0)) >> 10, packed and stored as one dword -- no LDS output row, no flush pass;
+//     ((32 - kx)*v0 + kx*v1 + 512) >> 10 (one v_dot2_u32_u16 on the tap pair), packed and stored as one dword -- no LDS
+//     output row, no flush pass;
 //     tap 1 is always "tap 0's pixel + 1" with kx forced to 0 where OpenCV clamps both taps to the same pixel (integer
 //     arithmetic: a zero weight is exact), so the clamped cases need no second offset logic.
 // Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
+constexpr int U8I_VLP = 4096 + 16;      // u16 elements per LDS row buffer: rows of <= 4096 bytes + one pixel of slack
+
 template <int KI, int KD, bool HWC>
 __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_my = smem;                                               // RMAX
-  const int VLP = ((p.VL + 7) & ~7) + 8;                            // u16 elements per LDS row (+ one pixel of slack)
+  // two row buffers a COMPILE-TIME distance apart: tap offsets then fold into the 16-bit offset field of the LDS
+  // instructions (with a run-time stride every one of the 8 reads per output dword cost a v_add_u32 for its address)
   uint16_t* vrow0 = reinterpret_cast<uint16_t*>(smem + RMAX);
-  uint16_t* vrow1 = vrow0 + VLP;
+  uint16_t* vrow1 = vrow0 + U8I_VLP;
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
   {
@@ -355,39 +359,35 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   uint8_t* dst_b = p.dst + (long long)b * p.oimg_stride;
 
   // source dwords this thread owns (clamped: padding lanes repeat the last dword)
-  int goff[KI], voff[KI];           // byte offset inside the image (row 0) / u16 index in the LDS row
-  bool vswap[KI];                   // this dword's two LDS dwords are stored swapped (bank swizzle, see lds_off)
+  unsigned goff[KI];                // byte offset inside the image (row 0): unsigned, so the loads take the SGPR-base form
+  int voff[KI];                     // u16 index in the LDS row
   {
     const int dpr = p.row_len >> 2, nd = p.VL >> 2;
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int d = min(tid + NT * k, nd - 1);
       const int pl = HWC ? 0 : d / dpr;
-      goff[k] = (int)(pl * p.plane_stride) + 4 * (d - pl * dpr);
+      goff[k] = (unsigned)(pl * p.plane_stride) + 4u * (unsigned)(d - pl * dpr);
       voff[k] = 4 * d;
-      vswap[k] = (d >> 5) & 1;
     }
   }
   // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
   // order) and kx
-  unsigned t0[KD][4], t1[KD][4], kxp[KD];
+  unsigned t0[KD][4], t1[KD][4], wpk[KD][4];    // wpk: (32 - kx) | kx << 16, the two weights of v_dot2_u32_u16
   int soff[KD];
   {
     const int dpo = p.orow_len >> 2, ndo = p.OVL >> 2;
-    // u16 element e of the row lives in dword 2*(e/4) + (e & 1), half (e >> 1) & 1 -- with the two dwords of a group
-    // SWAPPED in every other window of 64 dwords: a lane gathers 4 consecutive output bytes, i.e. for slopes near 1
-    // lanes l and l + 32 read dwords 128 bytes * 2 apart -- the same bank; the swap moves the upper half-wave onto the
-    // other 32 banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.27 -> see profiles/round3_chain_pmc.txt)
-    auto lds_off = [](unsigned e) -> unsigned {
-      return 2u * ((e & ~3u) | ((((e & 1u) ^ ((e >> 7) & 1u)) << 1) | ((e >> 1) & 1u)));
-    };
+    // u16 element e of the row lives at position [e0, e2, e1, e3] of its group of four (the vertical pass produces the
+    // pairs (0,2) and (1,3) of a source dword; no re-interleaving).  (Swapping the two dwords of a group in every other
+    // 64-dword window, so that lanes l and l + 32 of a slope-1 gather use different banks, was measured: no effect --
+    // the kernel is bound by VALU issue -- and cost two selects per source dword; taken out.)
+    auto lds_off = [](unsigned e) -> unsigned { return 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
 #pragma unroll
     for (int k = 0; k < KD; ++k) {
       const int d = min(tid + NT * k, ndo - 1);
       const int pl = HWC ? 0 : d / dpo;
       const int r0 = 4 * (d - pl * dpo);                            // first byte of the dword inside its plane row
       soff[k] = (int)(pl * p.oplane_stride) + r0;
-      unsigned kp = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = r0 + j, x = r / p.CS, c = r - x * p.CS;
@@ -400,9 +400,8 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
         const unsigned e1 = (i0 == i1) ? e0 : (unsigned)(pl * p.row_len + i1 * p.CS + c);
         t0[k][j] = lds_off(e0);
         t1[k][j] = lds_off(e1);
-        kp |= kx << (8 * j);
+        wpk[k][j] = (32u - kx) | (kx << 16);
       }
-      kxp[k] = kp;
     }
   }
 
@@ -419,11 +418,21 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   uint32_t A[KI], C[KI];
   int y0 = 0, nrows = 0;
 #define ATTWARP_U8I_FETCH()                                                                            \
-  _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                      \
-    A[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)ci0 * p.row_len + goff[k]);            \
-    C[k] = *reinterpret_cast<const uint32_t*>(src_b + (long long)ci1 * p.row_len + goff[k]);            \
+  {                                                                                                    \
+    const uint8_t* ra_ = src_b + (long long)ci0 * p.row_len;   /* block uniform: SGPR pair */           \
+    const uint8_t* rc_ = src_b + (long long)ci1 * p.row_len;                                            \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
+      A[k] = *reinterpret_cast<const uint32_t*>(ra_ + goff[k]);                                         \
+      C[k] = *reinterpret_cast<const uint32_t*>(rc_ + goff[k]);                                         \
+    }                                                                                                  \
   }
-#define ATTWARP_U8I_ROW(q_, vbuf)                                                                      \
+  /* Horizontal pass: (32 - kx) * v0 + kx * v1 + 512 is one v_dot2_u32_u16 on the tap pair (24 VALU instructions per     \
+     output dword, 30 with the scalar form of round 2).  Measured and dropped: both taps into one register with          \
+     ds_read_u16_d16 / _d16_hi -- on this part (SRAM ECC) a d16 load clears the other half instead of preserving it -- \
+     and, in any form, fewer VALU instructions: 139 -> 80 per row and thread left the time where it was (347 us at       \
+     1024 -> 1024 B=256): the kernel is not bound by VALU issue alone but by VALU + 8 LDS gathers per output dword (47 % \
+     of the LDS cycles bank conflicts on maps that are not near identity, profiles/round3_chain_pmc.txt) + HBM. */      \
+#define ATTWARP_U8I_ROW(q_, vbuf)                                                                \
   {                                                                                                    \
     const unsigned w1_ = cky, w0_ = 32u - cky;                                                         \
     const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
@@ -433,8 +442,8 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
       const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
       uint2 st_;                                                                                       \
-      st_.x = __builtin_bit_cast(uint32_t, vswap[k] ? v13_ : v02_);                                    \
-      st_.y = __builtin_bit_cast(uint32_t, vswap[k] ? v02_ : v13_);                                    \
+      st_.x = __builtin_bit_cast(uint32_t, v02_);                                                      \
+      st_.y = __builtin_bit_cast(uint32_t, v13_);                                                      \
       *reinterpret_cast<uint2*>((vbuf) + voff[k]) = st_;                                               \
     }                                                                                                  \
     if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
@@ -442,8 +451,8 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       ATTWARP_U8I_FETCH()                                                                              \
     }                                                                                                  \
     __syncthreads();                                                                                   \
-    const char* vb_ = reinterpret_cast<const char*>(vbuf);                                             \
     uint8_t* orow_ = dst_b + (long long)(y0 + (q_)) * p.orow_len;                                       \
+    const char* vb_ = reinterpret_cast<const char*>(vbuf);                                             \
     _Pragma("unroll") for (int k = 0; k < KD; ++k) {                                                    \
       unsigned v0_[4], v1_[4];                                                                         \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
@@ -451,10 +460,10 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
         v1_[j] = *reinterpret_cast<const uint16_t*>(vb_ + t1[k][j]);                                   \
       }                                                                                                \
       unsigned o_ = 0;                                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
-        const int kx_ = (int)((kxp[k] >> (8 * j)) & 0xffu);                                            \
-        const int in_ = (int)(v0_[j] << 5) + 512 + __mul24(kx_, (int)v1_[j] - (int)v0_[j]);            \
-        o_ |= ((unsigned)in_ >> 10) << (8 * j);                                                        \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {   /* (32 - kx) * v0 + kx * v1 + 512: one v_dot2_u32_u16 */ \
+        const us2 pr_ = {(unsigned short)v0_[j], (unsigned short)v1_[j]};                               \
+        const unsigned in_ = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u, false); \
+        o_ |= (in_ >> 10) << (8 * j);                                                                  \
       }                                                                                                \
       if (tid + NT * k < (p.OVL >> 2)) *reinterpret_cast<uint32_t*>(orow_ + soff[k]) = o_;             \
     }                                                                                                  \
@@ -483,8 +492,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
 
 template <int KI>
 static int launch_u8i_ki(const Params& p, hipStream_t st) {
-  const int VLP = ((p.VL + 7) & ~7) + 8;
-  const size_t lds = (size_t)RMAX * sizeof(float) + 2 * (size_t)VLP * sizeof(uint16_t);
+  const size_t lds = (size_t)RMAX * sizeof(float) + 2 * (size_t)U8I_VLP * sizeof(uint16_t);
   const int kd = ((p.OVL >> 2) + NT - 1) / NT;
   const dim3 g(p.nblocks), t(NT);
 #define ATTWARP_U8I_LAUNCH(KD)                                                                              \
