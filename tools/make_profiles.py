@@ -10,27 +10,43 @@ DST = os.path.join(ROOT, "profiles")
 
 def one(pattern):
     files = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    assert len(files) == 1, (pattern, files)
-    return files[0]
+    assert files, pattern
+    return max(files, key=os.path.getmtime)      # gpurun merges into gpurun_out/: older leases' files may still lie there
 
 stats = one("keep/trace/*kernel_stats.csv")
 shutil.copy(stats, os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))
+full = glob.glob(os.path.join(SRC, "keep/trace_full/*kernel_stats.csv"))
+if full:
+    shutil.copy(max(full, key=os.path.getmtime), os.path.join(DST, f"{tag}_bench_full_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 prof = json.loads([l for l in open(os.path.join(SRC, "bench_profiled.json")) if l.startswith("{")][-1])
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({tag})\n\n")
     f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
-            "--no-cpu-baseline` (tools/refresh_profiles.sh).  The run measures, in this order: mode=cv2 HWC (main line), "
-            "mode=exact HWC, mode=cv2 CHW, the fused one-launch step (`warp_step_kernel`), peaked and all-zero attention at "
-            "B=256 1024x1024, then B=64 and B=256 at 336x336 (fused graph path + eager); `remap_rows_kernel` rows are "
-            "per template instance (last template arguments: MODE 1 = cv2 / 0 = exact, SINGLE).\n\n")
+            "--no-cpu-baseline --no-also` (tools/refresh_profiles.sh): ONLY the main measurement -- 25 pre-conditioning + 3 "
+            "warm-up + 20 timed steps of mode=cv2 HWC at B=256 1024x1024 -- so the average of `remap_rows_kernel<..., 1, true>` "
+            "below is the average of the launches `bench.py` times (plus the untimed ones before them).  The stats of the "
+            "WHOLE default command (exact / CHW / fused / peaked / zero attention / 336 workloads, whose launches share kernel "
+            "names) are in `" + tag + "_bench_full_kernel_stats.csv`.\n\n")
     f.write("| kernel | calls | avg us | min us | max us | total ms | % |\n|---|---:|---:|---:|---:|---:|---:|\n")
     for r in rows:
         f.write(f"| `{r['Name'][:140]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                 f"{float(r['MaxNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['Percentage']):.2f} |\n")
+    tr = glob.glob(os.path.join(SRC, "keep/trace/*kernel_trace.csv"))
+    if tr:
+        d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+             for r in csv.DictReader(open(max(tr, key=os.path.getmtime))) if "remap_rows_kernel" in r["Kernel_Name"]]
+        d = [x for _, x in sorted(d)]
+        last = d[-prof["steps"]:]
+        alg = prof["roofline"]["algorithmic_bytes_per_launch"]
+        shutil.copy(max(tr, key=os.path.getmtime), os.path.join(DST, f"{tag}_bench_kernel_trace.csv"))
+        f.write(f"\nPer-dispatch durations of `remap_rows_kernel` from the kernel trace of the same run (`{tag}_bench_kernel_trace.csv`): all "
+                f"{len(d)} launches average {sum(d) / len(d):.1f} us; the LAST {len(last)} launches -- the ones `bench.py` times -- average "
+                f"**{sum(last) / len(last):.1f} us** (min {min(last):.1f}, max {max(last):.1f}) = {alg / (sum(last) / len(last) * 1e-6) / 8e12:.4f} of 8 TB/s; "
+                f"the first {len(d) - len(last)} are the untimed pre-conditioning and warm-up steps (the first launches of a process run slower).\n")
     f.write(f"\nbench.py's own HIP-event measurement in the same (profiled) process: ms_per_step {prof['ms_per_step']}, "
-            f"roofline {json.dumps(prof['roofline'])}, also_exact {json.dumps(prof.get('also_exact', {}).get('roofline'))}, "
-            f"also_chw {json.dumps(prof.get('also_chw', {}).get('roofline'))}, stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
+            f"roofline {json.dumps(prof['roofline'])}, "
+            f"stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
 
 def pmc(dirname, counter):
     vals = []
