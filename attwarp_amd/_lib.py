@@ -68,8 +68,10 @@ SIGNATURES = {
     "attwarp_axis_maps_from_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                   c_double, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_warp_step_fused": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                         c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                         c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+                                         c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_axis_maps_from_steps_t": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_resize_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "attwarp_remap_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_int, c_void_p]),

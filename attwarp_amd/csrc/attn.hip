@@ -31,9 +31,6 @@ template <> __device__ __forceinline__ __half nt_load<__half>(const __half* p) {
 template <> __device__ __forceinline__ __hip_bfloat16 nt_load<__hip_bfloat16>(const __hip_bfloat16* p) {
   return __builtin_bit_cast(__hip_bfloat16, __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(p)));
 }
-template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b evaluated in dtype T
-  return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
-}
 
 // One workgroup per (pseudo-)sample, any dtype / kv stride / slice length.  Each wave takes heads w, w+4, ...; lane l
 // owns tokens l, l+64, ... (NPL = ceil(ntok/64) values per head in registers).  Heads are processed HU at a time so

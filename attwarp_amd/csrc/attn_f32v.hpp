@@ -91,6 +91,23 @@ struct AttnStepArgsT {
   T* out;                  // [nb, ntok]
 };
 typedef AttnStepArgsT<float> AttnStepArgs;
+// the same arguments with the dtype as a run-time value (the fused step kernel switches on it, block uniform)
+struct AttnStepArgsAny {
+  const void* attn;
+  int dtype;               // ATTWARP_F32 / F16 / BF16
+  int heads;
+  int64_t sb, sh, row_off;
+  const int32_t* starts;
+  int starts_mod, max_start, ntok;
+  void* out;
+  template <typename T>
+  __device__ __forceinline__ AttnStepArgsT<T> as() const {
+    AttnStepArgsT<T> a;
+    a.attn = static_cast<const T*>(attn); a.heads = heads; a.sb = sb; a.sh = sh; a.row_off = row_off; a.starts = starts;
+    a.starts_mod = starts_mod; a.max_start = max_start; a.ntok = ntok; a.out = static_cast<T*>(out);
+    return a;
+  }
+};
 // LDS the block needs: (NT / 64) waves x NV*4*64 tokens, float32
 template <int NV>
 constexpr size_t attn_v4_lds_bytes() { return (size_t)(ATTN_NT / WAVE) * NV * 4 * WAVE * sizeof(float); }

@@ -70,11 +70,12 @@ __global__ __launch_bounds__(NT) void axis_maps_from_pdf_kernel(const float* __r
 
 // ---- A2 + A6 + A8 + A9 + A11 fused: per-step attention maps -> inverse maps, one launch (body: axis_blocks.hpp) ------
 // grid = (B, 2): y = 0 -> x axis, y = 1 -> y axis.
+template <typename ST>
 __global__ __launch_bounds__(NT) void axis_maps_from_steps_kernel(const StepsMapsArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
   __shared__ float tmp[64];
   __shared__ float pm[64];
-  axis_maps_from_steps_block<24>(a, blockIdx.x, blockIdx.y, smem_d, tmp, pm);
+  axis_maps_from_steps_block<24, ST>(a, blockIdx.x, blockIdx.y, smem_d, tmp, pm);
 }
 
 // ---- A7: safe_softmax over dim=1, MN/model.py:8-14 ---------------------------------------
@@ -226,21 +227,34 @@ extern "C" int attwarp_axis_maps_from_pdf(const float* px, const float* py, int 
   return check_launch("axis_maps_from_pdf_kernel");
 }
 
-extern "C" int attwarp_axis_maps_from_steps(const float* steps, int T, int B, int g, int W, int H, int W_out, int H_out,
-                                            const double* inv_x, const double* inv_y, float* map_x, float* map_y,
-                                            float* att_out, void* stream) {
+extern "C" int attwarp_axis_maps_from_steps_t(const void* steps, int dtype, int T, int B, int g, int W, int H, int W_out,
+                                              int H_out, const double* inv_x, const double* inv_y, float* map_x,
+                                              float* map_y, float* att_out, void* stream) {
   ATTWARP_REQUIRE(steps && inv_x && inv_y && map_x && map_y, "axis_maps_from_steps: null pointer");
   ATTWARP_REQUIRE(T > 0 && B > 0 && g > 0 && W > 0 && H > 0 && W_out > 0 && H_out > 0,
                   "axis_maps_from_steps: non-positive size");
+  ATTWARP_REQUIRE(dtype == ATTWARP_F32 || dtype == ATTWARP_F16 || dtype == ATTWARP_BF16,
+                  "axis_maps_from_steps: dtype must be F32, F16 or BF16 (got %d)", dtype);
   if (g > 64) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: grid side %d > 64", g);
   const int L = W > H ? W : H;
   if (L > 8192) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: max(W,H)=%d > 8192", L);
   if (B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_steps: B > 65535");
   StepsMapsArgs a;
-  a.steps = steps; a.T = T; a.B = B; a.g = g; a.W = W; a.H = H; a.W_out = W_out; a.H_out = H_out;
+  a.steps = steps; a.step_dtype = dtype; a.T = T; a.B = B; a.g = g; a.W = W; a.H = H; a.W_out = W_out; a.H_out = H_out;
   a.inv_x = inv_x; a.inv_y = inv_y; a.map_x = map_x; a.map_y = map_y; a.att_out = att_out;
-  hipLaunchKernelGGL(axis_maps_from_steps_kernel, dim3(B, 2), dim3(NT), steps_maps_lds_bytes(L, g), as_stream(stream), a);
+  const dim3 grid(B, 2), blk(NT);
+  const size_t lds = steps_maps_lds_bytes(L, g);
+  if (dtype == ATTWARP_F32) hipLaunchKernelGGL(axis_maps_from_steps_kernel<float>, grid, blk, lds, as_stream(stream), a);
+  else if (dtype == ATTWARP_F16) hipLaunchKernelGGL(axis_maps_from_steps_kernel<__half>, grid, blk, lds, as_stream(stream), a);
+  else hipLaunchKernelGGL(axis_maps_from_steps_kernel<__hip_bfloat16>, grid, blk, lds, as_stream(stream), a);
   return check_launch("axis_maps_from_steps_kernel");
+}
+
+extern "C" int attwarp_axis_maps_from_steps(const float* steps, int T, int B, int g, int W, int H, int W_out, int H_out,
+                                            const double* inv_x, const double* inv_y, float* map_x, float* map_y,
+                                            float* att_out, void* stream) {
+  return attwarp_axis_maps_from_steps_t(steps, ATTWARP_F32, T, B, g, W, H, W_out, H_out, inv_x, inv_y, map_x, map_y, att_out,
+                                        stream);
 }
 
 extern "C" int attwarp_safe_softmax(const float* logits, int B, int N, float eps, float* out, void* stream) {

@@ -143,7 +143,8 @@ __device__ void right_inverse_block(const float* y, int Lo, int L, const double*
 // g x g map (A6) -> right-inverse up-sample, clamp, CDF, inverse map (as axis_maps_from_pdf_kernel).
 // Bit-identical to running the stages one by one.  grid = (B, 2).
 struct StepsMapsArgs {
-  const float* steps;      // [T,B,g*g]
+  const void* steps;       // [T,B,g*g] in the attention dtype (float32 / float16 / bfloat16: what A1 wrote)
+  int step_dtype;          // ATTWARP_F32 / F16 / BF16
   int T, B, g, W, H, W_out, H_out;
   const double* inv_x;     // [g,g] cached inverse of A A^T + eps I for L = W
   const double* inv_y;     // ... for L = H
@@ -158,10 +159,13 @@ inline size_t steps_maps_lds_bytes(int L, int g) {
 // One 256-thread workgroup per (sample b, axis).  smem_d: steps_maps_lds_bytes(); tmp, pm: 64 floats of LDS each.
 // TC: steps of a token requested in one go (24: one memory round trip for T <= 24; the fused step kernel uses 8 to keep
 // its register allocation at the resample's)
-template <int TC>
+// ST: dtype of the step maps.  A2 (llava.py:409-411) runs in the model dtype: float64 accumulation in step order, ONE
+// rounding to ST, the division by T in ST (attn_finalize_kernel's arithmetic); everything after it is float32 as in
+// gt_marginals of the float() of that map.
+template <int TC, typename ST>
 __device__ __forceinline__ void axis_maps_from_steps_block(const StepsMapsArgs& a, int b, int axis, double* smem_d,
                                                            float* tmp, float* pm) {
-  const float* __restrict__ steps = a.steps;
+  const ST* __restrict__ steps = static_cast<const ST*>(a.steps);
   const int T = a.T, B = a.B, g = a.g;
   float* __restrict__ att_out = a.att_out;
   const int L = axis ? a.H : a.W, n_out = axis ? a.H_out : a.W_out, ntok = g * g;
@@ -195,11 +199,11 @@ __device__ __forceinline__ void axis_maps_from_steps_block(const StepsMapsArgs& 
 #pragma unroll
       for (int u = 0; u < TPT; ++u) acc[u] = 0.0;
       for (int t0 = 0; t0 < T; t0 += TC) {
-        float v[TPT][TC];
+        ST v[TPT][TC];
 #pragma unroll
         for (int u = 0; u < TPT; ++u) {
           const int i = i0 + threadIdx.x + NT * u;
-          const float* sp = steps + (size_t)b * ntok + min(i, ntok - 1);
+          const ST* sp = steps + (size_t)b * ntok + min(i, ntok - 1);
 #pragma unroll
           for (int j = 0; j < TC; ++j) v[u][j] = sp[(size_t)min(t0 + j, T - 1) * tstride];
         }
@@ -207,13 +211,13 @@ __device__ __forceinline__ void axis_maps_from_steps_block(const StepsMapsArgs& 
         for (int u = 0; u < TPT; ++u)
 #pragma unroll
           for (int j = 0; j < TC; ++j)
-            if (t0 + j < T) acc[u] += (double)v[u][j];
+            if (t0 + j < T) acc[u] += (double)to_f32<ST>(v[u][j]);
       }
 #pragma unroll
       for (int u = 0; u < TPT; ++u) {
         const int i = i0 + threadIdx.x + NT * u;
         if (i < ntok) {
-          const float m = (float)acc[u] / (float)T;
+          const float m = to_f32<ST>(div_t<ST>(from_f64<ST>(acc[u]), from_f32<ST>((float)T)));
           att[i] = m;
           if (att_out && axis == 0) att_out[(size_t)b * ntok + i] = m;
         }

@@ -113,6 +113,10 @@ template <> __device__ __forceinline__ __hip_bfloat16 from_f64<__hip_bfloat16>(d
   return __float2bfloat16(f64_to_f32_round_odd(v));
 }
 
+template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b evaluated in dtype T
+  return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- test / measurement overrides -----------------------------------------------

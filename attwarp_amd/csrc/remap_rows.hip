@@ -122,10 +122,10 @@ using namespace attwarp;
 
 extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
                                        int W_out, const float* map_x, const float* map_y, int mode,
-                                       const float* steps_in, int T, int g, const double* inv_x, const double* inv_y,
-                                       float* map_x_next, float* map_y_next,
-                                       const float* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
-                                       int starts_mod, int ntok, float* steps_out, void* stream) {
+                                       int attn_dtype, const void* steps_in, int T, int g, const double* inv_x,
+                                       const double* inv_y, float* map_x_next, float* map_y_next,
+                                       const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
+                                       int starts_mod, int ntok, void* steps_out, void* stream) {
   ATTWARP_REQUIRE(src && dst && map_x && map_y, "warp_step_fused: null image / map pointer");
   ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0, "warp_step_fused: non-positive size");
   ATTWARP_REQUIRE(layout == ATTWARP_HWC || layout == ATTWARP_CHW, "warp_step_fused: unknown layout %d", layout);
@@ -133,6 +133,9 @@ extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout,
   if (C > 4 || B > 65535 || H_out > 65535 || (long long)W_out * C > 2147483647LL / 2 ||
       (long long)H * W * C > 2147483647LL)
     return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: image shape outside the staged resample's limits");
+  if (steps_in || rows)
+    ATTWARP_REQUIRE(attn_dtype == ATTWARP_F32 || attn_dtype == ATTWARP_F16 || attn_dtype == ATTWARP_BF16,
+                    "warp_step_fused: attn_dtype must be F32, F16 or BF16 (got %d)", attn_dtype);
   StepExtra ex;
   memset(&ex, 0, sizeof(ex));
   if (steps_in) {      // M: per-step maps of the NEXT batch -> its inverse maps
@@ -140,7 +143,7 @@ extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout,
     ATTWARP_REQUIRE(T > 0 && g > 0, "warp_step_fused: non-positive T / g");
     ATTWARP_REQUIRE(map_x_next != map_x && map_y_next != map_y, "warp_step_fused: the next maps must not alias the current ones");
     if (g > 32 || std::max(W, H) > 8192) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: g > 32 or max(W,H) > 8192");
-    ex.maps.steps = steps_in; ex.maps.T = T; ex.maps.B = B; ex.maps.g = g; ex.maps.W = W; ex.maps.H = H;
+    ex.maps.steps = steps_in; ex.maps.step_dtype = attn_dtype; ex.maps.T = T; ex.maps.B = B; ex.maps.g = g; ex.maps.W = W; ex.maps.H = H;
     ex.maps.W_out = W_out; ex.maps.H_out = H_out; ex.maps.inv_x = inv_x; ex.maps.inv_y = inv_y;
     ex.maps.map_x = map_x_next; ex.maps.map_y = map_y_next; ex.maps.att_out = nullptr;
     ex.nM8 = (2 * B + 7) / 8;
@@ -152,7 +155,7 @@ extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout,
     ATTWARP_REQUIRE(steps_out != steps_in, "warp_step_fused: steps_out must not alias steps_in");
     if (ntok % 4 != 0 || ntok > 3 * 4 * WAVE)
       return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok must be a multiple of 4 and <= 768");
-    ex.attn.attn = rows; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
+    ex.attn.attn = rows; ex.attn.dtype = attn_dtype; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
     ex.attn.row_off = 0; ex.attn.starts = starts; ex.attn.starts_mod = starts_mod; ex.attn.max_start = kv_len - ntok;
     ex.attn.ntok = ntok; ex.attn.out = steps_out;
     ex.nA = n_rows;

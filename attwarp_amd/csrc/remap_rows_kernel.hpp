@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
 // resample chunks interleaved evenly instead: 0.064 / 0.216; 4 heads in flight per reduce wave: 0.069 / 0.233.
 struct StepExtra {
   StepsMapsArgs maps;      // nM8 * 8 >= 2 * maps.B blocks (0: no map work)
-  AttnStepArgs attn;       // nA reduce blocks (0: none)
+  AttnStepArgsAny attn;    // nA reduce blocks (0: none); its dtype is also the dtype of maps.steps
   int nM8, nA, nA8, nR8;   // blocks / 8 of the three ranges: ceil(2B / 8), ceil(nA / 8), ceil(nR / 8)
 };
 
@@ -468,13 +468,21 @@ __global__ __launch_bounds__(NT, step_min_waves(KI, KO, AFF)) void warp_step_ker
   __shared__ float s_tmp[64], s_pm[64];
   const int blk = blockIdx.x;
   if (blk < ex.nM8 * 8) {
-    if (blk < 2 * ex.maps.B)
-      axis_maps_from_steps_block<8>(ex.maps, blk >> 1, blk & 1, reinterpret_cast<double*>(smem), s_tmp, s_pm);
+    if (blk < 2 * ex.maps.B) {
+      double* sd = reinterpret_cast<double*>(smem);
+      if (ex.maps.step_dtype == ATTWARP_F32) axis_maps_from_steps_block<8, float>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
+      else if (ex.maps.step_dtype == ATTWARP_F16) axis_maps_from_steps_block<8, __half>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
+      else axis_maps_from_steps_block<8, __hip_bfloat16>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
+    }
     return;
   }
   const int j = blk - ex.nM8 * 8;
   if (j < ex.nA8 * 8) {
-    if (j < ex.nA) attn_reduce_v4_block<float, 3, 2>(ex.attn, j, smem);
+    if (j < ex.nA) {
+      if (ex.attn.dtype == ATTWARP_F32) attn_reduce_v4_block<float, 3, 2>(ex.attn.as<float>(), j, smem);
+      else if (ex.attn.dtype == ATTWARP_F16) attn_reduce_v4_block<__half, 3, 2>(ex.attn.as<__half>(), j, smem);
+      else attn_reduce_v4_block<__hip_bfloat16, 3, 2>(ex.attn.as<__hip_bfloat16>(), j, smem);
+    }
     return;
   }
   const int rb = j - ex.nA8 * 8;       // a multiple of 8 blocks precede: block % 8 still names the XCD

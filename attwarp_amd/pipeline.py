@@ -83,13 +83,14 @@ def warp_from_pdf(images: torch.Tensor, px: torch.Tensor, py: torch.Tensor, out_
 def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int],
                                    out_size: Optional[Tuple[int, int]] = None, eps: float = 1e-8,
                                    return_attention: bool = False, maps_out=None):
-    """Per-step aggregated maps [T,B,g*g] float32 (output of the A1 kernel) -> (map_x, map_y) in ONE
-    launch: mean over steps, marginals of the g x g map, PDF up-sample, CDF, inverse maps.
-    Bit-identical to attn_finalize -> gt_marginals -> axis_maps_from_pdf."""
+    """Per-step aggregated maps [T,B,g*g] in the attention dtype (output of the A1 kernel: float32 / float16 /
+    bfloat16) -> (map_x, map_y) in ONE launch: mean over steps (rounded in that dtype, llava.py:409-411), marginals of the
+    g x g map, PDF up-sample, CDF, inverse maps.  Bit-identical to attn_finalize -> float() -> gt_marginals ->
+    axis_maps_from_pdf."""
     dev = require_gpu(steps)
     s = steps.detach().contiguous()
-    if s.dtype != torch.float32:
-        raise TypeError("axis_maps_from_attention_steps: float32 step maps expected (use the staged path otherwise)")
+    if s.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+        raise TypeError("axis_maps_from_attention_steps: float32 / float16 / bfloat16 step maps expected")
     T, B, ntok = s.shape
     g = int(round(ntok ** 0.5))
     if g * g != ntok:
@@ -110,8 +111,8 @@ def axis_maps_from_attention_steps(steps: torch.Tensor, size_hw: Tuple[int, int]
                              "(the kernel writes dense [B,W_out] / [B,H_out] rows through the raw pointers)")
     att = torch.empty(B, ntok, device=dev, dtype=torch.float32) if return_attention else None
     with torch.cuda.device(dev):
-        call("attwarp_axis_maps_from_steps", ptr(s), T, B, g, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y), ptr(mx),
-             ptr(my), ptr(att), stream_ptr(dev))
+        call("attwarp_axis_maps_from_steps_t", ptr(s), _lib.dtype_id(s), T, B, g, W, H, W_out, H_out, ptr(inv_x), ptr(inv_y),
+             ptr(mx), ptr(my), ptr(att), stream_ptr(dev))
     return (mx, my, att) if return_attention else (mx, my)
 
 
@@ -130,19 +131,14 @@ def warp_from_attention_stack(images: torch.Tensor, rows: torch.Tensor, starts: 
                               channels_last=False, mode: str = "cv2", out: Optional[torch.Tensor] = None,
                               starts_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """images: batch on the GPU; rows [T,B,heads,kv] last-query attention rows; starts int32 [B].
-    Three launches for float32 attention: A1 (step maps) -> fused A2+A6+A8+A9+A11 (maps) -> A12 (warp)."""
+    Three launches: A1 (step maps) -> fused A2+A6+A8+A9+A11 (maps) -> A12 (warp), for attention in any of the three dtypes."""
     if channels_last:
         H, W = images.shape[1], images.shape[2]
     else:
         H, W = images.shape[2], images.shape[3]
-    if rows.dtype == torch.float32:
-        steps = attention_step_maps(rows, starts, ae.NUM_IMAGE_TOKENS, starts_tiled)
-        mx, my = axis_maps_from_attention_steps(steps, (H, W), out_size)
-    else:   # model-dtype (fp16 / bf16) attention: finalize rounds in that dtype, then the float32 chain
-        B = images.shape[0]
-        att = ae.attn_reduce_stack(rows, starts, ae.NUM_IMAGE_TOKENS).float().view(B, 1, GRID, GRID)
-        px, py = cu.gt_marginals(att)
-        mx, my = axis_maps_from_pdf(px, py, (H, W), out_size)
+    # any attention dtype (float32 / the model's float16 / bfloat16): A1 per step, then the fused A2 .. A11 launch
+    steps = attention_step_maps(rows, starts, ae.NUM_IMAGE_TOKENS, starts_tiled)
+    mx, my = axis_maps_from_attention_steps(steps, (H, W), out_size)
     return cu.remap_separable(images, mx, my, mode=mode, channels_last=channels_last, out=out)
 
 
@@ -288,8 +284,10 @@ class OverlappedWarp:
         dev = require_gpu(*self.images, *self.rows, starts)
         if not all(t.is_contiguous() for t in self.images + self.rows + [starts]):
             raise ValueError("OverlappedWarp: static input buffers must be contiguous (the graph holds raw pointers)")
-        if any(r.dtype != torch.float32 or r.dim() != 4 or r.shape != self.rows[0].shape for r in self.rows):
-            raise TypeError("OverlappedWarp: float32 attention rows [T,B,heads,kv] of one shape expected")
+        if any(r.dtype not in (torch.float32, torch.float16, torch.bfloat16) or r.dtype != self.rows[0].dtype or r.dim() != 4
+               or r.shape != self.rows[0].shape for r in self.rows):
+            raise TypeError("OverlappedWarp: attention rows [T,B,heads,kv] of one shape and one dtype (float32 / float16 / "
+                            "bfloat16) expected")
         if any(i.shape != self.images[0].shape or i.dtype != self.images[0].dtype for i in self.images):
             raise ValueError("OverlappedWarp: every image buffer of the ring must have the same shape and dtype")
         self.n = len(self.images)
@@ -320,7 +318,7 @@ class OverlappedWarp:
         self._inv = (_tables.right_inverse_inv(g, W, 1e-8, dev), _tables.right_inverse_inv(g, H, 1e-8, dev))
         if self.pattern in ("auto", "fused"):
             # one launch per step (attwarp_warp_step_fused) when the shapes are eligible: float32 images on the staged
-            # resample, float32 rows
+            # resample, attention rows in any of the three dtypes
             try:
                 if img0.dtype != torch.float32:
                     raise _lib.AttWarpError("fused step: float32 images only")
@@ -350,7 +348,7 @@ class OverlappedWarp:
         with torch.cuda.device(self._dev):
             call("attwarp_warp_step_fused", ptr(img), ptr(out), _lib.HWC if self.channels_last else _lib.CHW, B, C, H, W,
                  Ho, Wo, ptr(mx), ptr(my), _lib.MODE_IDS[self.mode],
-                 ptr(self.steps[c]), T, g, ptr(self._inv[0]), ptr(self._inv[1]), ptr(nx), ptr(ny),
+                 _lib.dtype_id(rows), ptr(self.steps[c]), T, g, ptr(self._inv[0]), ptr(self._inv[1]), ptr(nx), ptr(ny),
                  ptr(rows), T * B, heads, kv, ptr(self.starts_tiled), T * B, ae.NUM_IMAGE_TOKENS, ptr(self.steps[1 - c]),
                  stream_ptr(self._dev))
 

@@ -204,12 +204,21 @@ ATTWARP_API int attwarp_axis_maps_from_steps(const float* steps, int T, int B, i
                                  const double* inv_x, const double* inv_y, float* map_x, float* map_y,
                                  float* att_out, void* stream);
 
+/* the same for step maps in the model dtype (F32 / F16 / BF16): the mean over steps (A2) is accumulated in double,
+ * rounded ONCE to that dtype and divided by T in it, as attwarp_attn_finalize does; the rest is float32.  Equals
+ * attwarp_attn_finalize -> float() -> attwarp_gt_marginals -> attwarp_axis_maps_from_pdf bit for bit. */
+ATTWARP_API int attwarp_axis_maps_from_steps_t(const void* steps, int dtype, int T, int B, int g, int W, int H, int W_out,
+                                   int H_out, const double* inv_x, const double* inv_y, float* map_x, float* map_y,
+                                   float* att_out, void* stream);
+
 /* ---- one step of a STREAM of equally shaped batches in ONE launch (pipeline.OverlappedWarp; replaces the three
  * launches reduce -> maps -> resample of AGW/main_batched.py's per-batch chain when batches follow each other):
  *   R  the A12 resample of batch k      src [B,...] float32 + map_x/map_y (built by the previous step)  -> dst
  *   M  the maps of batch k+1            steps_in [T,B,g*g] (previous step's reduce) -> map_x_next / map_y_next
- *   A  the A1 reduce of batch k+2       rows [n_rows = T*B, heads, kv_len] float32, row j uses starts[j % starts_mod]
+ *   A  the A1 reduce of batch k+2       rows [n_rows = T*B, heads, kv_len], row j uses starts[j % starts_mod]
  *                                       -> steps_out [T*B, ntok]
+ * rows, steps_in and steps_out share attn_dtype (F32 / F16 / BF16: the model dtype, as the hook delivers them; A2's
+ * mean over steps is rounded in that dtype like llava.py:409-411);
  * as block ranges of one grid (map blocks first, then reduce and resample blocks interleaved in chunks of 8): no
  * launch boundary, no queue hand-off inside a step.  The three pieces work on different batches and must not alias
  * (steps_out != steps_in, map_*_next != map_*).  M (steps_in == NULL) and A (rows == NULL) are optional.  Same
@@ -218,10 +227,10 @@ ATTWARP_API int attwarp_axis_maps_from_steps(const float* steps, int T, int B, i
  * rows), ntok is not a multiple of 4 or > 768, or g > 32: use the three separate entry points then. */
 ATTWARP_API int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
                             int W_out, const float* map_x, const float* map_y, int mode,
-                            const float* steps_in, int T, int g, const double* inv_x, const double* inv_y,
-                            float* map_x_next, float* map_y_next,
-                            const float* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
-                            int starts_mod, int ntok, float* steps_out, void* stream);
+                            int attn_dtype, const void* steps_in, int T, int g, const double* inv_x,
+                            const double* inv_y, float* map_x_next, float* map_y_next,
+                            const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
+                            int starts_mod, int ntok, void* steps_out, void* stream);
 
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.

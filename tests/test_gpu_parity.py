@@ -1173,7 +1173,8 @@ def test_pipeline_attention_stack_end_to_end(dev):
     fmx2, fmy2 = pipeline.axis_maps_from_attention_steps(steps, (S, S), out_size=(150, 90))
     rx2, ry2 = O.maps_from_cdf(Fx, Fy, (150, 90))
     assert np.array_equal(N(fmx2), rx2) and np.array_equal(N(fmy2), ry2)
-    # fp16 attention goes through the staged path (rounding in the model dtype)
+    # fp16 attention: the same three launches, A2 rounded in the model dtype (vs the oracle chain A1+A2 in fp16 -> float
+    # -> marginals -> maps)
     out16 = pipeline.warp_from_attention_stack(T(img, dev), T(rows, dev).half(), T(starts, dev), channels_last=True)
     att16 = O.attn_reduce_stack(rows.astype(np.float16), starts).astype(np.float32).reshape(B, 1, 24, 24)
     p16x, p16y = O.gt_marginals(att16)
@@ -1978,10 +1979,13 @@ def test_remap_fuzz_shapes(dev):
         assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), tag
 
 
-@pytest.mark.parametrize("S,B,layout,mode", [(96, 5, "hwc", "cv2"), (336, 3, "hwc", "cv2"), (336, 2, "chw", "exact"),
-                                              (1024, 2, "hwc", "cv2"), (1024, 1, "hwc", "exact"), (1024, 1, "chw", "cv2"),
-                                              (512, 2, "hwc", "cv2"), (200, 3, "chw", "cv2")])
-def test_fused_step_equals_three_launches(dev, S, B, layout, mode):
+@pytest.mark.parametrize("S,B,layout,mode,adt", [(96, 5, "hwc", "cv2", torch.float32), (336, 3, "hwc", "cv2", torch.float32),
+                                                  (336, 2, "chw", "exact", torch.float32), (1024, 2, "hwc", "cv2", torch.float32),
+                                                  (1024, 1, "hwc", "exact", torch.float32), (1024, 1, "chw", "cv2", torch.float32),
+                                                  (512, 2, "hwc", "cv2", torch.float32), (200, 3, "chw", "cv2", torch.float32),
+                                                  (336, 3, "hwc", "cv2", torch.float16), (336, 2, "chw", "cv2", torch.bfloat16),
+                                                  (1024, 1, "hwc", "cv2", torch.float16), (96, 4, "hwc", "exact", torch.bfloat16)])
+def test_fused_step_equals_three_launches(dev, S, B, layout, mode, adt):
     """attwarp_warp_step_fused (resample of batch k + maps of batch k+1 + attention reduce of batch k+2 as block ranges
     of ONE launch) against the three separate entry points, bit for bit, on every staged resample family; and its
     argument checks."""
@@ -1990,9 +1994,10 @@ def test_fused_step_equals_three_launches(dev, S, B, layout, mode):
     T = 5
     cl = layout == "hwc"
     imgs = [torch.rand((B, S, S, 3) if cl else (B, 3, S, S), device=dev, generator=g) for _ in range(3)]
-    rws = [torch.softmax(torch.randn((T, B, 32, 640), device=dev, generator=g) * (1 + 2 * k), dim=-1) for k in range(3)]
+    rws = [torch.softmax(torch.randn((T, B, 32, 640), device=dev, generator=g) * (1 + 2 * k), dim=-1).to(adt) for k in range(3)]
     starts = (35 + torch.arange(B, device=dev) % 8).to(torch.int32)
     ow = pipeline.OverlappedWarp(imgs, rws, starts, channels_last=cl, mode=mode, pattern="fused")
+    assert ow.steps[0].dtype == adt
     assert ow.pattern == "fused"
     # one fused step by hand: R(0) with the maps of batch 0, M from the steps of batch 1, A on the rows of batch 2
     steps0 = pipeline.attention_step_maps(rws[0], starts)
@@ -2063,14 +2068,17 @@ def test_fused_step_argument_checks(dev):
     from attwarp_amd._lib import call, ptr, AttWarpError
     z = torch.zeros(64, device=dev)
     with pytest.raises(AttWarpError, match="null image"):
-        call("attwarp_warp_step_fused", None, ptr(z), 0, 1, 3, 4, 4, 4, 4, ptr(z), ptr(z), 1, None, 0, 0, None, None, None,
+        call("attwarp_warp_step_fused", None, ptr(z), 0, 1, 3, 4, 4, 4, 4, ptr(z), ptr(z), 1, 0, None, 0, 0, None, None, None,
              None, None, 0, 0, 0, None, 0, 0, None, None)
     with pytest.raises(AttWarpError, match="generic resample"):      # 5 floats per row: not a staged shape
-        call("attwarp_warp_step_fused", ptr(z), ptr(z), 0, 1, 1, 2, 5, 2, 5, ptr(z), ptr(z), 1, None, 0, 0, None, None, None,
+        call("attwarp_warp_step_fused", ptr(z), ptr(z), 0, 1, 1, 2, 5, 2, 5, ptr(z), ptr(z), 1, 0, None, 0, 0, None, None, None,
              None, None, 0, 0, 0, None, 0, 0, None, None)
     with pytest.raises(AttWarpError, match="multiple of 4"):
-        call("attwarp_warp_step_fused", ptr(z), ptr(z), 0, 1, 1, 2, 8, 2, 8, ptr(z), ptr(z), 1, None, 0, 0, None, None, None,
+        call("attwarp_warp_step_fused", ptr(z), ptr(z), 0, 1, 1, 2, 8, 2, 8, ptr(z), ptr(z), 1, 0, None, 0, 0, None, None, None,
              None, ptr(z), 1, 2, 30, ptr(z.int()), 1, 6, ptr(z), None)
+    with pytest.raises(AttWarpError, match="attn_dtype"):
+        call("attwarp_warp_step_fused", ptr(z), ptr(z), 0, 1, 1, 2, 8, 2, 8, ptr(z), ptr(z), 1, 3, None, 0, 0, None, None, None,
+             None, ptr(z), 1, 2, 30, ptr(z.int()), 1, 8, ptr(z), None)
 
 
 @pytest.mark.parametrize("pattern", ["fused", "dag", "join"])
