@@ -397,16 +397,22 @@ def time_overlapped(ow, K: int, W: int, D):
     return D.max_over_ranks(wall), wall
 
 
-def step_bytes(B: int, S: int) -> float:
+def step_bytes(B: int, S: int, attn_esize: int = 4) -> float:
     """Algorithmic bytes of one step: the resample's 2*S*S*3*4 per image + the attention rows the reduce
-    reads, T*heads*576*4 per image."""
-    return float(B) * (2.0 * S * S * 3 * 4 + T_STEPS * HEADS * NTOK * 4)
+    reads, T*heads*576*esize per image."""
+    return float(B) * (2.0 * S * S * 3 * 4 + T_STEPS * HEADS * NTOK * attn_esize)
 
 
-def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline):
+def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn_dtype=None):
     """configs[1] / configs[3]'s per-rank batch: the overlapped graph path over a ring of independent batches (>= 2 GiB,
-    every step streams from HBM) as the headline, the eager three-launch step with HIP events beside it."""
+    every step streams from HBM) as the headline, the eager three-launch step with HIP events beside it.
+    attn_dtype (torch.float16 / bfloat16): the attention rows in the model dtype LLaVA emits instead of float32."""
     st = Step(B, S, dev, seed=seed, mode=mode, layout=layout)
+    esize = 4
+    if attn_dtype is not None:
+        st.sets = [(img, rows.to(attn_dtype), out) for (img, rows, out) in st.sets]
+        st.img, st.rows, st.out = st.sets[0]
+        esize = 2
     for _ in range(5):
         st()
     ow = pipeline.OverlappedWarp([x[0] for x in st.sets], [x[1] for x in st.sets], st.starts,
@@ -420,7 +426,7 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline):
         same = same and bool(torch.equal(ow.outs[r], ref))
         del ref
     w_e, _ = time_steps(st, K, W, D)
-    sb = step_bytes(B, S)
+    sb = step_bytes(B, S, esize)
     ms = wall / K * 1e3
     res = {"ms_per_step": round(ms, 4), "images_per_s": round(B * K / wall, 1),
            "step_algorithmic_bytes": sb, "step_TBps": round(sb / (ms * 1e-3) / 1e12, 3),
@@ -674,6 +680,15 @@ def main():
             result[key] = res2
             del st2, ow2
             torch.cuda.empty_cache()
+        # the same per-rank batch with the attention rows in float16, the dtype LLaVA-1.5 emits (half the reduce's bytes)
+        B2, S2, cfg2 = WORKLOADS["336x256"]
+        res3, _, _, st3, ow3 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline,
+                                              attn_dtype=torch.float16)
+        result["also_336x256_fp16_attention"] = dict(
+            {"workload": f"batch-{B2} {S2}x{S2} per GPU, attention rows float16 (images float32), mode={args.mode}",
+             "value": res3["images_per_s"], "unit": "images/s", "steps": n2}, **res3)
+        del st3, ow3
+        torch.cuda.empty_cache()
 
     if rank == 0:
         print(json.dumps(result), flush=True)
