@@ -99,6 +99,22 @@ __device__ __forceinline__ float cv2_sum_pk(v2f p0 /* p00, p10 */, v2f p1 /* p01
   return fadd(fadd(fadd(s0.x, s1.x), s0.y), s1.y);
 }
 
+// Integer divisions of the per-workgroup prologue without the ~25-instruction run-time divide: the channel stride is
+// 1..4 (constant divisors: shifts / one multiply-high), the plane of a virtual-row element is found by comparison
+// (at most 4 planes).  The prologue is a third of the kernel's VALU instructions at 336x336x3.
+__device__ __forceinline__ unsigned div_small(unsigned r, int d) {
+  switch (d) {
+    case 1: return r;
+    case 2: return r >> 1;
+    case 3: return r / 3u;
+    case 4: return r >> 2;
+    default: return r / (unsigned)d;
+  }
+}
+__device__ __forceinline__ int plane_of(int e, int len) {     // e / len for e < 4 * len
+  return (e >= len) + (e >= 2 * len) + (e >= 3 * len);
+}
+
 struct RowsParams {
   const float* src;
   float* dst;
@@ -214,7 +230,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 #pragma unroll
     for (int k = 0; k < KO; ++k) {
       const int e = min(e0 + tid + NT * k, e1 - 1);
-      const int x = e / p.CS;
+      const int x = (int)div_small((unsigned)e, p.CS);
       const int c = e - x * p.CS;
       const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
       f0s[k] = tx.i0 * p.CS + c;
@@ -244,9 +260,9 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 #pragma unroll
   for (int k = 0; k < KO; ++k) {
     const int e = min(tid + NT * k, p.OVL - 1);
-    const int pl = HWC ? 0 : e / p.orow_len;
+    const int pl = HWC ? 0 : plane_of(e, p.orow_len);
     const int r = e - pl * p.orow_len;
-    const int x = r / p.CS;
+    const int x = (int)div_small((unsigned)r, p.CS);
     const int c = r - x * p.CS;
     const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
     const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;
@@ -259,7 +275,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 #pragma unroll
   for (int k = 0; k < KI; ++k) {
     const int f = min(tid + NT * k, p.VLV - 1) * 4;
-    const int pl = HWC ? 0 : f / p.row_len;
+    const int pl = HWC ? 0 : plane_of(f, p.row_len);
     goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
   }
   }
