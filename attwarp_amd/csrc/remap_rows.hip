@@ -6,7 +6,8 @@
 namespace attwarp {
 
 int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex) {
-  return launch_rows_mode<ATTWARP_EXACT, false, 1, 4>(p, tile_ko, st, ex);
+  if (ex) return launch_step_exact(p, tile_ko, st, ex);
+  return launch_rows_mode<ATTWARP_EXACT, false, 1, 4, false>(p, tile_ko, st, nullptr);
 }
 
 // Returns via *handled whether the fast path took the request.

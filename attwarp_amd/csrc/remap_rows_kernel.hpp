@@ -510,11 +510,14 @@ constexpr size_t rows_lds_bytes(int KI, int NT) {
   return (size_t)(RMAX + (SINGLE ? 1 : 2) * (MODE == ATTWARP_CV2 ? 2 : 1) * KI * NT * 4) * sizeof(float);
 }
 
-template <int NT, int KI, int KO, int MODE, bool SINGLE>
+// FUSED selects which kernel family a translation unit instantiates: the plain resample (remap_rows.hip,
+// remap_rows_cv2.hip) or the fused step (remap_step_exact.hip, remap_step_cv2.hip) -- four heavy translation units that
+// compile side by side instead of two twice as long.
+template <int NT, int KI, int KO, int MODE, bool SINGLE, bool FUSED>
 static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* ex) {
   size_t lds = rows_lds_bytes<MODE, SINGLE>(KI, NT) + (size_t)p.lds_pad;
   const dim3 t(NT);
-  if (ex) {        // the fused step (warp_step_kernel): map blocks, then chunks of 8 reduce / resample blocks
+  if constexpr (FUSED) {   // warp_step_kernel: map blocks, then the reduce blocks, then the resample blocks
     if (ex->nA > 0) lds = std::max(lds, attn_v4_lds_bytes<3>());
     if (ex->nM8 > 0) lds = std::max(lds, steps_maps_lds_bytes(std::max(ex->maps.W, ex->maps.H), ex->maps.g));
     const dim3 g((unsigned)((ex->nM8 + ex->nA8 + ex->nR8) * 8));
@@ -527,61 +530,68 @@ static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* e
     else
       hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, false, false, MODE, SINGLE>), g, t, lds, st, p, *ex);
     return check_launch("warp_step_kernel");
+  } else {
+    const dim3 g(p.nblocks);
+    if (p.NP == 1 && p.OVL == KO * NT)   // every (lane, k) is a distinct in-row element: affine store offsets
+      hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, true, false, MODE, SINGLE>), g, t, lds, st, p);
+    else if (p.NP == 1)
+      hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, false, false, MODE, SINGLE>), g, t, lds, st, p);
+    else if (p.OVL == KO * NT && p.orow_len % NT == 0)   // planar, every k-slice inside one plane
+      hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, true, false, MODE, SINGLE>), g, t, lds, st, p);
+    else
+      hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, false, false, MODE, SINGLE>), g, t, lds, st, p);
+    return check_launch("remap_rows_kernel");
   }
-  const dim3 g(p.nblocks);
-  if (p.NP == 1 && p.OVL == KO * NT)   // every (lane, k) is a distinct in-row element: affine store offsets
-    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, true, false, MODE, SINGLE>), g, t, lds, st, p);
-  else if (p.NP == 1)
-    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, true, false, false, MODE, SINGLE>), g, t, lds, st, p);
-  else if (p.OVL == KO * NT && p.orow_len % NT == 0)   // planar, every k-slice inside one plane
-    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, true, false, MODE, SINGLE>), g, t, lds, st, p);
-  else
-    hipLaunchKernelGGL((remap_rows_kernel<NT, KI, KO, false, false, false, MODE, SINGLE>), g, t, lds, st, p);
-  return check_launch("remap_rows_kernel");
 }
 
-template <int NT, int KI, int MODE, bool SINGLE>
+template <int NT, int KI, int MODE, bool SINGLE, bool FUSED>
 static int launch_rows_ki(const RowsParams& p, int ko, hipStream_t st, const StepExtra* ex) {
-  if (ko <= 4) return launch_rows_t<NT, KI, 4, MODE, SINGLE>(p, st, ex);
-  if (ko <= 8) return launch_rows_t<NT, KI, 8, MODE, SINGLE>(p, st, ex);
-  if (ko <= 12) return launch_rows_t<NT, KI, 12, MODE, SINGLE>(p, st, ex);
-  return launch_rows_t<NT, KI, 16, MODE, SINGLE>(p, st, ex);
+  if (ko <= 4) return launch_rows_t<NT, KI, 4, MODE, SINGLE, FUSED>(p, st, ex);
+  if (ko <= 8) return launch_rows_t<NT, KI, 8, MODE, SINGLE, FUSED>(p, st, ex);
+  if (ko <= 12) return launch_rows_t<NT, KI, 12, MODE, SINGLE, FUSED>(p, st, ex);
+  return launch_rows_t<NT, KI, 16, MODE, SINGLE, FUSED>(p, st, ex);
 }
 
 // all staged variants of one arithmetic mode; tile_ko != 0 selects the column-tiled kernel.
 // KIMIN..KIMAX bounds the float4-per-thread counts this instantiation serves (the CV2 kernel with two
 // [top | bottom] buffers needs 64 KB + of LDS at KI = 4, above the 64 KB a launch gets by default: KI = 4 runs
-// the SINGLE-buffer form there).  ex != nullptr: the fused step (not built for the column-tiled kernel).
-template <int MODE, bool SINGLE, int KIMIN, int KIMAX>
+// the SINGLE-buffer form there).  FUSED: the fused step (not built for the column-tiled kernel).
+template <int MODE, bool SINGLE, int KIMIN, int KIMAX, bool FUSED>
 static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex) {
   constexpr int NT = NT_BIG;
-  if (tile_ko != 0 && ex) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: rows wider than 4096 floats are not fused");
-  if (tile_ko == 8) {
-    if constexpr (KIMIN <= 3 && 3 <= KIMAX) {
-      const size_t lds = rows_lds_bytes<MODE, SINGLE>(3, NT) + (size_t)p.lds_pad;
-      hipLaunchKernelGGL((remap_rows_kernel<NT, 3, 8, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
-      return check_launch("remap_rows_kernel");
+  if constexpr (FUSED) {
+    if (tile_ko != 0) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: rows wider than 4096 floats are not fused");
+  } else {
+    if (tile_ko == 8) {
+      if constexpr (KIMIN <= 3 && 3 <= KIMAX) {
+        const size_t lds = rows_lds_bytes<MODE, SINGLE>(3, NT) + (size_t)p.lds_pad;
+        hipLaunchKernelGGL((remap_rows_kernel<NT, 3, 8, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+        return check_launch("remap_rows_kernel");
+      }
+      return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
     }
-    return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
-  }
-  if (tile_ko == 12) {
-    if constexpr (KIMIN <= 4 && 4 <= KIMAX) {
-      const size_t lds = rows_lds_bytes<MODE, SINGLE>(4, NT) + (size_t)p.lds_pad;
-      hipLaunchKernelGGL((remap_rows_kernel<NT, 4, 12, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
-      return check_launch("remap_rows_kernel");
+    if (tile_ko == 12) {
+      if constexpr (KIMIN <= 4 && 4 <= KIMAX) {
+        const size_t lds = rows_lds_bytes<MODE, SINGLE>(4, NT) + (size_t)p.lds_pad;
+        hipLaunchKernelGGL((remap_rows_kernel<NT, 4, 12, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+        return check_launch("remap_rows_kernel");
+      }
+      return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
     }
-    return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
   }
   const int ki = (p.VLV + NT - 1) / NT, ko = (p.OVL + NT - 1) / NT;
-  if constexpr (KIMIN <= 1 && 1 <= KIMAX) if (ki <= 1) return launch_rows_ki<NT, 1, MODE, SINGLE>(p, ko, st, ex);
-  if constexpr (KIMIN <= 2 && 2 <= KIMAX) if (ki == 2) return launch_rows_ki<NT, 2, MODE, SINGLE>(p, ko, st, ex);
-  if constexpr (KIMIN <= 3 && 3 <= KIMAX) if (ki == 3) return launch_rows_ki<NT, 3, MODE, SINGLE>(p, ko, st, ex);
-  if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE>(p, ko, st, ex);
+  if constexpr (KIMIN <= 1 && 1 <= KIMAX) if (ki <= 1) return launch_rows_ki<NT, 1, MODE, SINGLE, FUSED>(p, ko, st, ex);
+  if constexpr (KIMIN <= 2 && 2 <= KIMAX) if (ki == 2) return launch_rows_ki<NT, 2, MODE, SINGLE, FUSED>(p, ko, st, ex);
+  if constexpr (KIMIN <= 3 && 3 <= KIMAX) if (ki == 3) return launch_rows_ki<NT, 3, MODE, SINGLE, FUSED>(p, ko, st, ex);
+  if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE, FUSED>(p, ko, st, ex);
   return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: variant for %d float4 per thread not built", ki);
 }
 
-// defined in remap_rows.hip / remap_rows_cv2.hip
+// defined in remap_rows.hip / remap_rows_cv2.hip (plain resample; ex == nullptr) and remap_step_exact.hip /
+// remap_step_cv2.hip (the fused step; ex != nullptr)
 int launch_rows_exact(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
 int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
+int launch_step_exact(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
+int launch_step_cv2(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex);
 
 }  // namespace attwarp
