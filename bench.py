@@ -380,11 +380,24 @@ def overlapped_run(ow, K: int):
     ow.tail()
 
 
-def time_overlapped(ow, K: int, W: int, D):
+def time_overlapped(ow, K: int, W: int, D, prewarm_s: float = 0.0):
     """Graph path: one untimed pass of the same K steps (captures every graph the timed pass replays) + W further
     untimed steps, then exactly K steps between barrier + synchronize; no host call per kernel, no event records."""
     import torch
     overlapped_run(ow, K)
+    if prewarm_s > 0:
+        # device pre-conditioning, untimed and outside the contract's W warm-up steps (as PREWARM_STEPS of the 1024 workload):
+        # the first second of launches of a process runs ~7 % slower (clock ramp; 0.246 against 0.217-0.228 ms per step at
+        # B=256 336x336), which would only penalise a measurement that starts right after start-up
+        t_end = time.perf_counter() + prewarm_s
+        n_pre = 0
+        ow.reset(); ow.prime(); ow.prime2()
+        while time.perf_counter() < t_end:
+            ow.run(64)
+            n_pre += 64
+            torch.cuda.synchronize()
+        ow.tail()
+        time_overlapped.prewarm_steps = n_pre
     if W > 0:
         ow.reset(); ow.prime(); ow.prime2(); ow.run(W); ow.tail()
     D.barrier()
@@ -403,7 +416,10 @@ def step_bytes(B: int, S: int, attn_esize: int = 4) -> float:
     return float(B) * (2.0 * S * S * 3 * 4 + T_STEPS * HEADS * NTOK * attn_esize)
 
 
-def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn_dtype=None):
+PREWARM_SMALL_S = 0.5          # seconds of untimed graph replays before the warm-up steps of the 336 workloads
+
+
+def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn_dtype=None, prewarm_s=0.0):
     """configs[1] / configs[3]'s per-rank batch: the overlapped graph path over a ring of independent batches (>= 2 GiB,
     every step streams from HBM) as the headline, the eager three-launch step with HIP events beside it.
     attn_dtype (torch.float16 / bfloat16): the attention rows in the model dtype LLaVA emits instead of float32."""
@@ -417,7 +433,7 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn
         st()
     ow = pipeline.OverlappedWarp([x[0] for x in st.sets], [x[1] for x in st.sets], st.starts,
                                  channels_last=(layout == "hwc"), mode=mode)
-    wall, wall_local = time_overlapped(ow, K, W, D)
+    wall, wall_local = time_overlapped(ow, K, W, D, prewarm_s)
     # serial reference of every ring slot, AFTER the timed region: the overlapped outputs must equal it bit for bit
     same = True
     for r in range(min(ow.n, K)):                  # the slots the K timed steps wrote
@@ -543,7 +559,7 @@ def main():
         # configs[1] / configs[3]: the step is ~0.09-0.25 ms, so the timed loop is a HIP-graph replay with no host call
         # per kernel (the eager three-launch line with HIP events is attached as "also_eager")
         res, wall, wall_local, step, ow = small_workload(B, S, dev, 1234 + rank, args.mode, args.layout, args.steps,
-                                                         args.warmup, D, torch, pipeline)
+                                                         args.warmup, D, torch, pipeline, prewarm_s=PREWARM_SMALL_S)
         roof = res["eager"]["roofline"]
         roof["measured_in"] = "the eager pass right after the timed graph region (a graph replay has no per-kernel events)"
         extra = {"step_algorithmic_bytes": res["step_algorithmic_bytes"], "step_TBps": res["step_TBps"],
@@ -582,7 +598,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "prewarm_steps": 0 if small else PREWARM_STEPS,
+        "prewarm_steps": getattr(time_overlapped, "prewarm_steps", 0) if small else PREWARM_STEPS,
         "config": {"workload": workload_txt, "mode": args.mode, "batch_per_gpu": B, "image_size": S,
                    "layout": args.layout.upper(), "global_batch": world * B, "rotating_batches": nrot,
                    "sharding": "contiguous image blocks per rank, no data-path collective"},
