@@ -70,6 +70,9 @@ SIGNATURES = {
     "attwarp_warp_step_fused": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "attwarp_attn_reduce_and_maps": (c_int, [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
     "attwarp_axis_maps_from_steps_t": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_resize_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

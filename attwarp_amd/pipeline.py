@@ -274,8 +274,8 @@ class OverlappedWarp:
 
     def __init__(self, images, rows, starts: torch.Tensor, out_size=None, channels_last: bool = False,
                  mode: str = "cv2", pattern: str = "auto"):
-        if pattern not in ("auto", "fused", "dag", "join"):
-            raise ValueError("OverlappedWarp: pattern must be 'auto', 'fused', 'dag' or 'join'")
+        if pattern not in ("auto", "fused", "am", "dag", "join"):
+            raise ValueError("OverlappedWarp: pattern must be 'auto', 'fused', 'am', 'dag' or 'join'")
         self.pattern = pattern
         self.images = list(images) if isinstance(images, (list, tuple)) else [images]
         self.rows = list(rows) if isinstance(rows, (list, tuple)) else [rows]
@@ -316,6 +316,10 @@ class OverlappedWarp:
         torch.cuda.synchronize(dev)
         g = int(round(ae.NUM_IMAGE_TOKENS ** 0.5))
         self._inv = (_tables.right_inverse_inv(g, W, 1e-8, dev), _tables.right_inverse_inv(g, H, 1e-8, dev))
+        if self.pattern == "auto" and img0.dtype == torch.float32 and img0[0].numel() * 4 >= (4 << 20):
+            # large images (>= 4 MB each): the resample is > 90 % of a step and keeps its own launch (inside the fused launch it runs 2 %
+            # slower); the reduce and the latency-bound map construction share one (attwarp_attn_reduce_and_maps)
+            self.pattern = "am"
         if self.pattern in ("auto", "fused"):
             # one launch per step (attwarp_warp_step_fused) when the shapes are eligible: float32 images on the staged
             # resample, attention rows in any of the three dtypes
@@ -357,6 +361,24 @@ class OverlappedWarp:
         """Output buffer of the most recent step."""
         return self.outs[(self.k - 1) % self.n]
 
+    def _am_step(self, c, k):
+        """A(k+2) + M(k+1) as one launch, then R(k)."""
+        self._am_launch(c, k)
+        self._resample(c, k % self.n)
+
+    def _am_launch(self, c, k):
+        """A(k+2): rows[k+2] -> steps[1-c]  and  M(k+1): steps[c] -> maps[1-c]  as ONE launch."""
+        rows = self.rows[(k + 2) % self.n]
+        T, B, heads, kv = rows.shape
+        H, W = self.size_hw
+        Ho, Wo = (H, W) if self.out_size is None else self.out_size
+        g = int(round(ae.NUM_IMAGE_TOKENS ** 0.5))
+        nx, ny = self.maps[1 - c]
+        with torch.cuda.device(self._dev):
+            call("attwarp_attn_reduce_and_maps", _lib.dtype_id(rows), ptr(rows), T * B, heads, kv, ptr(self.starts_tiled), T * B,
+                 ae.NUM_IMAGE_TOKENS, ptr(self.steps[1 - c]), ptr(self.steps[c]), T, B, g, W, H, Wo, Ho, ptr(self._inv[0]),
+                 ptr(self._inv[1]), ptr(nx), ptr(ny), stream_ptr(self._dev))
+
     def _reduce(self, i, r):
         """A: rows[r] -> steps[i]"""
         T, B, heads, kv = self.rows[r].shape
@@ -384,9 +406,9 @@ class OverlappedWarp:
         main.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(main):
             with torch.cuda.graph(g, stream=main):
-                if self.pattern == "fused":
+                if self.pattern in ("fused", "am"):
                     for u in range(unroll):
-                        self._fused_step(c, k)
+                        (self._fused_step if self.pattern == "fused" else self._am_step)(c, k)
                         c ^= 1
                         k += 1
                 elif self.pattern == "dag":

@@ -233,6 +233,49 @@ def make_inputs(B: int, S: int, dev, seed: int, layout: str):
     return img, rows, starts
 
 
+class PipelinedStep:
+    """The 1024-class step of a batch STREAM, two launches with HIP events around the resample: the attention reduce of
+    the batch after next + the map construction of the next batch as ONE launch (attwarp_attn_reduce_and_maps), then the
+    resample of the current batch -- every step still runs exactly one reduce, one map construction and one resample;
+    the latency-bound map kernel and one launch boundary hide behind the reduce.  Same buffers as `Step` (one static
+    batch at this size: every batch of the stream is the same data), bit-identical output."""
+
+    def __init__(self, step):
+        import torch
+        from attwarp_amd import pipeline
+        self.torch, self.step = torch, step
+        self.ow = pipeline.OverlappedWarp([x[0] for x in step.sets], [x[1] for x in step.sets], step.starts,
+                                          channels_last=(step.layout == "hwc"), mode=step.mode, pattern="am")
+        self.ow.reset(); self.ow.prime(); self.ow.prime2()
+        self.events = []
+        self.B, self.S, self.mode, self.layout = step.B, step.S, step.mode, step.layout
+
+    def __call__(self, record: bool = False):
+        torch, ow = self.torch, self.ow
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record else None
+        rows = ow.rows[(ow.k + 2) % ow.n]
+        T, B, heads, kv = rows.shape
+        if record:
+            ev[0].record()
+        ow._am_launch(ow.cur, ow.k)
+        if record:
+            ev[1].record()
+        ow._resample(ow.cur, ow.k % ow.n)
+        if record:
+            ev[2].record()
+            self.events.append(ev)
+        ow.cur ^= 1
+        ow.k += 1
+        return ow.out
+
+    def remap_ms(self):
+        return [e[1].elapsed_time(e[2]) for e in self.events]
+
+    def stage_ms(self):
+        n = len(self.events)
+        return [sum(e[0].elapsed_time(e[1]) for e in self.events) / n, sum(e[1].elapsed_time(e[2]) for e in self.events) / n]
+
+
 class Step:
     """The hot-path step on static buffers, with HIP events around the dominant kernel."""
 
@@ -651,11 +694,27 @@ def main():
                                   else f"same batch as [B,S,S,3], mode={args.mode}",
                                   "value": round(B * args.steps / w3, 1), "unit": "images/s",
                                   "ms_per_step": round(w3 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+        # the step of a batch stream as TWO launches: reduce(k+2) + maps(k+1) in one, then the resample(k), eager with events
+        step.set_layout(args.layout)
+        ps = PipelinedStep(step)
+        for _ in range(5):
+            ps()
+        w6, _ = time_steps(ps, args.steps, args.warmup, D)
+        ref6 = pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
+                                                  channels_last=(args.layout == "hwc"), mode=args.mode)
+        result["also_pipelined"] = {"workload": "same batch as a stream: attention reduce of batch k+2 + map construction of batch k+1 in ONE "
+                                                "launch (attwarp_attn_reduce_and_maps), then the resample of batch k; eager, HIP events",
+                                    "value": round(B * args.steps / w6, 1), "unit": "images/s",
+                                    "ms_per_step": round(w6 / args.steps * 1e3, 4),
+                                    "stages_ms": [round(v, 4) for v in ps.stage_ms()],
+                                    "bit_identical_to_serial": bool(torch.equal(ps.ow.out, ref6)), "roofline": roofline_of(ps)}
+        del ps, ref6
+        torch.cuda.empty_cache()
         # the same step as ONE launch (attwarp_warp_step_fused through pipeline.OverlappedWarp): at this size it only
         # hides the map construction and two launch boundaries behind the resample
         step.set_layout(args.layout)
         ow = pipeline.OverlappedWarp([x[0] for x in step.sets], [x[1] for x in step.sets], step.starts,
-                                     channels_last=(args.layout == "hwc"), mode=args.mode)
+                                     channels_last=(args.layout == "hwc"), mode=args.mode, pattern="fused")
         w5, _ = time_overlapped(ow, args.steps, args.warmup, D)
         same = bool(torch.equal(ow.outs[0], pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
                                                                             channels_last=(args.layout == "hwc"), mode=args.mode)))

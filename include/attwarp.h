@@ -232,6 +232,16 @@ ATTWARP_API int attwarp_warp_step_fused(const float* src, float* dst, int layout
                             const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
                             int starts_mod, int ntok, void* steps_out, void* stream);
 
+/* ---- the attention reduce of batch k+2 and the map construction of batch k+1 of a batch stream in ONE launch (for
+ * large images, where the resample keeps its own launch): rows [n_rows = T*B, heads, kv_len] -> steps_out [T*B, ntok];
+ * steps_in [T,B,g*g] (the previous call's steps_out buffer of the other parity) -> map_x [B,W_out], map_y [B,H_out].
+ * One dtype (F32 / F16 / BF16) for rows and both step buffers; ntok == g*g.  Equals attwarp_attn_reduce_step +
+ * attwarp_axis_maps_from_steps_t bit for bit. */
+ATTWARP_API int attwarp_attn_reduce_and_maps(int attn_dtype, const void* rows, int n_rows, int heads, int kv_len,
+                                 const int32_t* starts, int starts_mod, int ntok, void* steps_out,
+                                 const void* steps_in, int T, int B, int g, int W, int H, int W_out, int H_out,
+                                 const double* inv_x, const double* inv_y, float* map_x, float* map_y, void* stream);
+
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.
  * ws: workspace of attwarp_axis_sums_workspace_bytes(B,h,w) bytes. */

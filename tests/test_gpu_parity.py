@@ -2064,6 +2064,32 @@ def test_remap_float64_pass_through(dev, mode):
     assert np.array_equal(N(hwc).transpose(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("adt", [torch.float32, torch.float16, torch.bfloat16])
+def test_attn_reduce_and_maps_equals_two_launches(dev, adt):
+    """attwarp_attn_reduce_and_maps (reduce of batch k+2 + maps of batch k+1 as one launch) == attn_reduce_step +
+    axis_maps_from_attention_steps, bit for bit, in every attention dtype; pattern auto picks it for large images."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, T, S = 3, 5, 128
+    imgs = [torch.rand((B, S, S, 3), device=dev, generator=g) for _ in range(3)]
+    rws = [torch.softmax(torch.randn((T, B, 32, 640), device=dev, generator=g) * (1 + k), dim=-1).to(adt) for k in range(3)]
+    starts = (35 + torch.arange(B, device=dev) % 8).to(torch.int32)
+    ow = pipeline.OverlappedWarp(imgs, rws, starts, channels_last=True, pattern="am")
+    steps1 = pipeline.attention_step_maps(rws[1], starts)
+    steps2 = pipeline.attention_step_maps(rws[2], starts)
+    m1 = pipeline.axis_maps_from_attention_steps(steps1, (S, S))
+    ow.steps[0].copy_(steps1); ow.steps[1].fill_(-1); ow.maps[1][0].fill_(-1); ow.maps[1][1].fill_(-1)
+    ow._am_launch(0, 0)
+    assert torch.equal(ow.steps[1], steps2) and torch.equal(ow.maps[1][0], m1[0]) and torch.equal(ow.maps[1][1], m1[1])
+    refs = [pipeline.warp_from_attention_stack(imgs[k], rws[k], starts, channels_last=True) for k in range(3)]
+    ow.reset(); ow.prime(); ow.prime2(); ow.run(9); ow.tail()
+    for r in range(3):
+        assert torch.equal(ow.outs[r], refs[r]), r
+    big = torch.rand((1, 1024, 1024, 3), device=dev)
+    assert pipeline.OverlappedWarp(big, rws[0][:, :1].contiguous(), starts[:1], channels_last=True).pattern == "am"
+    assert pipeline.OverlappedWarp(imgs[0], rws[0], starts, channels_last=True).pattern == "fused"
+
+
 def test_fused_step_argument_checks(dev):
     from attwarp_amd._lib import call, ptr, AttWarpError
     z = torch.zeros(64, device=dev)
@@ -2081,7 +2107,7 @@ def test_fused_step_argument_checks(dev):
              None, ptr(z), 1, 2, 30, ptr(z.int()), 1, 8, ptr(z), None)
 
 
-@pytest.mark.parametrize("pattern", ["fused", "dag", "join"])
+@pytest.mark.parametrize("pattern", ["fused", "am", "dag", "join"])
 def test_overlapped_warp_equals_serial(dev, pattern):
     """pipeline.OverlappedWarp (resample of batch k || maps of batch k+1 || attention reduce of batch k+2 as one fused
     launch per step, or as branches of one HIP graph): every step is bit-identical to warp_from_attention_stack on the
