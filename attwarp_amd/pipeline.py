@@ -250,13 +250,19 @@ def capture_step(fn, *args, warmup: int = 2):
 
 
 class OverlappedWarp:
-    """Steady-state form of ``warp_from_attention_stack`` for a stream of equally shaped batches: one HIP graph whose
-    THREE branches run side by side --
+    """Steady-state form of ``warp_from_attention_stack`` for a stream of equally shaped batches.  The three kernels of
+    a step belong to three different batches and are independent --
         R: the resample of batch k                      (HBM-bound, maps[c])
         M: the map construction of batch k+1            (latency-bound, steps[c] -> maps[1-c])
         A: the attention reduce of batch k+2            (a second bandwidth stream, rows -> steps[1-c])
-    -- instead of reduce -> maps -> resample back to back for every batch.  Buffers are static (graph replay); the
-    per-step maps and the per-step attention maps are double buffered.
+    -- so they need not run reduce -> maps -> resample back to back for every batch.  ``pattern``:
+        "fused": R | M | A as block ranges of ONE launch (attwarp_warp_step_fused; float32 images on the staged resample)
+        "am":    A + M as one launch (attwarp_attn_reduce_and_maps), then R on its own (images of >= 4 MB, where the
+                 resample is > 90 % of the step and runs best with its stand-alone dispatch; any image dtype)
+        "dag":   R and A on one stream, M on a side stream with exactly the edges the buffers need
+        "join":  three graph branches forked and joined in every step
+        "auto":  "am" for float32 images of >= 4 MB, else "fused" when eligible, else "dag".
+    Steps are replayed as HIP graphs over static buffers; the per-step maps and attention maps are double buffered.
 
     ``images`` / ``rows`` are either one static buffer each (the caller copies every batch in) or RINGS of n buffers
     (lists of equal length): batch k lives in ``images[k % n]`` / ``rows[k % n]`` and is warped into ``outs[k % n]``,
@@ -461,6 +467,15 @@ class OverlappedWarp:
         for _ in range(n):
             self.step()
         return self.out
+
+    def set_starts(self, starts: torch.Tensor):
+        """New first-image-token positions ([B] int32) for the batches reduced from now on: copied into the static
+        buffer the captured graphs read (stream ordered; the attention runs two batches ahead of the images, so a
+        stream whose prompts change per batch calls this before the step that reduces that batch)."""
+        if starts.shape != self.starts.shape or starts.dtype != self.starts.dtype or starts.device != self.starts.device:
+            raise ValueError("OverlappedWarp.set_starts: same shape, dtype and device as the starts given at construction")
+        self.starts.copy_(starts)
+        self.starts_tiled.copy_(starts.repeat(self.rows[0].shape[0]))
 
     def reset(self):
         """Back to ring position 0 / buffer set 0 (a new stream on the same static buffers; prime() again)."""

@@ -2159,6 +2159,22 @@ def test_overlapped_warp_equals_serial(dev, pattern):
         assert ow4.k == K
         for r in range(4):
             assert torch.equal(ow4.outs[r], refs[r]), (K, r)
+    # prompts of another length from batch 2 on: set_starts before the step that reduces that batch
+    starts_b = (starts + 5).contiguous()
+    st = starts.clone()
+    ow5 = OW(img, rows, st, channels_last=True)
+    rows.copy_(rws[0]); ow5.prime()
+    rows.copy_(rws[1]); ow5.prime2()
+    for k in range(4):
+        img.copy_(imgs[k])
+        if k + 2 < 4:
+            ow5.set_starts(starts_b)
+            rows.copy_(rws[k + 2])
+        out = ow5.step()
+        ref = refs[k] if k < 2 else pipeline.warp_from_attention_stack(imgs[k], rws[k], starts_b, channels_last=True)
+        assert torch.equal(out, ref), k
+    with pytest.raises(ValueError):
+        ow5.set_starts(starts_b[:-1])
     with pytest.raises(ValueError):
         OW(imgs[0].permute(0, 2, 1, 3), rws[0], starts, channels_last=True)
     steps = pipeline.attention_step_maps(rws[0], starts)

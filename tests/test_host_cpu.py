@@ -81,6 +81,43 @@ def test_c_abi_argument_validation_without_gpu(lib):
     assert lib.attwarp_axis_sums_workspace_bytes(2, 3, 5) == 2 * 8 * 8
 
 
+def test_stream_step_abi_validation_without_gpu(lib):
+    """The two stream-step entry points (attwarp_attn_reduce_and_maps, attwarp_warp_step_fused) validate before they enqueue."""
+    import ctypes
+    p = ctypes.cast(ctypes.create_string_buffer(1 << 16), ctypes.c_void_p)
+    q = ctypes.c_void_p(p.value + 4096)
+    am = lib.attwarp_attn_reduce_and_maps
+    ok = dict(attn_dtype=0, rows=p, n_rows=2, heads=4, kv_len=640, starts=p, starts_mod=2, ntok=576, steps_out=p, steps_in=q,
+              T=1, B=2, g=24, W=64, H=64, W_out=64, H_out=64, inv_x=p, inv_y=p, map_x=p, map_y=p, stream=None)
+    def call(**kw):
+        a = dict(ok, **kw)
+        return am(*[a[k] for k in ok])
+    assert call(rows=None) == -1 and b"null pointer" in lib.attwarp_last_error()
+    assert call(attn_dtype=3) == -1                      # uint8 attention
+    assert call(kv_len=500) == -1                        # ntok > kv_len
+    assert call(steps_in=p) == -1 and b"alias" in lib.attwarp_last_error()
+    assert call(ntok=572) == -2                          # ntok != g*g
+    assert call(g=40, ntok=1600, kv_len=2000) == -2
+    assert call(W=9000) == -2
+    assert call(B=0) == -1
+    fused = lib.attwarp_warp_step_fused
+    # (src, dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, attn_dtype, steps_in, T, g, inv_x, inv_y, map_x_next,
+    #  map_y_next, rows, n_rows, heads, kv_len, starts, starts_mod, ntok, steps_out, stream)
+    base = [p, q, 0, 2, 3, 64, 64, 64, 64, p, p, 1, 0, p, 1, 24, p, p, q, q, p, 2, 4, 640, p, 2, 576, q, None]
+    def fcall(**kw):
+        names = ["src", "dst", "layout", "B", "C", "H", "W", "H_out", "W_out", "map_x", "map_y", "mode", "attn_dtype", "steps_in",
+                 "T", "g", "inv_x", "inv_y", "map_x_next", "map_y_next", "rows", "n_rows", "heads", "kv_len", "starts",
+                 "starts_mod", "ntok", "steps_out", "stream"]
+        a = dict(zip(names, base)); a.update(kw)
+        return fused(*[a[k] for k in names])
+    assert fcall(src=None) == -1
+    assert fcall(mode=7) == -1
+    assert fcall(attn_dtype=3) == -1
+    assert fcall(steps_out=p) == -1                      # aliases steps_in
+    assert fcall(map_x_next=p) == -1                     # aliases the maps being read
+    assert fcall(kv_len=100) == -1
+
+
 def test_probe_abi_validation_without_gpu(lib):
     import ctypes
     p = ctypes.cast(ctypes.create_string_buffer(4096), ctypes.c_void_p)
