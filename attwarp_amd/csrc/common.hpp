@@ -142,6 +142,7 @@ enum TuneKey {
   TUNE_REMAP_CPW,           // row blocks per workgroup of the float32 staged resample (strided inside the image)
   TUNE_REMAP_SKEW,          // XCD x starts x * skew blocks into its contiguous range of row blocks
   TUNE_ATTN_HU,             // heads in flight per wave of the four-tokens-per-lane attention reduce (1, 2, 4, 8)
+  TUNE_U8_AHEAD,            // integer uint8 resample: output rows whose source rows are requested ahead (1, 2, 4)
   TUNE_COUNT
 };
 #ifdef ATTWARP_TUNING

@@ -82,6 +82,7 @@ struct Params {
   long long img_stride, plane_stride, oimg_stride, oplane_stride;
   int R, nblk, nblocks;
   int wpi;   // integer cv2 kernel: workgroups per image; workgroup j owns row blocks j, j + wpi, ... (else == nblk)
+  int grp;   // integer cv2 kernel, block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g
   int ntiles;              // TILED: column tiles per row (each KO*NT output bytes), else 1
   int map_div;             // maps belong to image b / map_div (planes of a planar image dispatched as images)
 };
@@ -340,7 +341,7 @@ static int launch_ko(const Params& p, hipStream_t st) {
 // Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
 constexpr int U8I_VLP = 4096 + 16;      // u16 elements per LDS row buffer: rows of <= 4096 bytes + one pixel of slack
 
-template <int KI, int KD, bool HWC>
+template <int KI, int KD, bool HWC, int PD>
 __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* s_my = smem;                                               // RMAX
@@ -350,13 +351,20 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   uint16_t* vrow1 = vrow0 + U8I_VLP;
   const int tid = threadIdx.x;
   int bid = blockIdx.x;
-  {
+  {     // block order, as in remap_rows_kernel.hpp
     const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    if (p.grp == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    else if (p.grp >= 2) {
+      const int g = p.grp, per = 8 * g, grp = idx / g, within = idx - grp * g, cand = grp * per + xcd * g + within;
+      bid = cand < (n / per) * per ? cand : bid;
+    }
   }
   const int b = bid / p.wpi, rb0 = bid - b * p.wpi;
-  const uint8_t* src_b = p.src + (long long)b * p.img_stride;
-  uint8_t* dst_b = p.dst + (long long)b * p.oimg_stride;
+  // per-image buffer descriptors (block uniform; images are < 2 GiB: plane_stride * NP is checked by the host)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(p.src + (long long)b * p.img_stride), 0, (int)p.img_stride, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)b * p.oimg_stride, 0,
+                                                                        (int)p.oimg_stride, 0x00020000);
 
   // source dwords this thread owns (clamped: padding lanes repeat the last dword)
   unsigned goff[KI];                // byte offset inside the image (row 0): unsigned, so the loads take the SGPR-base form
@@ -381,7 +389,10 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
     // pairs (0,2) and (1,3) of a source dword; no re-interleaving).  (Swapping the two dwords of a group in every other
     // 64-dword window, so that lanes l and l + 32 of a slope-1 gather use different banks, was measured: no effect --
     // the kernel is bound by VALU issue -- and cost two selects per source dword; taken out.)
-    auto lds_off = [](unsigned e) -> unsigned { return 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
+    // t0 / t1 hold ABSOLUTE LDS addresses (of the tap in row buffer 0): as offsets from the buffer pointer every one of
+    // the 8 reads per output dword paid a v_add_u32 with the (link-time) base of the dynamic LDS block.
+    const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)vrow0;
+    auto lds_off = [vbase](unsigned e) -> unsigned { return vbase + 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
 #pragma unroll
     for (int k = 0; k < KD; ++k) {
       const int d = min(tid + NT * k, ndo - 1);
@@ -400,12 +411,15 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
         const unsigned e1 = (i0 == i1) ? e0 : (unsigned)(pl * p.row_len + i1 * p.CS + c);
         t0[k][j] = lds_off(e0);
         t1[k][j] = lds_off(e1);
+        // opaque, or address-mode sinking moves the "+ base" back in front of every read of the row loop
+        asm volatile("" : "+v"(t0[k][j]), "+v"(t1[k][j]));
         wpk[k][j] = (32u - kx) | (kx << 16);
       }
     }
   }
 
   typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
   auto row_taps = [&](float m, int& i0, int& i1, unsigned& ky) {
     const int q = cv_round_q5(m);
     const int i = q >> 5;
@@ -414,31 +428,33 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
     ky = (unsigned)(q & 31);
   };
   int ci0, ci1;
-  unsigned cky;
-  uint32_t A[KI], C[KI];
+  // PD register sets: the two source rows of output row q sit in set q % PD, requested PD rows ahead
+  unsigned ky[PD];                  // their vertical fractions
+  uint32_t A[PD][KI], C[PD][KI];
   int y0 = 0, nrows = 0;
-#define ATTWARP_U8I_FETCH()                                                                            \
+  /* buffer loads / stores: image base in an SGPR descriptor, row offset in the scalar offset, the thread's dword in the
+     32-bit vector offset -- no per-access 64-bit address arithmetic (a v_lshl_add_u64 per load and store before) */
+#define ATTWARP_U8I_FETCH(AX, CX)                                                                      \
   {                                                                                                    \
-    const uint8_t* ra_ = src_b + (long long)ci0 * p.row_len;   /* block uniform: SGPR pair */           \
-    const uint8_t* rc_ = src_b + (long long)ci1 * p.row_len;                                            \
+    const int ra_ = ci0 * p.row_len, rc_ = ci1 * p.row_len;      /* block uniform: SGPRs */              \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
-      A[k] = *reinterpret_cast<const uint32_t*>(ra_ + goff[k]);                                         \
-      C[k] = *reinterpret_cast<const uint32_t*>(rc_ + goff[k]);                                         \
+      AX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], ra_, 0);                         \
+      CX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], rc_, 0);                         \
     }                                                                                                  \
   }
-  /* Horizontal pass: (32 - kx) * v0 + kx * v1 + 512 is one v_dot2_u32_u16 on the tap pair (24 VALU instructions per     \
-     output dword, 30 with the scalar form of round 2).  Measured and dropped: both taps into one register with          \
-     ds_read_u16_d16 / _d16_hi -- on this part (SRAM ECC) a d16 load clears the other half instead of preserving it -- \
-     and, in any form, fewer VALU instructions: 139 -> 80 per row and thread left the time where it was (347 us at       \
-     1024 -> 1024 B=256): the kernel is not bound by VALU issue alone but by VALU + 8 LDS gathers per output dword (47 % \
-     of the LDS cycles bank conflicts on maps that are not near identity, profiles/round3_chain_pmc.txt) + HBM. */      \
-#define ATTWARP_U8I_ROW(q_, vbuf)                                                                \
+  /* One output row.  Its two source rows were requested PD rows ahead (a workgroup's own row takes about a microsecond
+     with eight of them sharing a CU, less than the loaded HBM latency: with PD = 1 the kernel waits for memory in
+     every row); the vertical pass writes LDS row buffer q & 1, one barrier, the horizontal pass gathers from it.
+     Horizontal pass: (32 - kx) * v0 + kx * v1 + 512 is one v_dot2_u32_u16 on the tap pair.  Measured and dropped: both
+     taps into one register with ds_read_u16_d16 / _d16_hi -- on this part (SRAM ECC) a d16 load clears the other half
+     instead of preserving it. */
+#define ATTWARP_U8I_ROW(q_, vbuf, VOFF, AX, CX, KY)                                                    \
   {                                                                                                    \
-    const unsigned w1_ = cky, w0_ = 32u - cky;                                                         \
+    const unsigned w1_ = KY, w0_ = 32u - KY;                                                           \
     const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
-      const uint32_t a02_ = A[k] & 0x00ff00ffu, a13_ = (A[k] >> 8) & 0x00ff00ffu;                        \
-      const uint32_t c02_ = C[k] & 0x00ff00ffu, c13_ = (C[k] >> 8) & 0x00ff00ffu;                        \
+      const uint32_t a02_ = AX[k] & 0x00ff00ffu, a13_ = (AX[k] >> 8) & 0x00ff00ffu;                      \
+      const uint32_t c02_ = CX[k] & 0x00ff00ffu, c13_ = (CX[k] >> 8) & 0x00ff00ffu;                      \
       const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
       const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
       uint2 st_;                                                                                       \
@@ -446,18 +462,17 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
       st_.y = __builtin_bit_cast(uint32_t, v13_);                                                      \
       *reinterpret_cast<uint2*>((vbuf) + voff[k]) = st_;                                               \
     }                                                                                                  \
-    if ((q_) + 1 < nrows) { /* fetch the next output row's two source rows now */                      \
-      row_taps(s_my[(q_) + 1], ci0, ci1, cky);                                                         \
-      ATTWARP_U8I_FETCH()                                                                              \
+    if ((q_) + PD < nrows) { /* this register set is free: request the rows of output row q + PD */   \
+      row_taps(s_my[(q_) + PD], ci0, ci1, KY);                                                         \
+      ATTWARP_U8I_FETCH(AX, CX)                                                                        \
     }                                                                                                  \
     __syncthreads();                                                                                   \
-    uint8_t* orow_ = dst_b + (long long)(y0 + (q_)) * p.orow_len;                                       \
-    const char* vb_ = reinterpret_cast<const char*>(vbuf);                                             \
+    const int orow_ = (y0 + (q_)) * p.orow_len;                                                        \
     _Pragma("unroll") for (int k = 0; k < KD; ++k) {                                                    \
       unsigned v0_[4], v1_[4];                                                                         \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
-        v0_[j] = *reinterpret_cast<const uint16_t*>(vb_ + t0[k][j]);                                   \
-        v1_[j] = *reinterpret_cast<const uint16_t*>(vb_ + t1[k][j]);                                   \
+        v0_[j] = *(lds_cu16*)(uintptr_t)(t0[k][j] + (VOFF));                                           \
+        v1_[j] = *(lds_cu16*)(uintptr_t)(t1[k][j] + (VOFF));                                           \
       }                                                                                                \
       unsigned o_ = 0;                                                                                 \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {   /* (32 - kx) * v0 + kx * v1 + 512: one v_dot2_u32_u16 */ \
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
         const unsigned in_ = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u, false); \
         o_ |= (in_ >> 10) << (8 * j);                                                                  \
       }                                                                                                \
-      if (tid + NT * k < (p.OVL >> 2)) *reinterpret_cast<uint32_t*>(orow_ + soff[k]) = o_;             \
+      if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, 0); \
     }                                                                                                  \
   }
   // Row blocks of this workgroup: rb0, rb0 + wpi, ... -- the column-tap prologue above (a cvRound and two integer
@@ -477,39 +492,60 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
     if (rb != rb0) __syncthreads();          // the previous block's last gather is done with s_my and the row buffers
     if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
     __syncthreads();
-    row_taps(s_my[0], ci0, ci1, cky);
-    ATTWARP_U8I_FETCH()
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+      if (u < nrows) {
+        row_taps(s_my[u], ci0, ci1, ky[u]);
+        ATTWARP_U8I_FETCH(A[u], C[u])
+      }
     int q = 0;
-    for (; q + 1 < nrows; q += 2) {
-      ATTWARP_U8I_ROW(q, vrow0)
-      ATTWARP_U8I_ROW(q + 1, vrow1)
+    for (; q + 3 < nrows; q += 4) {          // unrolled by 4: LDS buffer q & 1 and register set q % PD are compile-time
+      ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
+      ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
+      ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
+      ATTWARP_U8I_ROW(q + 3, vrow1, 2u * U8I_VLP, A[3 % PD], C[3 % PD], ky[3 % PD])
     }
-    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0)
+    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
+    if (q + 1 < nrows) ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
+    if (q + 2 < nrows) ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
   }
 #undef ATTWARP_U8I_ROW
 #undef ATTWARP_U8I_FETCH
 }
 
-template <int KI>
+template <int KI, int PD>
 static int launch_u8i_ki(const Params& p, hipStream_t st) {
   const size_t lds = (size_t)RMAX * sizeof(float) + 2 * (size_t)U8I_VLP * sizeof(uint16_t);
   const int kd = ((p.OVL >> 2) + NT - 1) / NT;
   const dim3 g(p.nblocks), t(NT);
 #define ATTWARP_U8I_LAUNCH(KD)                                                                              \
-  if (p.NP == 1) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true>), g, t, lds, st, p);                \
-  else hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, false>), g, t, lds, st, p)
+  if (p.NP == 1) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true, PD>), g, t, lds, st, p);            \
+  else hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, false, PD>), g, t, lds, st, p)
   if (kd <= 1) { ATTWARP_U8I_LAUNCH(1); } else if (kd == 2) { ATTWARP_U8I_LAUNCH(2); }
   else if (kd == 3) { ATTWARP_U8I_LAUNCH(3); } else { ATTWARP_U8I_LAUNCH(4); }
 #undef ATTWARP_U8I_LAUNCH
   return check_launch("remap_rows_u8i_kernel");
 }
+// Rows requested ahead.  Measured on MI355X, one process cycling the variants (tools/u8_ahead.py): rows of <= 2 KB
+// (336x3: 1 KB) want 4 -- B=256 336 -> 500: 113.6 us with 1 row ahead, 103.9 with 2, 94.6 with 4; planar 336 -> 336:
+// 53.5 / 51.2 / 48.9 -- rows of 3 KB (1024x3) 2: 1024 -> 500 161.8 / 153.8 / 153.0 at B=256 but 42.6 / 41.5 / 44.4 at B=64;
+// 1024 -> 1024 is the same with all three (it follows the lease: 308 - 357 us).
+template <int KI>
+static int launch_u8i_depth(const Params& p, hipStream_t st) {
+#ifdef ATTWARP_TUNING
+  if (tune(TUNE_U8_AHEAD) == 1) return launch_u8i_ki<KI, 1>(p, st);
+  if (tune(TUNE_U8_AHEAD) == 2) return launch_u8i_ki<KI, 2>(p, st);
+  if (tune(TUNE_U8_AHEAD) == 4) return launch_u8i_ki<KI, 4>(p, st);
+#endif
+  return launch_u8i_ki<KI, (KI <= 2 ? 4 : 2)>(p, st);
+}
 static int launch_u8i(const Params& p, hipStream_t st) {
   const int ki = ((p.VL >> 2) + NT - 1) / NT;
   switch (ki) {
-    case 1: return launch_u8i_ki<1>(p, st);
-    case 2: return launch_u8i_ki<2>(p, st);
-    case 3: return launch_u8i_ki<3>(p, st);
-    default: return launch_u8i_ki<4>(p, st);
+    case 1: return launch_u8i_depth<1>(p, st);
+    case 2: return launch_u8i_depth<2>(p, st);
+    case 3: return launch_u8i_depth<3>(p, st);
+    default: return launch_u8i_depth<4>(p, st);
   }
 }
 
@@ -550,6 +586,7 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
     return ATTWARP_OK;
   p.map_div = 1;
   p.ntiles = 1;
+  p.grp = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : 0;
   // up to 4096 bytes per staged row (16-bit LDS offsets); wider rows run in column tiles, planar ones plane by plane
   const bool tiled = VL > 4096 || OVL > 4096;
   if (tiled) {
@@ -582,7 +619,9 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.R = R;
   p.nblk = (Ho + R - 1) / R;
   p.wpi = p.nblk;
-  const bool integer_form = mode == ATTWARP_CV2 && !tiled && tune(TUNE_REMAP_VARIANT) != 2;
+  // (the integer kernel addresses an image through 32-bit buffer offsets)
+  const bool integer_form = mode == ATTWARP_CV2 && !tiled && tune(TUNE_REMAP_VARIANT) != 2 &&
+                            p.img_stride <= 2147483647LL && p.oimg_stride <= 2147483647LL;
   if (integer_form) {
     // Large rows that are not strongly minified: smaller row blocks, several per workgroup (the column-tap prologue is
     // still paid once per 64 rows, the rows in flight form a compact window).  Measured on MI355X, B=256 1024 -> 1024

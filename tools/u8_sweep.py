@@ -18,10 +18,11 @@ for (B, S, So, layout, kind) in [(256, 1024, 1024, "hwc", "uniform"), (256, 1024
     mx, my = pipeline.axis_maps_from_pdf(px, px, (S, S), (So, So))
     ref = cu.remap_separable(img8, mx, my, mode="cv2", channels_last=(layout == "hwc"))
     res = []
-    for R, c in [(-1, -1), (32, 2), (16, 2), (16, 4), (8, 2), (8, 4), (8, 8), (4, 4), (4, 8), (4, 16), (6, 4), (12, 2)]:
-        with _lib.debug_override(remap_rows=R, remap_cpw=c):
+    G = [int(a[1:]) for a in sys.argv[1:] if a.startswith("g")] or [-1]
+    for R, c, g in [(R, c, g) for g in G for (R, c) in [(-1, -1), (32, 2), (16, 2), (16, 4), (8, 2), (8, 4), (8, 8), (4, 4), (4, 8), (6, 4), (12, 2)]]:
+        with _lib.debug_override(remap_rows=R, remap_cpw=c, remap_noswz=g):
             out = cu.remap_separable(img8, mx, my, mode="cv2", channels_last=(layout == "hwc"))
             assert torch.equal(out, ref), (R, c)
             ms = t(lambda: cu.remap_separable(img8, mx, my, mode="cv2", channels_last=(layout == "hwc"), out=out))
-        res.append(f"R{R}c{c} {ms*1e3:.1f}")
+        res.append(f"R{R}c{c}g{g} {ms*1e3:.1f}")
     print(f"u8 cv2 {layout} {kind} B={B} {S}->{So}: " + "  ".join(res) + f"   [{B*(S*S*3+So*So*3)/1e6:.0f} MB]", flush=True)
