@@ -10,6 +10,7 @@
 //   head mean four partial sums P_w over heads w, w+4, w+8, ... (ascending), then ((0 + P_0) + P_1) + P_2) + P_3.
 // Every value crossing a reference op boundary is rounded to the model dtype T as before.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace attwarp {
@@ -119,7 +120,9 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
   constexpr int NT = ATTN_NT, PW = NV * 4 * WAVE, NW = NT / WAVE;
   const int heads = a.heads, ntok = a.ntok;
   const int64_t sh = a.sh;
-  const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+  // the wave index as a scalar: head offsets and row pointers then live in SGPRs (as a vector value every head paid a
+  // 64-bit multiply and four 64-bit adds for its three load addresses)
+  const int lane = threadIdx.x & (WAVE - 1), wid = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   // a slice start outside [0, kv_len - ntok] is clamped for memory safety; the host shims reject such starts
   // (the reference would raise: a truncated slice cannot be stacked, llava.py:390-395)
   const int st = min(max(a.starts[b % a.starts_mod], 0), a.max_start);
@@ -135,7 +138,9 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int t = min(4 * lane + 4 * WAVE * i, ntok - 4);       // clamped: tail lanes re-read, masked below
-        v[u][i] = load4_nt<T>(rp + t);
+        unsigned bo = (unsigned)t * (unsigned)sizeof(T);
+        asm volatile("" : "+v"(bo));      // the zero extension stays next to the load: scalar base + 32-bit lane offset
+        v[u][i] = load4_nt<T>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + bo));
       }
     }
 #pragma unroll
@@ -146,16 +151,18 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
         for (int i = 0; i < NV; ++i)
           if (4 * lane + 4 * WAVE * i < ntok)
             s = fadd(s, fadd(fadd(v[u][i].x, v[u][i].y), fadd(v[u][i].z, v[u][i].w)));
-        s = wave_sum(s);                                            // butterfly, o = 32 .. 1
+        s = wave_sum_dpp(s);                                        // butterfly, o = 32 .. 1
         const float den = to_f32<T>(add_tiny<T>(from_f32<T>(s)));   // (row sum -> T) + 1e-12 in T
         // smallest non-zero and largest bit pattern of this lane's numerators (0 - 1 wraps to the top: zeros do not
         // lower the minimum; negative, infinite and NaN numerators exceed SDIV_NUM_HI)
+        // (float16 numerators are 0 or >= 2^-24: only the upper bound -- negative, Inf, NaN -- can fail)
+        constexpr bool kNeedLo = !std::is_same<T, __half>::value;
         uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const uint32_t bx = __float_as_uint(v[u][i].x), by = __float_as_uint(v[u][i].y),
                          bz = __float_as_uint(v[u][i].z), bw = __float_as_uint(v[u][i].w);
-          lo = min(min(lo, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
+          if (kNeedLo) lo = min(min(lo, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
           hi = max(max(hi, bx), max(by, max(bz, bw)));
         }
         const bool box = den >= 8.673617379884035e-19f && den <= 4.0f &&       // 2^-60 .. 4 (wave uniform)

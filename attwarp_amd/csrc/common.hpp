@@ -56,6 +56,26 @@ __device__ __forceinline__ T wave_sum(T v) {
   for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
   return v;
 }
+// The same butterfly (lane l adds the value of lane l ^ o, o = 32, 16, 8, 4, 2, 1: identical bits, float addition is
+// commutative) without the six LDS round trips of ds_bpermute: v_permlane32_swap / v_permlane16_swap (gfx950) for
+// o = 32 / 16, DPP row_ror:8 for o = 8, two bank-masked row shifts for o = 4, quad permutes for o = 2, 1.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(old), __float_as_uint(v), CTRL, 0xf, BANKS, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);                    // o = 32
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);                    // o = 16
+  v = dpp_f32<0x128, 0xf>(0.0f, v) + v;                                 // o = 8: row_ror:8
+  float t = dpp_f32<0x104, 0x5>(0.0f, v);                               // o = 4: lanes 0-3, 8-11 of a row read lane + 4 (row_shl:4)
+  t = dpp_f32<0x114, 0xa>(t, v);                                        //        lanes 4-7, 12-15 read lane - 4 (row_shr:4)
+  v = t + v;
+  v = dpp_f32<0x4e, 0xf>(0.0f, v) + v;                                  // o = 2: quad_perm [2,3,0,1]
+  v = dpp_f32<0xb1, 0xf>(0.0f, v) + v;                                  // o = 1: quad_perm [1,0,3,2]
+  return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = WAVE / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
