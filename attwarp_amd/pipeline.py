@@ -261,7 +261,7 @@ class OverlappedWarp:
                  resample is > 90 % of the step and runs best with its stand-alone dispatch; any image dtype)
         "dag":   R and A on one stream, M on a side stream with exactly the edges the buffers need
         "join":  three graph branches forked and joined in every step
-        "auto":  "am" for float32 images of >= 4 MB, else "fused" when eligible, else "dag".
+        "auto":  "am" for float32 images of >= 4 MB, else "fused" when eligible (float32 images), else "am".
     Steps are replayed as HIP graphs over static buffers; the per-step maps and attention maps are double buffered.
 
     ``images`` / ``rows`` are either one static buffer each (the caller copies every batch in) or RINGS of n buffers
@@ -338,7 +338,9 @@ class OverlappedWarp:
             except _lib.AttWarpError:
                 if self.pattern == "fused":
                     raise
-                self.pattern = "dag"
+                # measured (tools/pattern_probe.py, uint8 images): "am" 0.040 / 0.124 ms per step at B=64 / 256 336x336
+                # against 0.048 / 0.131 ("dag") and 0.048 / 0.125 ("join")
+                self.pattern = "am"
             # the trial step overwrote maps[1] / steps[1] with what they held anyway (same inputs)
 
     def _fused_step(self, c, k):

@@ -2088,6 +2088,14 @@ def test_attn_reduce_and_maps_equals_two_launches(dev, adt):
     big = torch.rand((1, 1024, 1024, 3), device=dev)
     assert pipeline.OverlappedWarp(big, rws[0][:, :1].contiguous(), starts[:1], channels_last=True).pattern == "am"
     assert pipeline.OverlappedWarp(imgs[0], rws[0], starts, channels_last=True).pattern == "fused"
+    # uint8 images are not eligible for the one-launch step: auto takes the two-launch form, same results
+    if adt == torch.float32:
+        imgs8 = [(im * 255).to(torch.uint8) for im in imgs]
+        ow8 = pipeline.OverlappedWarp(imgs8, rws, starts, channels_last=True)
+        assert ow8.pattern == "am"
+        ow8.prime(); ow8.prime2(); ow8.run(7); ow8.tail()
+        for r in range(3):
+            assert torch.equal(ow8.outs[r], pipeline.warp_from_attention_stack(imgs8[r], rws[r], starts, channels_last=True)), r
 
 
 def test_fused_step_argument_checks(dev):
