@@ -42,7 +42,30 @@ struct SharedDiv {
     const float e2 = __builtin_fmaf(-d, q1, a);
     return __builtin_fmaf(e2, r1, q1);
   }
+  // For a quotient that is rounded to float16 / bfloat16 next (numerator and denominator being values of that type: p and
+  // p-bit significands, p = 11 / 8) the first refinement is enough: RN_T(q1) == RN_T(RN_32(a / d)) == RN_T(a / d).
+  //  * a / d is either exactly a rounding midpoint m of T (a (p+1)-bit number) or at least |a/d| / (M D) > 2^-23 |a/d|
+  //    away from every midpoint (a 2^k - m d is a non-zero integer multiple of one unit of the (2p+1)-bit product; in the
+  //    subnormal range of float16 the distance is >= 2^-25 / D > 2^-36 against an error of 2^-38);
+  //  * q1 = RN_32(q0 + e1 r1) with e1 = a - d q0 exact: |q1 - a/d| <= (2^-24 + 2^-45) |a/d|, so q1 lies on the same side of
+  //    every midpoint as a / d, and when a / d IS a midpoint (representable in float32) the value before rounding is
+  //    within 2^-45 of it and q1 equals it exactly -- the tie then breaks as it does for RN_32(a / d) itself.
+  // Checked exhaustively for float16 (every non-negative finite a, every d in (0, 4], reciprocal off by -1, 0, +1 ulp) and
+  // bfloat16 by tests/test_oracle_properties.py::test_three_step_division_* against the float32 quotient.
+  __device__ __forceinline__ float first_refinement(float a) const {
+    const float q0 = fmul(a, r1);
+    const float e1 = __builtin_fmaf(-d, q0, a);
+    return __builtin_fmaf(e1, r1, q0);
+  }
+  template <typename T> __device__ __forceinline__ float rounded_to(float a) const;   // RN_T(a / d) as a float
 };
+template <> __device__ __forceinline__ float SharedDiv::rounded_to<float>(float a) const { return (*this)(a); }
+template <> __device__ __forceinline__ float SharedDiv::rounded_to<__half>(float a) const {
+  return __half2float(__float2half_rn(first_refinement(a)));
+}
+template <> __device__ __forceinline__ float SharedDiv::rounded_to<__hip_bfloat16>(float a) const {
+  return __bfloat162float(__float2bfloat16(first_refinement(a)));
+}
 constexpr uint32_t SDIV_NUM_LO = 0x0D800000u;   // 2^-100
 constexpr uint32_t SDIV_NUM_HI = 0x49800000u;   // 2^20
 
@@ -77,6 +100,28 @@ template <> __device__ __forceinline__ F4v load4_nt<__hip_bfloat16>(const __hip_
   const v4h_a2 q = __builtin_nontemporal_load(reinterpret_cast<const v4h_a2*>(p));
   return F4v{__uint_as_float((uint32_t)q.x << 16), __uint_as_float((uint32_t)q.y << 16),
              __uint_as_float((uint32_t)q.z << 16), __uint_as_float((uint32_t)q.w << 16)};
+}
+// the same four tokens as loaded (the pipelined form of the block keeps the NEXT heads' rows in this form: 2 registers
+// per four 16-bit tokens) and their conversion
+template <typename T> struct Raw4 { uint32_t lo, hi; };
+template <> struct Raw4<float> { float x, y, z, w; };
+template <typename T> __device__ __forceinline__ Raw4<T> load4_raw(const T* p) {
+  typedef uint16_t v4h_a2 __attribute__((ext_vector_type(4), aligned(2)));
+  const v4h_a2 q = __builtin_nontemporal_load(reinterpret_cast<const v4h_a2*>(p));
+  return Raw4<T>{(uint32_t)q.x | ((uint32_t)q.y << 16), (uint32_t)q.z | ((uint32_t)q.w << 16)};
+}
+template <> __device__ __forceinline__ Raw4<float> load4_raw<float>(const float* p) {
+  const F4v q = load4_nt<float>(p);
+  return Raw4<float>{q.x, q.y, q.z, q.w};
+}
+__device__ __forceinline__ F4v cvt4(const Raw4<float>& r) { return F4v{r.x, r.y, r.z, r.w}; }
+__device__ __forceinline__ F4v cvt4(const Raw4<__half>& r) {
+  return F4v{__half2float(__builtin_bit_cast(__half, (uint16_t)(r.lo & 0xffffu))), __half2float(__builtin_bit_cast(__half, (uint16_t)(r.lo >> 16))),
+             __half2float(__builtin_bit_cast(__half, (uint16_t)(r.hi & 0xffffu))), __half2float(__builtin_bit_cast(__half, (uint16_t)(r.hi >> 16)))};
+}
+__device__ __forceinline__ F4v cvt4(const Raw4<__hip_bfloat16>& r) {
+  return F4v{__uint_as_float(r.lo << 16), __uint_as_float(r.lo & 0xffff0000u), __uint_as_float(r.hi << 16),
+             __uint_as_float(r.hi & 0xffff0000u)};
 }
 // round a float32 intermediate to the model dtype and back (identity for float32)
 template <typename T> __device__ __forceinline__ float round_to(float v) { return to_f32<T>(from_f32<T>(v)); }
@@ -115,6 +160,8 @@ constexpr size_t attn_v4_lds_bytes() { return (size_t)(ATTN_NT / WAVE) * NV * 4 
 
 // One 256-thread workgroup per (pseudo-)sample b.  Wave w takes heads w, w+4, ...; lane l owns tokens 4l..4l+3 (+256
 // per vector, NV = ceil(ntok / 256)); HU heads are in flight per wave.  part: LDS, attn_v4_lds_bytes<NV>().
+// (Measured and dropped: requesting the rows of the next HU heads before the current HU heads are reduced -- two register
+// sets of raw rows -- 53.0-53.9 us against 52.0-52.2 for float16 rows.)
 template <typename T, int NV, int HU>
 __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, int b, float* part) {
   constexpr int NT = ATTN_NT, PW = NV * 4 * WAVE, NW = NT / WAVE;
@@ -130,27 +177,101 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
   float acc[NV][4];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
-  for (int h0 = wid; h0 < heads; h0 += NW * HU) {
-    F4v v[HU][NV];
+
+  // 16-bit rows: the image-token slice starts at an arbitrary token (35 + ... in LLaVA-1.5 prompts), so the natural
+  // 8-byte load of a lane is 2-byte aligned -- measured 59.6 us against 47.0 us for an aligned slice (T*B = 5120 rows x 32
+  // heads, tools/attn_layout_probe.py): the texture addresser splits every such access.  ALIGN16: a lane loads the ALIGNED
+  // 8-byte chunk that holds its first token (chunk c = 64 i + l of the row, counted from the aligned address below the
+  // slice start) and assembles its four tokens from its own chunk and the next lane's (DPP wave_shl:1; lane 63 takes
+  // lane 0 of the next vector) with v_alignbyte_b32 -- same values, same order, only the way they reach the registers.
+  // The first chunk may begin up to 3 tokens before the slice and the last one end up to 3 tokens behind it: inside the
+  // same aligned 8 bytes as a token of the slice, hence on the same page.
+  // The image-token slice starts at an arbitrary token (35 + ... in LLaVA-1.5 prompts), so the natural load of a lane --
+  // its four tokens -- is only element aligned, and the texture addresser splits every such access: float16 rows 59.6 us
+  // against 47.0 us for an aligned slice, float32 76.2 against 72.5 (T*B = 5120 rows x 32 heads,
+  // tools/attn_layout_probe.py).  For the 16-bit dtypes a lane therefore loads the ALIGNED four-token chunk that holds its
+  // first token (chunk c = 64 i + l of the row, counted from the aligned address below the slice start) and assembles its
+  // four tokens from its own chunk and the next lane's in registers -- same values in the same lanes, only the way they
+  // get there: float16 59.6 -> 51.5 us (aligned slices: 44-45; the same treatment left float32 rows where they were and
+  // is not applied to them).  The first chunk may begin up to 3 tokens before the slice and the last one end up to 3
+  // tokens behind it: inside the same aligned 8 bytes as a token of the slice, hence on the same page.
+  auto head_ptr = [&](int h) { return base + (int64_t)min(h, heads - 1) * sh; };
+  auto misalign = [&](const T* rp) { return (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 3u); };   // tokens
+  constexpr bool ALIGN16 = sizeof(T) == 2;
+  auto load = [&](Raw4<T> (&r)[HU][NV], int h0) {
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
-      const T* rp = base + (int64_t)min(h0 + u * NW, heads - 1) * sh;
+      const T* rp = head_ptr(h0 + u * NW);
+      if constexpr (ALIGN16) {
+        const int mis = misalign(rp);
+        const T* ap = rp - mis;                                     // aligned to four tokens (8 bytes)
+        const int cmax = (mis + ntok - 1) >> 2;                     // last chunk that holds a token of the slice
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int t = min(4 * lane + 4 * WAVE * i, ntok - 4);       // clamped: tail lanes re-read, masked below
-        unsigned bo = (unsigned)t * (unsigned)sizeof(T);
-        asm volatile("" : "+v"(bo));      // the zero extension stays next to the load: scalar base + 32-bit lane offset
-        v[u][i] = load4_nt<T>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + bo));
+        for (int i = 0; i < NV; ++i) {
+          unsigned bo = (unsigned)min(lane + WAVE * i, cmax) * 4u * (unsigned)sizeof(T);
+          asm volatile("" : "+v"(bo));    // the zero extension stays next to the load: scalar base + 32-bit lane offset
+          typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+          const v2u q = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(reinterpret_cast<const char*>(ap) + bo));
+          r[u][i].lo = q.x;
+          r[u][i].hi = q.y;
+        }
+      } else {                            // float32: the element-aligned 16-byte load itself (realigning gains nothing there)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int t = min(4 * lane + 4 * WAVE * i, ntok - 4);     // clamped: tail lanes re-read, masked below
+          unsigned bo = (unsigned)t * (unsigned)sizeof(T);
+          asm volatile("" : "+v"(bo));
+          r[u][i] = load4_raw<T>(reinterpret_cast<const T*>(reinterpret_cast<const char*>(rp) + bo));
+        }
       }
     }
+  };
+  // tokens mis .. mis + 3 of the 8 tokens [own chunk | next chunk].  mis is wave uniform (a scalar branch per head); the
+  // next lane's dword comes through DPP wave_shl:1, whose lane 63 keeps `old`: the first chunk of the next vector rotated
+  // into lane 63 (wave_rol:1) -- no scalar round trip.
+  auto next_dword = [&](uint32_t own, uint32_t next_vec) -> uint32_t {
+    const uint32_t rot = __builtin_amdgcn_update_dpp(0u, next_vec, 0x134, 0xf, 0xf, false);     // wave_rol:1: lane 63 <- lane 0
+    return __builtin_amdgcn_update_dpp(rot, own, 0x130, 0xf, 0xf, false);                       // wave_shl:1: lane l <- lane l + 1
+  };
+  auto realign = [&](const Raw4<T> (&r)[NV], int mis, Raw4<T> (&o)[NV]) {
+    if (!ALIGN16 || mis == 0) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = r[i];
+      return;
+    }
+    if constexpr (ALIGN16) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {                                // dwords [w0 w1 | w2 w3], two tokens each
+        const Raw4<T>& n = r[i + 1 < NV ? i + 1 : i];               // (the last vector's lane 63 holds no token)
+        if (mis == 1) {
+          const uint32_t w2 = next_dword(r[i].lo, n.lo);
+          o[i].lo = __builtin_amdgcn_alignbyte(r[i].hi, r[i].lo, 2);
+          o[i].hi = __builtin_amdgcn_alignbyte(w2, r[i].hi, 2);
+        } else if (mis == 2) {
+          o[i].lo = r[i].hi;
+          o[i].hi = next_dword(r[i].lo, n.lo);
+        } else {
+          const uint32_t w2 = next_dword(r[i].lo, n.lo), w3 = next_dword(r[i].hi, n.hi);
+          o[i].lo = __builtin_amdgcn_alignbyte(w2, r[i].hi, 2);
+          o[i].hi = __builtin_amdgcn_alignbyte(w3, w2, 2);
+        }
+      }
+    }
+  };
+  auto reduce = [&](const Raw4<T> (&r)[HU][NV], int h0) {
 #pragma unroll
     for (int u = 0; u < HU; ++u) {
       if (h0 + u * NW < heads) {                                    // wave uniform
+        F4v v[NV];
+        Raw4<T> sh4[NV];
+        realign(r[u], misalign(head_ptr(h0 + u * NW)), sh4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = cvt4(sh4[i]);
         float s = 0.0f;
 #pragma unroll
         for (int i = 0; i < NV; ++i)
           if (4 * lane + 4 * WAVE * i < ntok)
-            s = fadd(s, fadd(fadd(v[u][i].x, v[u][i].y), fadd(v[u][i].z, v[u][i].w)));
+            s = fadd(s, fadd(fadd(v[i].x, v[i].y), fadd(v[i].z, v[i].w)));
         s = wave_sum_dpp(s);                                        // butterfly, o = 32 .. 1
         const float den = to_f32<T>(add_tiny<T>(from_f32<T>(s)));   // (row sum -> T) + 1e-12 in T
         // smallest non-zero and largest bit pattern of this lane's numerators (0 - 1 wraps to the top: zeros do not
@@ -160,8 +281,8 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
         uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-          const uint32_t bx = __float_as_uint(v[u][i].x), by = __float_as_uint(v[u][i].y),
-                         bz = __float_as_uint(v[u][i].z), bw = __float_as_uint(v[u][i].w);
+          const uint32_t bx = __float_as_uint(v[i].x), by = __float_as_uint(v[i].y),
+                         bz = __float_as_uint(v[i].z), bw = __float_as_uint(v[i].w);
           if (kNeedLo) lo = min(min(lo, bx - 1u), min(by - 1u, min(bz - 1u, bw - 1u)));
           hi = max(max(hi, bx), max(by, max(bz, bw)));
         }
@@ -171,22 +292,28 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
           const SharedDiv dv(den);
 #pragma unroll
           for (int i = 0; i < NV; ++i) {
-            acc[i][0] = fadd(acc[i][0], round_to<T>(dv(v[u][i].x)));
-            acc[i][1] = fadd(acc[i][1], round_to<T>(dv(v[u][i].y)));
-            acc[i][2] = fadd(acc[i][2], round_to<T>(dv(v[u][i].z)));
-            acc[i][3] = fadd(acc[i][3], round_to<T>(dv(v[u][i].w)));
+            acc[i][0] = fadd(acc[i][0], dv.template rounded_to<T>(v[i].x));
+            acc[i][1] = fadd(acc[i][1], dv.template rounded_to<T>(v[i].y));
+            acc[i][2] = fadd(acc[i][2], dv.template rounded_to<T>(v[i].z));
+            acc[i][3] = fadd(acc[i][3], dv.template rounded_to<T>(v[i].w));
           }
         } else {
 #pragma unroll
           for (int i = 0; i < NV; ++i) {
-            acc[i][0] = fadd(acc[i][0], round_to<T>(v[u][i].x / den));
-            acc[i][1] = fadd(acc[i][1], round_to<T>(v[u][i].y / den));
-            acc[i][2] = fadd(acc[i][2], round_to<T>(v[u][i].z / den));
-            acc[i][3] = fadd(acc[i][3], round_to<T>(v[u][i].w / den));
+            acc[i][0] = fadd(acc[i][0], round_to<T>(v[i].x / den));
+            acc[i][1] = fadd(acc[i][1], round_to<T>(v[i].y / den));
+            acc[i][2] = fadd(acc[i][2], round_to<T>(v[i].z / den));
+            acc[i][3] = fadd(acc[i][3], round_to<T>(v[i].w / den));
           }
         }
       }
     }
+  };
+  constexpr int HS = NW * HU;                                       // heads per iteration of a wave
+  for (int h0 = wid; h0 < heads; h0 += HS) {                       // (h0 is a scalar: wave-uniform branches)
+    Raw4<T> r[HU][NV];
+    load(r, h0);
+    reduce(r, h0);
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i)

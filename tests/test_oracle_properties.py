@@ -122,3 +122,58 @@ def test_remap_float64_keeps_double_precision():
         b = O.remap_bilinear(d.astype(np.float32), mx, my, mode)
         assert a.dtype == np.float64 and b.dtype == np.float32 and 0 < np.abs(a - b).max() < 1e-6
     assert np.array_equal(O.remap_bilinear(d, np.arange(11, dtype=np.float32), np.arange(9, dtype=np.float32), "cv2"), d)
+
+
+# ---- the three-step division of the 16-bit attention reduce (attn_f32v.hpp, SharedDiv::first_refinement) ----------------
+def _three_step_division_mismatches(dtype: str, d_stride: int, d_offset: int = 0) -> tuple:
+    """Emulates q1 = fma(a - d*q0, r, q0), q0 = a*r, for every numerator a and every `d_stride`-th denominator d of the
+    shared-division box, with the refined reciprocal r off by -1 / 0 / +1 float32 ulp from RN(1/d) (whatever v_rcp_f32
+    returned), and compares RN_T(q1) with RN_T(RN_32(a / d)) -- what `a / d` in the model dtype gives in the reference.
+    float64 / 80-bit long double hold every intermediate exactly, so each fma rounds once.  -> (pairs checked, mismatches)."""
+    ld = np.longdouble
+    assert np.finfo(ld).nmant >= 63, "needs the x87 80-bit long double"
+    if dtype == "float16":
+        a16 = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16)             # every non-negative finite float16
+        d16 = np.arange(1, 0x4401, dtype=np.uint16).view(np.float16)             # (0, 4]
+        a = a16.astype(np.float32)
+        dens = d16.astype(np.float32)
+        def rn_t(x32):
+            with np.errstate(over="ignore"):                                      # quotients above 65504 become inf, as on the GPU
+                return x32.astype(np.float16).view(np.uint16)
+    else:
+        hi = np.arange(0x0D80, 0x4980 + 1, dtype=np.uint32)                      # bfloat16 patterns of 2^-100 .. 2^20
+        a = np.concatenate([np.zeros(1, np.float32), (hi << 16).view(np.float32)])
+        dens = (np.arange(0x2180, 0x4080 + 1, dtype=np.uint32) << 16).view(np.float32)   # 2^-60 .. 4
+        def rn_t(x32):
+            b = x32.view(np.uint32).astype(np.uint64)
+            return ((b + 0x7FFF + ((b >> 16) & 1)) >> 16).astype(np.uint32)
+    a64 = a.astype(np.float64)
+    checked = bad = 0
+    for d in dens[d_offset::d_stride]:
+        ref = rn_t(a / d)                                                         # numpy float32 division is IEEE
+        r_rn = np.float32(1.0) / d
+        d64 = np.float64(d)
+        for r in (np.nextafter(r_rn, np.float32(0)), r_rn, np.nextafter(r_rn, np.float32(np.inf))):
+            r64 = np.float64(r)
+            q0 = (a64 * r64).astype(np.float32)                                   # 11 x 24 bits: exact in float64
+            e1 = (a64 - d64 * q0.astype(np.float64)).astype(np.float32)           # exact (cancellation), representable
+            q1 = (q0.astype(ld) + e1.astype(ld) * ld(r)).astype(np.float32)       # <= 61 bits: exact in long double
+            bad += int(np.count_nonzero(rn_t(q1) != ref))
+            checked += a.size
+    return checked, bad
+
+
+def test_three_step_division_float16():
+    """A stride sample of the exhaustive run (every 24th denominator; `python tests/test_oracle_properties.py` runs all)."""
+    checked, bad = _three_step_division_mismatches("float16", 24, 7)
+    assert checked > 60_000_000 and bad == 0
+
+
+def test_three_step_division_bfloat16():
+    checked, bad = _three_step_division_mismatches("bfloat16", 12, 5)
+    assert checked > 20_000_000 and bad == 0
+
+
+if __name__ == "__main__":
+    for dt in ("float16", "bfloat16"):
+        print(dt, "exhaustive (pairs x 3 reciprocals, mismatches):", _three_step_division_mismatches(dt, 1), flush=True)

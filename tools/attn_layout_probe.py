@@ -13,8 +13,8 @@ def timeit(fn, n=30):
 x = torch.empty(1 << 28, device=dev)
 for _ in range(200): x.add_(1.0)
 B = 256
-for kv, s0, spread in ((640, 35, 8), (640, 32, 1), (640, 64, 1), (576, 0, 1), (1024, 35, 8), (1024, 64, 1)):
-    rows = torch.rand(20, B, 32, kv, device=dev)
+for kv, s0, spread in ((640, 35, 8), (640, 32, 1), (640, 36, 1), (640, 33, 1), (640, 34, 1), (640, 35, 1), (640, 32, 8), (576, 0, 1)):
+    rows = torch.softmax(torch.randn(20, B, 32, kv, device=dev), -1)
     starts = (s0 + torch.arange(B, device=dev) % spread).int()
     st = starts.repeat(20)
     for name, r in (("fp32", rows), ("fp16", rows.half())):
