@@ -915,6 +915,31 @@ def test_remap_uint8_cv2_integer_kernel_wide_rows(dev, shape, kind):
         assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (variant, "chw")
 
 
+@pytest.mark.parametrize("shape", [(26, 1024, 18, 1024, 3), (25, 336, 7, 500, 3), (24, 64, 3, 64, 4), (30, 700, 2, 256, 1),
+                                   (70, 512, 66, 300, 3)])
+def test_remap_uint8_integer_kernel_prefetch_depth_and_block_order(dev, shape):
+    """The integer uint8 kernel requests its source rows 1, 2 or 4 output rows ahead (register sets) and can order its
+    workgroups per XCD, plainly or in groups: every combination, with row blocks of 1 ... 64 rows (fewer rows than
+    register sets, remainders of the unroll by four) and several blocks per workgroup, equals the oracle."""
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C = shape
+    rng = np.random.default_rng(H * 13 + W + Wo)
+    B = 3
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, "cdf")
+    img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], "cv2") for b in range(B)])
+    ti, tx, ty = T(img, dev), T(mx, dev), T(my, dev)
+    tc = T(img.transpose(0, 3, 1, 2), dev)
+    for ahead in (1, 2, 4):
+        for rows, cpw in ((-1, -1), (1, 1), (2, 3), (3, 2), (5, 4), (7, 1), (64, 1)):
+            for grp in (0, 1, 2):
+                with _lib.debug_override(u8_ahead=ahead, remap_rows=rows, remap_cpw=cpw, remap_noswz=grp):
+                    hwc = N(cu.remap_separable(ti, tx, ty, mode="cv2", channels_last=True))
+                    chw = N(cu.remap_separable(tc, tx, ty, mode="cv2"))
+                assert np.array_equal(hwc, ref), (ahead, rows, cpw, grp, "hwc")
+                assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), (ahead, rows, cpw, grp, "chw")
+
+
 @pytest.mark.parametrize("C", [1, 2, 3, 4])
 @pytest.mark.parametrize("kind", ["cdf", "wild", "identity"])
 def test_remap_cv2_staged_channels_and_edges(dev, C, kind):
