@@ -68,6 +68,35 @@ def test_attn_steps_vs_oracle_and_golden(dev, golden):
     assert hl.step_attentions == [] and hl.batch_size == 0
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_attn_step_16bit_rows_every_alignment(dev, dt):
+    """The 16-bit rows are read as aligned four-token words and put back together in registers: every residue of the slice
+    start (prompt lengths 32 .. 39 and 0 .. 3), of the row stride (kv lengths that are and are not multiples of four) and
+    of the tensor's own offset inside its allocation (a view 0 .. 3 elements into a buffer), against the oracle bit for
+    bit; the last row ends at the very end of the buffer."""
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(77)
+    heads, ntok = 32, 576
+    for kv in (640, 613, 579):
+        for off in (0, 1, 2, 3):
+            B = 9
+            a = rng.random((B, heads, 2, kv), dtype=np.float32) ** 6
+            a /= a.sum(-1, keepdims=True)
+            starts = np.array([(s0 % (kv - ntok + 1)) for s0 in (32, 33, 34, 35, 36, 37, 0, 1, 3)], np.int32)
+            buf = torch.zeros(off + a.size, device=dev, dtype=dt)
+            view = buf[off:].view(B, heads, 2, kv)
+            view.copy_(T(a, dev).to(dt))
+            got = ae.attn_reduce_step(view, T(starts, dev), ntok)
+            if dt == torch.float16:
+                ref = O.attn_reduce_step(N(view), starts, starts + ntok)
+                assert np.array_equal(N(got), ref), (kv, off)
+            else:       # numpy has no bfloat16: the generic one-token-per-lane kernel (strided call) is the cross-check
+                wide = torch.zeros(B, heads, 2, 2 * kv, device=dev, dtype=dt)
+                wide[..., ::2] = view
+                ref = ae.attn_reduce_step(wide[..., ::2], T(starts, dev), ntok)
+                assert torch.equal(got, ref), (kv, off)
+
+
 def test_attn_step_division_matches_ieee_everywhere(dev):
     """The float32 step kernel divides by (row sum + 1e-12) with a reciprocal shared by the row when the operands sit
     inside the box where v_div_scale does not rescale (attn.hip, SharedDiv) and with the plain IEEE division outside:
