@@ -106,7 +106,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.skew = tune(TUNE_REMAP_SKEW) >= 0 ? tune(TUNE_REMAP_SKEW) : 0;
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
-  p.nt_loads = tune(TUNE_REMAP_NT) == 1;
+  p.nt_loads = tune(TUNE_REMAP_NT) > 0 ? tune(TUNE_REMAP_NT) : 0;      // bit 0: nontemporal loads of block-private rows, bit 1: nontemporal stores
 #endif
   *handled = true;
   // (one-wave workgroups for rows <= 4 KB were measured too: 336x336x3, B=256: 0.136 ms vs 0.134 ms with

@@ -38,8 +38,10 @@
 // product library always issues plain loads.
 #ifdef ATTWARP_TUNING
 typedef float rows_v4f __attribute__((ext_vector_type(4)));
+#define ATTWARP_ROW_STORE(ptr_, v_)                                                                                 \
+  do { if (p.nt_loads & 2) __builtin_nontemporal_store((v_), (ptr_)); else *(ptr_) = (v_); } while (0)
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
-  if (p.nt_loads && srow_ != row_lo && srow_ != row_hi) {                                                           \
+  if ((p.nt_loads & 1) && srow_ != row_lo && srow_ != row_hi) {                                                           \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                                 \
       const rows_v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k]));             \
       X[k] = make_float4(t_.x, t_.y, t_.z, t_.w);                                                                   \
@@ -48,6 +50,7 @@ typedef float rows_v4f __attribute__((ext_vector_type(4)));
     _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);           \
   }
 #else
+#define ATTWARP_ROW_STORE(ptr_, v_) (*(ptr_) = (v_))
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
   { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
 #endif
@@ -415,7 +418,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
           } else {                                                                                  \
             o_ = lerp_rn(v0[kk], v1[kk], fxr[k]);                                                   \
           }                                                                                         \
-          *reinterpret_cast<float*>(orow + off) = o_;                                               \
+          ATTWARP_ROW_STORE(reinterpret_cast<float*>(orow + off), o_);                              \
         }                                                                                           \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \

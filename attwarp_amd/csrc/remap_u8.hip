@@ -339,6 +339,12 @@ static int launch_ko(const Params& p, hipStream_t st) {
 //     tap 1 is always "tap 0's pixel + 1" with kx forced to 0 where OpenCV clamps both taps to the same pixel (integer
 //     arithmetic: a zero weight is exact), so the clamped cases need no second offset logic.
 // Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
+// Output dwords are written once and never read by this kernel: nontemporal stores (cache-policy bit 1 of the buffer
+// instruction) leave L2 / Infinity Cache to the source rows.  Measured in one process (tools/u8_nt_probe.py, B=256):
+// 336 -> 500 95.8 -> 76.2 us, 1024 -> 1024 343.6 -> 336.4, 1024 -> 500 156.0 -> 155.0; nontemporal LOADS lose
+// everywhere (the row shared with the neighbouring output row then misses: 1024 -> 1024 459.7 us).  The float32 kernels
+// do not respond to either (docs/experiments.md).
+constexpr int U8I_STORE_NT = 2;
 constexpr int U8I_VLP = 4096 + 16;      // u16 elements per LDS row buffer: rows of <= 4096 bytes + one pixel of slack
 
 template <int KI, int KD, bool HWC, int PD>
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
         const unsigned in_ = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u, false); \
         o_ |= (in_ >> 10) << (8 * j);                                                                  \
       }                                                                                                \
-      if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, 0); \
+      if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, U8I_STORE_NT); \
     }                                                                                                  \
   }
   // Row blocks of this workgroup: rb0, rb0 + wpi, ... -- the column-tap prologue above (a cvRound and two integer
