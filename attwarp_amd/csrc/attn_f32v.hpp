@@ -178,25 +178,19 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 0.0f;
 
-  // 16-bit rows: the image-token slice starts at an arbitrary token (35 + ... in LLaVA-1.5 prompts), so the natural
-  // 8-byte load of a lane is 2-byte aligned -- measured 59.6 us against 47.0 us for an aligned slice (T*B = 5120 rows x 32
-  // heads, tools/attn_layout_probe.py): the texture addresser splits every such access.  ALIGN16: a lane loads the ALIGNED
-  // 8-byte chunk that holds its first token (chunk c = 64 i + l of the row, counted from the aligned address below the
-  // slice start) and assembles its four tokens from its own chunk and the next lane's (DPP wave_shl:1; lane 63 takes
-  // lane 0 of the next vector) with v_alignbyte_b32 -- same values, same order, only the way they reach the registers.
-  // The first chunk may begin up to 3 tokens before the slice and the last one end up to 3 tokens behind it: inside the
-  // same aligned 8 bytes as a token of the slice, hence on the same page.
   // The image-token slice starts at an arbitrary token (35 + ... in LLaVA-1.5 prompts), so the natural load of a lane --
-  // its four tokens -- is only element aligned, and the texture addresser splits every such access: float16 rows 59.6 us
-  // against 47.0 us for an aligned slice, float32 76.2 against 72.5 (T*B = 5120 rows x 32 heads,
-  // tools/attn_layout_probe.py).  For the 16-bit dtypes a lane therefore loads the ALIGNED four-token chunk that holds its
-  // first token (chunk c = 64 i + l of the row, counted from the aligned address below the slice start) and assembles its
-  // four tokens from its own chunk and the next lane's in registers -- same values in the same lanes, only the way they
-  // get there: float16 59.6 -> 51.5 us (aligned slices: 44-45; the same treatment left float32 rows where they were and
-  // is not applied to them).  The first chunk may begin up to 3 tokens before the slice and the last one end up to 3
-  // tokens behind it: inside the same aligned 8 bytes as a token of the slice, hence on the same page.
+  // its four tokens -- is only element aligned.  For the 16-bit dtypes an ODD token offset makes it a 2-byte aligned 8-byte
+  // load, which the texture addresser splits: float16 rows 59.6 us against 47.0 us for an aligned slice (T*B = 5120 rows x
+  // 32 heads, tools/attn_layout_probe.py; a dword-aligned address is as good as an 8-byte aligned one, and float32 rows
+  // do not care).  In that case a lane loads the four-token chunk one token BELOW its first token (dword aligned: chunk
+  // c = 64 i + l of the row counted from there) and assembles its tokens from its own chunk and the first token pair of
+  // the next lane's in registers -- same values in the same lanes, only the way they get there: 59.6 -> 48.0 us.  The
+  // first chunk then begins one token before the slice and the last one ends three tokens behind it: inside the same
+  // aligned 8 bytes as a token of the slice, hence on the same page.
   auto head_ptr = [&](int h) { return base + (int64_t)min(h, heads - 1) * sh; };
-  auto misalign = [&](const T* rp) { return (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 3u); };   // tokens
+  // tokens by which a row's slice misses the alignment its loads need: a dword-aligned 8-byte load is as good as an
+  // 8-byte aligned one, so only an ODD token offset (a 2-byte aligned address) is realigned
+  auto misalign = [&](const T* rp) { return (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 1u); };
   constexpr bool ALIGN16 = sizeof(T) == 2;
   auto load = [&](Raw4<T> (&r)[HU][NV], int h0) {
 #pragma unroll
@@ -204,8 +198,8 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
       const T* rp = head_ptr(h0 + u * NW);
       if constexpr (ALIGN16) {
         const int mis = misalign(rp);
-        const T* ap = rp - mis;                                     // aligned to four tokens (8 bytes)
-        const int cmax = (mis + ntok - 1) >> 2;                     // last chunk that holds a token of the slice
+        const T* ap = rp - mis;                                     // dword aligned
+        const int cmax = (mis + ntok - 1) >> 2;                     // last four-token chunk that holds a token of the slice
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           unsigned bo = (unsigned)min(lane + WAVE * i, cmax) * 4u * (unsigned)sizeof(T);
@@ -226,9 +220,9 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
       }
     }
   };
-  // tokens mis .. mis + 3 of the 8 tokens [own chunk | next chunk].  mis is wave uniform (a scalar branch per head); the
-  // next lane's dword comes through DPP wave_shl:1, whose lane 63 keeps `old`: the first chunk of the next vector rotated
-  // into lane 63 (wave_rol:1) -- no scalar round trip.
+  // tokens 1 .. 4 of the 8 tokens [own chunk | next chunk].  mis is wave uniform (a scalar branch per head); the next
+  // lane's dword comes through DPP wave_shl:1, whose lane 63 keeps `old`: the first chunk of the next vector rotated into
+  // lane 63 (wave_rol:1) -- no scalar round trip.
   auto next_dword = [&](uint32_t own, uint32_t next_vec) -> uint32_t {
     const uint32_t rot = __builtin_amdgcn_update_dpp(0u, next_vec, 0x134, 0xf, 0xf, false);     // wave_rol:1: lane 63 <- lane 0
     return __builtin_amdgcn_update_dpp(rot, own, 0x130, 0xf, 0xf, false);                       // wave_shl:1: lane l <- lane l + 1
@@ -241,20 +235,11 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
     }
     if constexpr (ALIGN16) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i) {                                // dwords [w0 w1 | w2 w3], two tokens each
+      for (int i = 0; i < NV; ++i) {                                // dwords [w0 w1 | w2 ..], two tokens each; tokens 1 .. 4
         const Raw4<T>& n = r[i + 1 < NV ? i + 1 : i];               // (the last vector's lane 63 holds no token)
-        if (mis == 1) {
-          const uint32_t w2 = next_dword(r[i].lo, n.lo);
-          o[i].lo = __builtin_amdgcn_alignbyte(r[i].hi, r[i].lo, 2);
-          o[i].hi = __builtin_amdgcn_alignbyte(w2, r[i].hi, 2);
-        } else if (mis == 2) {
-          o[i].lo = r[i].hi;
-          o[i].hi = next_dword(r[i].lo, n.lo);
-        } else {
-          const uint32_t w2 = next_dword(r[i].lo, n.lo), w3 = next_dword(r[i].hi, n.hi);
-          o[i].lo = __builtin_amdgcn_alignbyte(w2, r[i].hi, 2);
-          o[i].hi = __builtin_amdgcn_alignbyte(w3, w2, 2);
-        }
+        const uint32_t w2 = next_dword(r[i].lo, n.lo);
+        o[i].lo = __builtin_amdgcn_alignbyte(r[i].hi, r[i].lo, 2);
+        o[i].hi = __builtin_amdgcn_alignbyte(w2, r[i].hi, 2);
       }
     }
   };

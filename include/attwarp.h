@@ -80,9 +80,9 @@ ATTWARP_API int attwarp_debug_set(const char* key, int value, int* previous);
  * starts[b] .. starts[b]+ntok-1; per-head renormalisation (x / (sum + 1e-12)), mean over heads.
  * out [B,ntok] in the same dtype (F32/F16/BF16).  starts: device int32[B]; ntok <= kv_len is required and a start
  * outside [0, kv_len-ntok] is clamped into it on the device (no out-of-row reads).
- * F16 / BF16 rows with unit kv stride are read in ALIGNED 8-byte words: the words that hold the first and the last
- * element of a slice are read whole (up to 3 elements before / behind the slice, always inside the same aligned 8 bytes
- * as an element of it -- for the first / last row of the tensor that may be up to 6 bytes outside the tensor but never
+ * F16 / BF16 rows with unit kv stride whose slice starts at an odd element are read in dword-aligned four-element words:
+ * one element before the slice and up to three behind it are read with it (always inside the same aligned 8 bytes as an
+ * element of the slice -- for the first / last row of the tensor that may be up to 6 bytes outside the tensor but never
  * outside its 8-byte aligned extent; hipMalloc / torch allocations are aligned and padded far beyond that). */
 ATTWARP_API int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int heads, int q_len, int kv_len,
                              int64_t stride_b, int64_t stride_h, int64_t stride_q, int64_t stride_kv,
