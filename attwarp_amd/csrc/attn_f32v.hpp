@@ -185,12 +185,15 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
   // do not care).  In that case a lane loads the four-token chunk one token BELOW its first token (dword aligned: chunk
   // c = 64 i + l of the row counted from there) and assembles its tokens from its own chunk and the first token pair of
   // the next lane's in registers -- same values in the same lanes, only the way they get there: 59.6 -> 48.0 us.  The
-  // first chunk then begins one token before the slice and the last one ends three tokens behind it: inside the same
-  // aligned 8 bytes as a token of the slice, hence on the same page.
+  // first chunk then begins one token before the slice (an odd address is never the first element of an allocation) and
+  // the last one ends up to three tokens behind it: tokens of the same row (`tail_room` below).
   auto head_ptr = [&](int h) { return base + (int64_t)min(h, heads - 1) * sh; };
   // tokens by which a row's slice misses the alignment its loads need: a dword-aligned 8-byte load is as good as an
   // 8-byte aligned one, so only an ODD token offset (a 2-byte aligned address) is realigned
-  auto misalign = [&](const T* rp) { return (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 1u); };
+  // (only while three tokens behind the slice still belong to the row -- the last chunk reads up to there; a slice that
+  // ends within three tokens of the row's end keeps the plain element-aligned loads, which read exactly the slice)
+  const bool tail_room = st + 3 <= a.max_start;
+  auto misalign = [&](const T* rp) { return tail_room ? (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 1u) : 0; };
   constexpr bool ALIGN16 = sizeof(T) == 2;
   auto load = [&](Raw4<T> (&r)[HU][NV], int h0) {
 #pragma unroll

@@ -297,7 +297,7 @@ class OverlappedWarp:
         if any(i.shape != self.images[0].shape or i.dtype != self.images[0].dtype for i in self.images):
             raise ValueError("OverlappedWarp: every image buffer of the ring must have the same shape and dtype")
         self.n = len(self.images)
-        self.starts = starts
+        self.starts = starts.clone()         # own copy: set_starts() writes into it
         self.channels_last, self.mode = channels_last, mode
         img0 = self.images[0]
         H, W = (img0.shape[1], img0.shape[2]) if channels_last else (img0.shape[2], img0.shape[3])

@@ -81,9 +81,10 @@ ATTWARP_API int attwarp_debug_set(const char* key, int value, int* previous);
  * out [B,ntok] in the same dtype (F32/F16/BF16).  starts: device int32[B]; ntok <= kv_len is required and a start
  * outside [0, kv_len-ntok] is clamped into it on the device (no out-of-row reads).
  * F16 / BF16 rows with unit kv stride whose slice starts at an odd element are read in dword-aligned four-element words:
- * one element before the slice and up to three behind it are read with it (always inside the same aligned 8 bytes as an
- * element of the slice -- for the first / last row of the tensor that may be up to 6 bytes outside the tensor but never
- * outside its 8-byte aligned extent; hipMalloc / torch allocations are aligned and padded far beyond that). */
+ * the element before the slice and up to three elements behind it are read with it -- elements of the same row (a slice
+ * that ends within three elements of the row's end is read with plain element-aligned loads instead), so nothing outside
+ * the allocation the tensor lives in is touched (the element before the slice of a view that starts at an odd element of
+ * its buffer is the only access outside the tensor itself). */
 ATTWARP_API int attwarp_attn_reduce_step(const void* attn, int dtype, int B, int heads, int q_len, int kv_len,
                              int64_t stride_b, int64_t stride_h, int64_t stride_q, int64_t stride_kv,
                              const int32_t* starts, int ntok, void* out, void* stream);
