@@ -13,13 +13,16 @@
 
 namespace attwarp {
 
+// Register budget: both bodies share one allocation, and the reduce -- 5120 of the 5632 blocks -- is the one that needs
+// the occupancy.  With 24 step maps per request the map body took 138 VGPRs (3 waves per SIMD for every block; the
+// reduce alone runs at 82 VGPRs = 5 waves): 8 per request and a 5-wave bound keep the launch at the reduce's occupancy.
 template <typename T>
-__global__ __launch_bounds__(ATTN_NT) void attn_maps_kernel(const AttnStepArgsT<T> a, const StepsMapsArgs m, int n_maps8) {
+__global__ __launch_bounds__(ATTN_NT, 5) void attn_maps_kernel(const AttnStepArgsT<T> a, const StepsMapsArgs m, int n_maps8) {
   extern __shared__ __attribute__((aligned(16))) float am_smem[];
   __shared__ float s_tmp[64], s_pm[64];
   const int blk = blockIdx.x;
   if (blk < n_maps8) {          // map blocks first: the longest dependent chain starts at once
-    if (blk < 2 * m.B) axis_maps_from_steps_block<24, T>(m, blk >> 1, blk & 1, reinterpret_cast<double*>(am_smem), s_tmp, s_pm);
+    if (blk < 2 * m.B) axis_maps_from_steps_block<8, T>(m, blk >> 1, blk & 1, reinterpret_cast<double*>(am_smem), s_tmp, s_pm);
     return;
   }
   attn_reduce_v4_block<T, 3, 4>(a, blk - n_maps8, am_smem);
