@@ -13,6 +13,7 @@
 // accumulated in double and rounded once (see oracle/warp_oracle.py, module docstring).
 #include "common.hpp"
 #include "attn_f32v.hpp"
+#include "mask_blocks.hpp"
 
 namespace attwarp {
 
@@ -121,95 +122,16 @@ __global__ __launch_bounds__(NT) void attn_finalize_kernel(const T* __restrict__
   out[i] = div_t<T>(from_f64<T>(acc), from_f32<T>((float)Tn));
 }
 
-// ---- A3: one workgroup per mask -----------------------------------------------------------
+// ---- A3: one workgroup per mask (body: mask_blocks.hpp) ---------------------------------------
 __global__ __launch_bounds__(NT) void mask_postproc_kernel(const float* __restrict__ mask, int n, int ks, float coe,
                                                            float* __restrict__ out) {
   __shared__ float x[32 * 32];
   __shared__ double red[NT / WAVE];
   __shared__ float fred[2][NT / WAVE];
-  const int b = blockIdx.x, cnt = n * n;
-  const float* m = mask + (size_t)b * cnt;
-  float mn = INFINITY, mx = -INFINITY;
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    const float v = m[k];
-    x[k] = v;
-    mn = fminf(mn, v);
-    mx = fmaxf(mx, v);
-  }
-  mn = wave_min(mn);
-  mx = wave_max(mx);
-  if ((threadIdx.x & (WAVE - 1)) == 0) {
-    fred[0][threadIdx.x / WAVE] = mn;
-    fred[1][threadIdx.x / WAVE] = mx;
-  }
-  __syncthreads();
-  mn = fred[0][0]; mx = fred[1][0];
-  for (int w = 1; w < NT / WAVE; ++w) { mn = fminf(mn, fred[0][w]); mx = fmaxf(mx, fred[1][w]); }
-  // normalize("min"): (mat - min) / (max - min)
-  const float range = fsub(mx, mn);
-  double acc = 0.0;
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    const float v = fsub(x[k], mn) / range;
-    x[k] = v;
-    acc += (double)v;
-  }
-  // enhance: mat - mean ; / std (unbiased) ; * coe ; sigmoid ; clamp(0,1)
-  const float mean = (float)(block_sum(acc, red) / (double)cnt);
-  acc = 0.0;
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    const float v = fsub(x[k], mean);
-    x[k] = v;
-    acc += (double)v;
-  }
-  const double mu2 = block_sum(acc, red) / (double)cnt;
-  acc = 0.0;
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    const double d = (double)x[k] - mu2;
-    acc += d * d;
-  }
-  const float sd = (float)sqrt(block_sum(acc, red) / (double)(cnt - 1));
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    float v = x[k] / sd;
-    v = fmul(v, coe);
-    v = (float)(1.0 / (1.0 + exp(-(double)v)));
-    x[k] = (v != v) ? v : fminf(fmaxf(v, 0.0f), 1.0f);     // torch.clamp propagates NaN (a constant map: 0 / 0 above)
-  }
-  __syncthreads();
-  // Conv2d(1,1,ks,padding=(ks-1)/2,padding_mode="replicate"), all weights 1/ks^2
-  const int pad = (ks - 1) / 2;
-  const float wgt = 1.0f / (float)(ks * ks);
-  for (int k = threadIdx.x; k < cnt; k += NT) {
-    const int r = k / n, c = k - r * n;
-    double a = 0.0;
-    for (int dy = -pad; dy <= pad; ++dy)
-      for (int dx = -pad; dx <= pad; ++dx) {
-        const int rr = min(max(r + dy, 0), n - 1), cc = min(max(c + dx, 0), n - 1);
-        a += (double)fmul(x[rr * n + cc], wgt);
-      }
-    out[(size_t)b * cnt + k] = (float)a;
-  }
+  mask_postproc_block(mask, n, ks, coe, out, blockIdx.x, x, red, &fred[0][0]);
 }
 
-// ---- A4: Pillow's 8-bit separable resampler (ImagingResampleHorizontal/Vertical_8bpc) ----
-constexpr int PIL_PRECISION_BITS = 32 - 8 - 2;
-
-__device__ __forceinline__ uint8_t pil_clip8(int v) { return (uint8_t)min(max(v >> PIL_PRECISION_BITS, 0), 255); }
-// four clip8 results packed into a dword: gfx950's v_ashr_pk_u8_i32 shifts, saturates to [0,255] and packs two
-// values into the low 16 bits.  Used through the builtin with an explicit 16-bit mask: when the compiler forms the
-// instruction by itself from `clip8(a) | clip8(b) << 8 | clip8(c) << 16 | ...` it omits that mask (ROCm 7.2) and the
-// stale upper half of the destination register corrupts bytes 2 and 3.
-__device__ __forceinline__ uint32_t pil_clip8x4(int s0, int s1, int s2, int s3) {
-  const uint32_t lo = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(s0, s1, PIL_PRECISION_BITS);
-  const uint32_t hi = (uint32_t)(uint16_t)__builtin_amdgcn_ashr_pk_u8_i32(s2, s3, PIL_PRECISION_BITS);
-  return lo | (hi << 16);
-}
-
-// ToPILImage on a float tensor: pic.mul(255).byte()  (truncating cast)
-__device__ __forceinline__ uint8_t to_pil_u8(float v) {
-  const float s = fmul(v, 255.0f);
-  return (uint8_t)min(max((int)truncf(s), 0), 255);
-}
-
+// ---- A4: Pillow's 8-bit separable resampler (ImagingResampleHorizontal/Vertical_8bpc); helpers in mask_blocks.hpp ----
 // horizontal pass: tmp[b][y][xx], one thread per output.  grid = (ceil(out_w/NT), h, B)
 __global__ __launch_bounds__(NT) void lanczos_h_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
                                                        int h, int w, int out_w, const int32_t* __restrict__ bounds,
@@ -407,115 +329,12 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
   }
 }
 
-// Up-sampling form of the fused kernel (<= 8 taps on both axes: the 24 x 24 token grid blown up to the image size).
-// The cost is the vertical pass -- out_h * out_w outputs of <= 8 taps each -- so the decomposition is chosen for it:
-//   * a workgroup owns a COLUMN STRIP of 256 pixels (64 dwords, one per lane) and a chunk of the output rows; its
-//     horizontal pass therefore produces each tile value it needs exactly once (h x 256 bytes of LDS) -- in the
-//     row-block form every block of R rows recomputed ~8 of the 24 tile rows at full width, a third of all VALU work
-//     (SQ_INSTS_VALU, profiles/round2_chain_pmc.txt);
-//   * the four waves split the chunk's rows; everything that depends on the output row only (bounds, the 8
-//     zero-padded coefficients) is wave uniform and comes from scalar loads issued one row ahead; a lane keeps the 8
-//     tile rows of the current tap window unpacked in registers (the window slides by one tile row every
-//     out_h / h rows), so an output dword costs 28-32 v_mad_i32_i24 (8-bit pixels, coefficients < 2^23), two
-//     v_ashr_pk_u8_i32 and one store.
-// Same integer arithmetic as the other forms (bit-identical to Pillow).  grid = (nstrips * nchunks, B).
-// LDS: src[h*w] | tile[h][256].   kk_y rows hold exactly 8 coefficients (zero padded).
+// Up-sampling form of the fused kernel (<= 8 taps on both axes): body lanczos_strip_block (mask_blocks.hpp).
+// grid = (nstrips * nchunks, B).  LDS: src[h*w] | tile[h][256].   kk_y rows hold exactly 8 coefficients (zero padded).
 template <int KS>
-__global__ __launch_bounds__(NT) void lanczos_strip_kernel(const float* __restrict__ mf, const uint8_t* __restrict__ mu,
-                                                           int h, int w, int out_h, int out_w,
-                                                           const int32_t* __restrict__ bounds_x,
-                                                           const int32_t* __restrict__ kk_x, int ksize_x,
-                                                           const int32_t* __restrict__ bounds_y,
-                                                           const int32_t* __restrict__ kk_y, int nchunks, int rows_per_chunk,
-                                                           uint8_t* __restrict__ out) {
+__global__ __launch_bounds__(NT) void lanczos_strip_kernel(const LanczosStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz[];
-  constexpr int SW = NT;                               // strip width in pixels
-  const int srcp = (h * w + 3) & ~3;
-  uint8_t* src = lz;
-  uint8_t* tile = lz + srcp;
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int strip = blockIdx.x / nchunks, chunk = blockIdx.x - strip * nchunks;
-  const int yy0 = chunk * rows_per_chunk, yy1 = min(yy0 + rows_per_chunk, out_h);
-  const int ys = bounds_y[2 * yy0];                                          // first / one-past-last source row
-  const int ye = bounds_y[2 * (yy1 - 1)] + bounds_y[2 * (yy1 - 1) + 1];
-  const size_t ib = (size_t)b * h * w;
-  for (int i = ys * w + tid; i < ye * w; i += NT) src[i] = mf ? to_pil_u8(mf[ib + i]) : mu[ib + i];
-  __syncthreads();
-  {   // horizontal pass: one column per thread
-    const int xx = min(strip * SW + tid, out_w - 1);
-    const int xmin = bounds_x[2 * xx], cnt = bounds_x[2 * xx + 1];
-    int kreg[KS], toff[KS];
-#pragma unroll
-    for (int x = 0; x < KS; ++x) {
-      kreg[x] = (x < cnt) ? kk_x[(size_t)xx * ksize_x + min(x, ksize_x - 1)] : 0;
-      toff[x] = xmin + min(x, cnt - 1);
-    }
-    for (int r = ys; r < ye; ++r) {
-      const uint8_t* row = src + r * w;
-      int ss = 1 << (PIL_PRECISION_BITS - 1);
-#pragma unroll
-      for (int x = 0; x < KS; ++x) ss += __mul24((int)row[toff[x]], kreg[x]);
-      tile[r * SW + tid] = pil_clip8(ss);
-    }
-  }
-  __syncthreads();
-  const int lane = tid & (WAVE - 1);
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nq = out_w >> 2;
-  const int q = strip * (SW / 4) + lane;               // global dword column
-  const int nrows = yy1 - yy0;
-  const int rows_per_wave = (nrows + NT / WAVE - 1) / (NT / WAVE);
-  const int r_beg = yy0 + wid * rows_per_wave, r_end = min(r_beg + rows_per_wave, yy1);
-  if (r_beg >= r_end) return;
-  int win[8][4];
-  int base = -0x40000000;
-#pragma unroll
-  for (int y = 0; y < 8; ++y) win[y][0] = win[y][1] = win[y][2] = win[y][3] = 0;
-  auto load_row = [&](int r, int (&dst)[4]) {
-    const uint32_t wv = reinterpret_cast<const uint32_t*>(tile + min(r, h - 1) * SW)[lane];
-    dst[0] = (int)(wv & 0xffu); dst[1] = (int)((wv >> 8) & 0xffu); dst[2] = (int)((wv >> 16) & 0xffu); dst[3] = (int)(wv >> 24);
-  };
-  // the NEXT row's bounds and coefficients are fetched while the current row is computed
-  int kc[8], ymin_c = bounds_y[2 * r_beg];
-#pragma unroll
-  for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)r_beg * 8 + y];
-  uint32_t* orow = reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + r_beg) * out_w) + min(q, nq - 1);
-  for (int yy = r_beg; yy < r_end; ++yy) {
-    const int ymin = ymin_c;
-    int kv[8];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) kv[y] = kc[y];
-    const int yn = min(yy + 1, out_h - 1);
-    ymin_c = bounds_y[2 * yn];
-#pragma unroll
-    for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)yn * 8 + y];
-    if (ymin != base) {                                      // wave uniform
-      if (ymin == base + 1) {
-#pragma unroll
-        for (int y = 0; y < 7; ++y) { win[y][0] = win[y + 1][0]; win[y][1] = win[y + 1][1]; win[y][2] = win[y + 1][2]; win[y][3] = win[y + 1][3]; }
-        load_row(ymin + 7, win[7]);
-      } else {
-#pragma unroll
-        for (int y = 0; y < 8; ++y) load_row(ymin + y, win[y]);
-      }
-      base = ymin;
-    }
-    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
-#pragma unroll
-    for (int y = 0; y < 8; ++y) {
-      if (y == 7 && kv[7] == 0) break;                       // 24 -> 1024 has 7 taps: the padded 8th is skipped (uniform)
-      // one v_mad_i32_i24 per tap and pixel (left to itself the compiler pairs v_mul_i32_i24 with v_add3_u32:
-      // 1.5 instructions per tap); the coefficient is wave uniform and sits in an SGPR
-      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s0) : "v"(win[y][0]), "s"(kv[y]));
-      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s1) : "v"(win[y][1]), "s"(kv[y]));
-      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s2) : "v"(win[y][2]), "s"(kv[y]));
-      asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s3) : "v"(win[y][3]), "s"(kv[y]));
-    }
-    // (written once by this kernel: nontemporal -- 24 -> 1024 B=256 109.9 -> 106.2 us, 24 -> 336 40.6 -> 36.6, and the
-    // marginals kernel that reads the mask next is not slower for it)
-    if (q < nq) __builtin_nontemporal_store(pil_clip8x4(s0, s1, s2, s3), orow);
-    orow += nq;
-  }
+  lanczos_strip_block<KS>(a, blockIdx.x, blockIdx.y, lz);
 }
 
 // copy / quantise pass used when an axis keeps its size (Pillow skips that pass)
@@ -719,8 +538,8 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     if (const int v = tune(TUNE_LANCZOS_ROWS); v >= 1) rows_per_chunk = v < out_h ? v : out_h;
     nchunks = (out_h + rows_per_chunk - 1) / rows_per_chunk;
     const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * NT;
-    hipLaunchKernelGGL((lanczos_strip_kernel<8>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, mask_f32, mask_u8, h, w,
-                       out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, (int)nchunks, rows_per_chunk, out);
+    LanczosStripArgs la{mask_f32, mask_u8, h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, (int)nchunks, rows_per_chunk, out};
+    hipLaunchKernelGGL((lanczos_strip_kernel<8>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, la);
     return check_launch("lanczos_strip_kernel");
   }
   // small source and both passes needed, any tap count: one fused launch (row-block form)

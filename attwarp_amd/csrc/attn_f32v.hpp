@@ -192,7 +192,9 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
   // 8-byte aligned one, so only an ODD token offset (a 2-byte aligned address) is realigned
   // (only while three tokens behind the slice still belong to the row -- the last chunk reads up to there; a slice that
   // ends within three tokens of the row's end keeps the plain element-aligned loads, which read exactly the slice)
-  const bool tail_room = st + 3 <= a.max_start;
+  // ... and only while lane 63 of the LAST vector owns no token: at ntok == NV * 256 its fourth token would come from
+  // chunk NV * 64, which no vector loads (wave_rol would hand it chunk (NV - 1) * 64's first dword instead)
+  const bool tail_room = st + 3 <= a.max_start && ntok < NV * 4 * WAVE;
   auto misalign = [&](const T* rp) { return tail_room ? (int)((reinterpret_cast<uintptr_t>(rp) / sizeof(T)) & 1u) : 0; };
   constexpr bool ALIGN16 = sizeof(T) == 2;
   auto load = [&](Raw4<T> (&r)[HU][NV], int h0) {
@@ -207,7 +209,9 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
         for (int i = 0; i < NV; ++i) {
           unsigned bo = (unsigned)min(lane + WAVE * i, cmax) * 4u * (unsigned)sizeof(T);
           asm volatile("" : "+v"(bo));    // the zero extension stays next to the load: scalar base + 32-bit lane offset
-          typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+          // dword aligned when realigned (mis == 1) or when the slice starts on an even token; a slice that starts on an odd
+          // token without tail room keeps its 2-byte aligned address: the type must not promise more than that
+          typedef uint32_t v2u __attribute__((ext_vector_type(2), aligned(2)));
           const v2u q = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(reinterpret_cast<const char*>(ap) + bo));
           r[u][i].lo = q.x;
           r[u][i].hi = q.y;

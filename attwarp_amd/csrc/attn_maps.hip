@@ -36,6 +36,7 @@ static int launch_attn_maps(const void* rows, int n_rows, int heads, int kv_len,
   a.starts = starts; a.starts_mod = starts_mod; a.max_start = kv_len - ntok; a.ntok = ntok; a.out = static_cast<T*>(steps_out);
   const int n_maps8 = ((2 * m.B + 7) / 8) * 8;
   const size_t lds = std::max(attn_v4_lds_bytes<3>(), steps_maps_lds_bytes(std::max(m.W, m.H), m.g));
+  if (const int rc = grant_dynamic_lds(attn_maps_kernel<T>, lds, "attn_reduce_and_maps")) return rc;
   hipLaunchKernelGGL((attn_maps_kernel<T>), dim3(n_maps8 + n_rows), dim3(ATTN_NT), lds, st, a, m, n_maps8);
   return check_launch("attn_maps_kernel");
 }

@@ -222,6 +222,7 @@ extern "C" int attwarp_axis_maps_from_pdf(const float* px, const float* py, int 
   const int L = W > H ? W : H;
   if (L > 8192) return fail(ATTWARP_E_UNSUPPORTED, "axis_maps_from_pdf: max(W,H)=%d > 8192", L);
   const size_t lds = (size_t)(8 + L + 2) * sizeof(double) + (size_t)L * sizeof(float);
+  if (const int rc = grant_dynamic_lds(axis_maps_from_pdf_kernel, lds, "axis_maps_from_pdf")) return rc;
   hipLaunchKernelGGL(axis_maps_from_pdf_kernel, dim3(B, 2), dim3(NT), lds, as_stream(stream), px, py, Lo, W, H, W_out,
                      H_out, inv_x, inv_y, map_x, map_y);
   return check_launch("axis_maps_from_pdf_kernel");
@@ -244,6 +245,10 @@ extern "C" int attwarp_axis_maps_from_steps_t(const void* steps, int dtype, int 
   a.inv_x = inv_x; a.inv_y = inv_y; a.map_x = map_x; a.map_y = map_y; a.att_out = att_out;
   const dim3 grid(B, 2), blk(NT);
   const size_t lds = steps_maps_lds_bytes(L, g);
+  if (const int rc = dtype == ATTWARP_F32 ? grant_dynamic_lds(axis_maps_from_steps_kernel<float>, lds, "axis_maps_from_steps")
+                     : dtype == ATTWARP_F16 ? grant_dynamic_lds(axis_maps_from_steps_kernel<__half>, lds, "axis_maps_from_steps")
+                                            : grant_dynamic_lds(axis_maps_from_steps_kernel<__hip_bfloat16>, lds, "axis_maps_from_steps"))
+    return rc;
   if (dtype == ATTWARP_F32) hipLaunchKernelGGL(axis_maps_from_steps_kernel<float>, grid, blk, lds, as_stream(stream), a);
   else if (dtype == ATTWARP_F16) hipLaunchKernelGGL(axis_maps_from_steps_kernel<__half>, grid, blk, lds, as_stream(stream), a);
   else hipLaunchKernelGGL(axis_maps_from_steps_kernel<__hip_bfloat16>, grid, blk, lds, as_stream(stream), a);

@@ -139,6 +139,19 @@ template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A launch gets at most 64 KB of dynamic LDS unless the kernel has been granted more (a CU of gfx950 has 160 KB).  The
+// per-axis kernels keep a whole axis in LDS (12 bytes per pixel of max(W, H): 64 KB is reached near 4800 pixels), so
+// their launchers call this first; it is idempotent and touches only the runtime's attribute of that one kernel.
+constexpr size_t LDS_DEFAULT_MAX = 64 * 1024, LDS_CU_BYTES = 160 * 1024;
+template <typename K>
+inline int grant_dynamic_lds(K kernel, size_t bytes, const char* what) {
+  if (bytes <= LDS_DEFAULT_MAX) return ATTWARP_OK;
+  if (bytes > LDS_CU_BYTES) return fail(ATTWARP_E_UNSUPPORTED, "%s: needs %zu bytes of LDS (> %zu)", what, bytes, LDS_CU_BYTES);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(ATTWARP_E_UNSUPPORTED, "%s: %zu bytes of dynamic LDS refused: %s", what, bytes, hipGetErrorString(e));
+  return ATTWARP_OK;
+}
+
 // ---- test / measurement overrides -----------------------------------------------
 // Kernel selection is automatic.  The A/B tools and the parity tests need to force a particular variant
 // (e.g. "the generic gather kernel") to check the variants against each other.  That exists ONLY in the tuning flavour

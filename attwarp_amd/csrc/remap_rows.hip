@@ -156,6 +156,9 @@ extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout,
     ATTWARP_REQUIRE(steps_out != steps_in, "warp_step_fused: steps_out must not alias steps_in");
     if (ntok % 4 != 0 || ntok > 3 * 4 * WAVE)
       return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok must be a multiple of 4 and <= 768");
+    // A writes steps_out as [n_rows, ntok]; the next step's M reads that buffer as [T, B, g * g]
+    if (steps_in && ntok != g * g)
+      return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok=%d must equal g*g=%d when both pieces are present", ntok, g * g);
     ex.attn.attn = rows; ex.attn.dtype = attn_dtype; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
     ex.attn.row_off = 0; ex.attn.starts = starts; ex.attn.starts_mod = starts_mod; ex.attn.max_start = kv_len - ntok;
     ex.attn.ntok = ntok; ex.attn.out = steps_out;

@@ -523,6 +523,10 @@ static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* e
   if constexpr (FUSED) {   // warp_step_kernel: map blocks, then the reduce blocks, then the resample blocks
     if (ex->nA > 0) lds = std::max(lds, attn_v4_lds_bytes<3>());
     if (ex->nM8 > 0) lds = std::max(lds, steps_maps_lds_bytes(std::max(ex->maps.W, ex->maps.H), ex->maps.g));
+    // (the one-launch step is for small images; an axis too long for the default 64 KB of LDS takes the separate launches)
+    if (lds > LDS_DEFAULT_MAX)
+      return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: %zu bytes of LDS per workgroup (> %zu): use the separate launches", lds,
+                  LDS_DEFAULT_MAX);
     const dim3 g((unsigned)((ex->nM8 + ex->nA8 + ex->nR8) * 8));
     if (p.NP == 1 && p.OVL == KO * NT)
       hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, true, true, MODE, SINGLE>), g, t, lds, st, p, *ex);

@@ -14,12 +14,22 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend: str | None = None, device_index: int | None = None, use_gpu: bool = True) -> Tuple[int, int, int]:
+def _grouped() -> bool:
+    """True when the collectives below have a process group to run on (any world size, including a one-rank group)."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def init(backend: str | None = None, device_index: int | None = None, use_gpu: bool = True,
+         force_group: bool = False) -> Tuple[int, int, int]:
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world_size, local_rank).  Single-process runs need no environment.
     ``device_index`` overrides the GPU (default: LOCAL_RANK) -- only used to smoke-test the N>1 code
     path on a one-GPU box with the gloo backend.  ``use_gpu=False`` (bench.py --dry-run, CPU tests) never touches
-    the GPU and defaults to gloo."""
+    the GPU and defaults to gloo.
+    ``force_group=True`` builds the process group even for WORLD_SIZE == 1 (rendezvous on 127.0.0.1 when MASTER_* are
+    absent): every helper below then runs its real collective -- on a one-GPU box that is a one-rank RCCL communicator,
+    which loads librccl, creates the communicator on the device and executes broadcast / all_gather / all_reduce /
+    barrier exactly as a rank of N would (``bench.py --gpus 1 --force-dist``, tests/test_gpu_parity.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -27,11 +37,27 @@ def init(backend: str | None = None, device_index: int | None = None, use_gpu: b
     have_gpu = use_gpu and torch.cuda.is_available()
     if have_gpu:
         torch.cuda.set_device(dev_idx)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_group) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if have_gpu else "gloo"
-        dist.init_process_group(backend)      # "nccl" is RCCL on ROCm; rendezvous from MASTER_ADDR/PORT
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        kw = {}
+        if backend == "nccl":                 # bind the communicator to this rank's GPU up front (no lazy device guess)
+            kw["device_id"] = torch.device("cuda", dev_idx)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)   # "nccl" is RCCL on ROCm
     return rank, world, local
+
+
+def shutdown():
+    """Destroy the process group if there is one (a forced one-rank group included)."""
+    if _grouped():
+        dist.destroy_process_group()
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -44,7 +70,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 def broadcast_module_weights(module: torch.nn.Module, src: int = 0) -> int:
     """Broadcast every parameter and buffer of ``module`` from ``src`` as ONE flat message.
     Returns the number of bytes moved (0 without a process group)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _grouped():
         return 0
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     if not tensors:
@@ -69,7 +95,7 @@ def broadcast_module_weights(module: torch.nn.Module, src: int = 0) -> int:
 def all_gather_counters(values: Dict[str, float]) -> Dict[str, list]:
     """Gather a few per-rank scalars (image counts, timings) on every rank."""
     keys = sorted(values)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _grouped():
         return {k: [float(values[k])] for k in keys}
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=dev)
@@ -79,7 +105,7 @@ def all_gather_counters(values: Dict[str, float]) -> Dict[str, list]:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _grouped():
         if dist.get_backend() == "nccl":
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
@@ -87,7 +113,7 @@ def barrier():
 
 
 def max_over_ranks(value: float) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _grouped():
         return float(value)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([float(value)], dtype=torch.float64, device=dev)

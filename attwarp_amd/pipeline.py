@@ -513,3 +513,210 @@ class OverlappedWarp:
         self.cur ^= 1
         self.k += 1
         return self.flush()
+
+
+class MaskChainStream:
+    """Steady-state form of :func:`warp_from_masks` -- the chain ``main_batched.py:243-287`` runs per image -- for a STREAM
+    of equally shaped batches.  The stages of the chain belong to different batches and are independent:
+
+        V(j)  revise_mask            masks[j] [B,24,24] float32       -> rev               llava.py:223-238
+        L(j)  x255, PIL LANCZOS      rev                              -> mota [B,H,W] u8   llava.py:192-196,243,253
+        P(j)  float64 marginals      mota                             -> axis sums         new_method.py:206-226
+        F(j)  cumsum / np.interp     axis sums                        -> maps              new_method.py:228-265
+        R(j)  uint8 cv2.remap        images[j] [B,H,W,3] + maps       -> outs[j]           new_method.py:268-271
+
+    V, L, P, F are bound by instruction issue (integer multiply-adds, float64 adds in numpy's orders) and by dependent
+    latency chains; R is the one that streams HBM.  Run back to back for every batch (``pattern="serial"``, the launches
+    of ``warp_from_masks`` on static buffers) nothing overlaps.  ``pattern``:
+
+        "branches": R(k) | P(k+1) -> F(k+1) | V(k+2) -> L(k+2) as three branches of one HIP graph, forked and joined every
+                    step (existing kernels, the hardware schedules workgroups of the branches side by side)
+        "fused":    R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as block ranges of ONE launch per step
+                    (attwarp_mask_chain_step), replayed as graphs of ``unroll`` steps
+        "auto":     "fused" when the shapes are eligible, else "branches"
+
+    ``images`` / ``masks`` are rings of n static buffers (lists of equal length; a single tensor = a ring of one): batch k
+    lives in slot k % n and is warped into ``outs[k % n]``.  Usage (d = pipeline depth: 2 for "branches", 4 for "fused"):
+
+        mc = MaskChainStream(images, masks, out_size=(500, 500))
+        masks[0 .. d-1] <- the first d batches;  mc.prime()
+        for k in 0 .. N-1:
+            images[k % n] <- batch k;  masks[(k + d) % n] <- mask of batch k + d (if any)
+            out = mc.step()                                   # -> outs[k % n]
+
+    Every step is bit-identical to ``warp_from_masks`` on its batch (same arithmetic per stage; the parity tests compare
+    both with the oracle)."""
+
+    PATTERNS = ("auto", "serial", "branches", "fused")
+
+    def __init__(self, images, masks, out_size=(500, 500), enhance_coe=10, kernel_size=3, transform="identity",
+                 exp_scale=1.0, exp_divisor=1.0, apply_inverse=False, mode: str = "cv2", pattern: str = "auto"):
+        if pattern not in self.PATTERNS:
+            raise ValueError(f"MaskChainStream: pattern must be one of {self.PATTERNS}")
+        self.images = list(images) if isinstance(images, (list, tuple)) else [images]
+        self.masks = list(masks) if isinstance(masks, (list, tuple)) else [masks]
+        if len(self.images) != len(self.masks) or not self.images:
+            raise ValueError("MaskChainStream: images and masks must be rings of the same length")
+        dev = require_gpu(*self.images, *self.masks)
+        img0, m0 = self.images[0], self.masks[0]
+        if any(i.dtype != torch.uint8 or i.dim() != 4 or i.shape != img0.shape or not i.is_contiguous() for i in self.images):
+            raise TypeError("MaskChainStream: images must be contiguous uint8 [B,H,W,C] tensors of one shape")
+        if any(m.dtype != torch.float32 or m.dim() != 3 or m.shape != m0.shape or not m.is_contiguous() for m in self.masks):
+            raise TypeError("MaskChainStream: masks must be contiguous float32 [B,n,n] tensors of one shape")
+        B, H, W, C = img0.shape
+        if m0.shape[0] != B or m0.shape[1] != m0.shape[2]:
+            raise ValueError("MaskChainStream: masks [B,n,n] must match the image batch")
+        if kernel_size % 2 != 1:
+            raise ValueError("MaskChainStream: kernel_size must be odd")
+        self.n = len(self.images)
+        self.B, self.H, self.W, self.C, self.g = B, H, W, C, int(m0.shape[1])
+        self.Ho, self.Wo = int(out_size[0]), int(out_size[1])
+        self.mode = mode
+        self.enhance_coe, self.kernel_size = float(enhance_coe), int(kernel_size)
+        self.transform = transform if transform in nm._KNOWN else "identity"
+        self.exp_scale, self.exp_divisor, self.apply_inverse = float(exp_scale), float(exp_divisor), bool(apply_inverse)
+        self._dev = dev
+        lib = _lib.load()
+        self.outs = [torch.empty(B, self.Ho, self.Wo, C, device=dev, dtype=torch.uint8) for _ in range(self.n)]
+        # parity-indexed intermediates (batch j uses slot j % 2 of each)
+        self.rev = [torch.empty(B, self.g, self.g, device=dev, dtype=torch.float32) for _ in (0, 1)]
+        self.mota = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in (0, 1)]
+        self.ws = [torch.empty(lib.attwarp_axis_sums_workspace_bytes(B, H, W), device=dev, dtype=torch.uint8) for _ in (0, 1)]
+        self.maps = [(torch.empty(B, self.Wo, device=dev, dtype=torch.float32),
+                      torch.empty(B, self.Ho, device=dev, dtype=torch.float32)) for _ in (0, 1)]
+        self._tmp = torch.empty(B, self.g, W, device=dev, dtype=torch.uint8)       # two-pass Lanczos forms only
+        self._tx = _tables.lanczos_tables(self.g, W, dev) if W != self.g else (None, None, 0)
+        self._ty = _tables.lanczos_tables(self.g, H, dev) if H != self.g else (None, None, 0)
+        self.k = 0
+        self._graphs = {}
+        self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        self.pattern = pattern
+        if pattern in ("auto", "fused"):
+            try:
+                self._fused_launch(0, dry=True)
+                self.pattern = "fused"
+            except (_lib.AttWarpError, AttributeError):
+                if pattern == "fused":
+                    raise
+                self.pattern = "branches"
+        self.depth = {"serial": 0, "branches": 2, "fused": 4}[self.pattern]
+
+    # ---- the stages on static buffers (same entry points as warp_from_masks) ----
+    def _V(self, j):
+        with torch.cuda.device(self._dev):
+            call("attwarp_mask_postproc", ptr(self.masks[j % self.n]), self.B, self.g, self.kernel_size, self.enhance_coe,
+                 ptr(self.rev[j & 1]), stream_ptr(self._dev))
+
+    def _L(self, j):
+        (bx, kx, ksx), (by, ky, ksy) = self._tx, self._ty
+        with torch.cuda.device(self._dev):
+            call("attwarp_mask_upsample_lanczos", ptr(self.rev[j & 1]), None, self.B, self.g, self.g, self.H, self.W,
+                 ptr(bx), ptr(kx), ksx, ptr(by), ptr(ky), ksy, ptr(self._tmp), ptr(self.mota[j & 1]), stream_ptr(self._dev))
+
+    def _PF(self, j):
+        mx, my = self.maps[j & 1]
+        with torch.cuda.device(self._dev):
+            call("attwarp_axis_maps_from_attention", ptr(self.mota[j & 1]), _lib.U8, self.B, self.H, self.W, self.Wo, self.Ho,
+                 _lib.TRANSFORM_IDS[self.transform], self.exp_scale, self.exp_divisor, int(self.apply_inverse), ptr(mx),
+                 ptr(my), ptr(self.ws[j & 1]), stream_ptr(self._dev))
+
+    def _R(self, j):
+        cu.remap_separable(self.images[j % self.n], *self.maps[j & 1], mode=self.mode, channels_last=True,
+                           out=self.outs[j % self.n])
+
+    def _fused_launch(self, k, dry=False):
+        """R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as ONE launch."""
+        raise _lib.AttWarpError("mask chain: the one-launch step is not built")
+
+    # ---- driving ----
+    def prime(self):
+        """Everything the first step expects to find done for the batches at ring positions k .. k+depth-1 (serial)."""
+        k = self.k
+        if self.pattern == "branches":      # step k runs R(k) | PF(k+1) | VL(k+2)
+            self._V(k); self._L(k); self._PF(k)
+            self._V(k + 1); self._L(k + 1)
+        elif self.pattern == "fused":       # step k runs R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4)
+            for j in (k, k + 1, k + 2):
+                self._V(j); self._L(j)
+                if j <= k + 1:
+                    self._PF(j)             # (P(k+1) included: its F runs again inside step k, same result)
+            self._V(k + 3)
+
+    def _one(self, k):
+        if self.pattern == "serial":
+            self._V(k); self._L(k); self._PF(k); self._R(k)
+        elif self.pattern == "fused":
+            self._fused_launch(k)
+        else:
+            raise RuntimeError("branches are only defined inside a capture")
+
+    def _capture(self, k, unroll):
+        g = torch.cuda.CUDAGraph()
+        main = torch.cuda.Stream(device=self._dev)
+        main.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(main):
+            with torch.cuda.graph(g, stream=main):
+                for u in range(unroll):
+                    if self.pattern == "branches":
+                        s1, s2 = self._side
+                        s1.wait_stream(main); s2.wait_stream(main)          # fork
+                        with torch.cuda.stream(s1):
+                            self._PF(k + 1)
+                        with torch.cuda.stream(s2):
+                            self._V(k + 2); self._L(k + 2)
+                        self._R(k)
+                        main.wait_stream(s1); main.wait_stream(s2)          # join
+                    else:
+                        self._one(k)
+                    k += 1
+        torch.cuda.current_stream().wait_stream(main)
+        return g
+
+    def _graph(self, unroll):
+        # the buffer indices of a step depend on k mod n (ring) and k mod 2 (parity)
+        import math
+        key = (self.k % math.lcm(2, self.n), unroll)
+        if key not in self._graphs:
+            self._graphs[key] = self._capture(self.k, unroll)
+        return self._graphs[key]
+
+    @property
+    def out(self) -> torch.Tensor:
+        """Output buffer of the most recent step."""
+        return self.outs[(self.k - 1) % self.n]
+
+    def step(self) -> torch.Tensor:
+        self._graph(1).replay()
+        self.k += 1
+        return self.out
+
+    def run(self, n: int, unroll: int = 8) -> torch.Tensor:
+        """n steps on the buffers as they are (steady-state measurement / a producer that stays ahead of the ring): graphs
+        of ``unroll`` steps (one host call each; a multiple of lcm(2, ring length), so the graph is re-used), then single
+        steps."""
+        import math
+        period = math.lcm(2, self.n)
+        unroll = max(period, unroll - unroll % period)
+        while n >= unroll:
+            self._graph(unroll).replay()
+            self.k += unroll
+            n -= unroll
+        for _ in range(n):
+            self.step()
+        return self.out
+
+    def reset(self):
+        self.k = 0
+
+    def drain(self) -> torch.Tensor:
+        """The last ``depth`` batches of a stream that ends (no further masks): the remaining stages, serially."""
+        k = self.k
+        if self.pattern == "branches":
+            self._R(k); self._PF(k + 1); self._R(k + 1)
+        elif self.pattern == "fused":
+            self._R(k)
+            self._PF(k + 1); self._R(k + 1)
+            self._PF(k + 2); self._R(k + 2)
+            self._L(k + 3); self._PF(k + 3); self._R(k + 3)
+        self.k += self.depth
+        return self.out

@@ -523,6 +523,9 @@ def main():
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="force the GPU index (smoke-testing the N>1 path on a one-GPU box with --dist-backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="build the process group even with --gpus 1 (a one-rank RCCL communicator): the run then goes through "
+                         "exactly the code of a rank of N -- RCCL init, weight broadcast, all_gather / all_reduce / barrier")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: rendezvous, weight broadcast, counters and the JSON line only (CPU tests)")
     args = ap.parse_args()
@@ -552,7 +555,8 @@ def main():
     import torch
     from attwarp_amd import dist as D, _lib
     rank, world, local = D.init(args.dist_backend if not args.dry_run else (args.dist_backend or "gloo"), args.device,
-                                use_gpu=not args.dry_run)
+                                use_gpu=not args.dry_run, force_group=args.force_dist)
+    grouped = world > 1 or args.force_dist
     if args.device is not None:
         local = args.device
     _lib.load()
@@ -561,7 +565,7 @@ def main():
     if args.dry_run:
         from attwarp_amd.model import MarginalNet
         net = MarginalNet(16, 24, 8)
-        nbytes = D.broadcast_module_weights(net, src=0) if world > 1 else 0
+        nbytes = D.broadcast_module_weights(net, src=0) if grouped else 0
         D.barrier()
         t0 = time.perf_counter()
         time.sleep(0.01 * (1 + rank))
@@ -574,8 +578,7 @@ def main():
                               "weights_broadcast": {"bytes": nbytes}, "per_rank_images": per["images"],
                               "ranks_seen": ranks_seen, "cpu_affinity_rank0": affinity,
                               "max_wall_s": wall, "config": {"workload": args.workload, "batch_per_gpu": B}}), flush=True)
-        if world > 1:
-            torch.distributed.destroy_process_group()
+        D.shutdown()
         return
 
     if not torch.cuda.is_available():
@@ -586,7 +589,7 @@ def main():
 
     # start-up collective of the multi-GPU path: one RCCL broadcast of MarginalNet weights (untimed)
     bcast = None
-    if world > 1:
+    if grouped:
         from attwarp_amd.model import MarginalNet
         net = MarginalNet(1024, 4096, 256).to(dev)
         torch.cuda.synchronize(); D.barrier()
@@ -654,7 +657,7 @@ def main():
         del ref_main
         nrot = step.nrot
     roof["calibration"] = calibration_of(step)
-    per_rank = D.all_gather_counters({"images_per_s": B * args.steps / wall_local})
+    per_rank = D.all_gather_counters({"images_per_s": B * args.steps / wall_local, "roofline_frac": roof["frac"]})
     ms_per_step = wall / args.steps * 1e3
     value = world * B * args.steps / wall
 
@@ -687,9 +690,16 @@ def main():
         result["stages_ms"] = {"attn_maps_kernel": round(st_ms[0], 4), "remap_rows_kernel": round(st_ms[1], 4)}
         del main_step
         torch.cuda.empty_cache()
-    if world > 1:
-        result["per_rank_images_per_s"] = [round(v, 1) for v in per_rank["images_per_s"]]
+    if grouped:
+        rates = per_rank["images_per_s"]
+        result["per_rank_images_per_s"] = [round(v, 1) for v in rates]
+        result["per_rank_roofline_frac"] = [round(v, 4) for v in per_rank["roofline_frac"]]
+        # `value` is N * B * K / the SLOWEST rank's time, and GPUs of one node differ by several per cent: this
+        # is the job's rate against N x the mean rank -- 1.0 means the ranks lose nothing to each other beyond their own
+        # spread -- so the curve can be read apart from which GPU the N=1 run happened to land on
+        result["scaling_efficiency_vs_rank_mean"] = round(value / (world * sum(rates) / len(rates)), 4)
         result["rccl_ranks_seen"] = ranks_seen
+        result["dist_backend"] = torch.distributed.get_backend()
         result["cpu_affinity_rank0"] = affinity
     if bcast:
         result["weights_broadcast"] = bcast
@@ -787,8 +797,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    D.shutdown()
 
 
 if __name__ == "__main__":

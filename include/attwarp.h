@@ -229,7 +229,9 @@ ATTWARP_API int attwarp_axis_maps_from_steps_t(const void* steps, int dtype, int
  * (steps_out != steps_in, map_*_next != map_*).  M (steps_in == NULL) and A (rows == NULL) are optional.  Same
  * arithmetic, bit for bit, as attwarp_remap_bilinear / attwarp_axis_maps_from_steps / attwarp_attn_reduce_step.
  * ATTWARP_E_UNSUPPORTED when the image shape takes the generic resample (rows wider than 4096 floats, unaligned
- * rows), ntok is not a multiple of 4 or > 768, or g > 32: use the three separate entry points then. */
+ * rows), ntok is not a multiple of 4 or > 768, g > 32, ntok != g*g while both steps_in and rows are given (steps_out of
+ * one call is steps_in [T,B,g*g] of the next), or an axis so long that the map construction needs more than 64 KB of
+ * LDS (max(W,H) > ~4800): use the three separate entry points then. */
 ATTWARP_API int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
                             int W_out, const float* map_x, const float* map_y, int mode,
                             int attn_dtype, const void* steps_in, int T, int g, const double* inv_x,

@@ -97,6 +97,57 @@ def test_attn_step_16bit_rows_every_alignment(dev, dt):
                 assert torch.equal(got, ref), (kv, off)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_attn_step_16bit_rows_full_three_vectors(dev, dt):
+    """ntok == 768 fills all three 256-token vectors of the four-tokens-per-lane kernel: lane 63 of the last vector owns
+    tokens 764..767, and with an odd slice start its fourth token would have to come from a chunk no vector loads (ADVICE r3:
+    the realigned load returned token 511 there).  Odd and even starts, odd and even row strides, with and without room
+    behind the slice, against the oracle (float16) / the one-token-per-lane kernel (bfloat16)."""
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(78)
+    heads, ntok = 8, 768
+    for kv in (800, 801, 771, 768):
+        B = 6
+        a = rng.random((B, heads, 1, kv), dtype=np.float32) ** 4
+        a /= a.sum(-1, keepdims=True)
+        starts = np.array([s0 % (kv - ntok + 1) for s0 in (0, 1, 2, 3, 31, 32)], np.int32)
+        for off in (0, 1):
+            buf = torch.zeros(off + a.size, device=dev, dtype=dt)
+            view = buf[off:].view(B, heads, 1, kv)
+            view.copy_(T(a, dev).to(dt))
+            got = ae.attn_reduce_step(view, T(starts, dev), ntok)
+            if dt == torch.float16:
+                assert np.array_equal(N(got), O.attn_reduce_step(N(view), starts, starts + ntok)), (kv, off)
+            else:
+                wide = torch.zeros(B, heads, 1, 2 * kv, device=dev, dtype=dt)
+                wide[..., ::2] = view
+                assert torch.equal(got, ae.attn_reduce_step(wide[..., ::2], T(starts, dev), ntok)), (kv, off)
+
+
+def test_axis_kernels_long_axis_dynamic_lds(dev):
+    """An axis of 8192 pixels needs ~100 KB of LDS per workgroup: above the 64 KB a launch gets by default, so the launchers
+    grant it to the kernel first.  Same results as the oracle chain; the stream entry points either grant it
+    (attn_reduce_and_maps) or refuse up front (warp_step_fused: small images only)."""
+    from attwarp_amd import pipeline
+    rng = np.random.default_rng(5)
+    B, L = 2, 8192
+    px = rng.random((B, 24), dtype=np.float32); px /= px.sum(-1, keepdims=True)
+    py = rng.random((B, 24), dtype=np.float32); py /= py.sum(-1, keepdims=True)
+    mx, my = pipeline.axis_maps_from_pdf(T(px, dev), T(py, dev), (L, L // 2))
+    Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, L // 2), 0))
+    Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, L), 0))
+    rx, ry = O.maps_from_cdf(Fx, Fy)
+    assert np.array_equal(N(mx), rx) and np.array_equal(N(my), ry)
+    steps = torch.rand(3, B, 576, device=dev)
+    sx, sy = pipeline.axis_maps_from_attention_steps(steps, (L, 64))
+    att = O.attn_finalize([N(s) for s in steps]).reshape(B, 1, 24, 24)
+    qx, qy = O.gt_marginals(att)
+    Gx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(qx, 64), 0))
+    Gy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(qy, L), 0))
+    gx, gy = O.maps_from_cdf(Gx, Gy)
+    assert np.array_equal(N(sx), gx) and np.array_equal(N(sy), gy)
+
+
 def test_attn_step_division_matches_ieee_everywhere(dev):
     """The float32 step kernel divides by (row sum + 1e-12) with a reciprocal shared by the row when the operands sit
     inside the box where v_div_scale does not rescale (attn.hip, SharedDiv) and with the plain IEEE division outside:
@@ -1774,6 +1825,60 @@ def test_bench_gpus2_self_launch_on_one_gpu(dev):
     assert d["bit_identical_to_serial"] is True and d["rccl_ranks_seen"] == [0, 1] and "also_eager" in d
 
 
+_RCCL_ONE_RANK = r"""
+import json, sys, torch
+sys.path.insert(0, sys.argv[1])
+from attwarp_amd import dist as D
+from attwarp_amd.model import MarginalNet
+import torch.distributed as dist
+rank, world, local = D.init(force_group=True)                  # WORLD_SIZE unset: a ONE-rank nccl (= RCCL) group on cuda:0
+assert (rank, world) == (0, 1) and dist.is_initialized() and dist.get_backend() == "nccl"
+net = MarginalNet(1024, 4096, 256).cuda()
+before = [p.detach().clone() for p in net.parameters()]
+nbytes = D.broadcast_module_weights(net, src=0)                # device branch: flat.to(dev) + dist.broadcast over RCCL
+same = all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+g = D.all_gather_counters({"images": 256.0, "rank": float(rank)})   # device-side all_gather
+m = D.max_over_ranks(3.25)                                     # device-side all_reduce(MAX)
+D.barrier()                                                    # barrier(device_ids=[...])
+torch.cuda.synchronize()
+print(json.dumps({"bytes": nbytes, "same": same, "gather": g, "max": m, "backend": dist.get_backend()}))
+D.shutdown()
+assert not dist.is_initialized()
+"""
+
+
+def test_rccl_one_rank_group_runs_every_collective(dev):
+    """the RCCL branches of dist.py (weight broadcast, all_gather, all_reduce, barrier) executed on the one GPU
+    this box has, as a one-rank communicator in its own process (the process group is process-global state)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"bytes": 11020296, "same": True, "gather": {"images": [256.0], "rank": [0.0]}, "max": 3.25, "backend": "nccl"}
+
+
+def test_bench_force_dist_goes_through_rccl_on_one_gpu(dev):
+    """`bench.py --gpus 1 --force-dist`: the code of a rank of N (RCCL init, weight broadcast, gathered counters, max over
+    ranks, barriers around the timed region) on the one GPU, with the fields the N > 1 line carries."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--workload", "336x256",
+                        "--steps", "8", "--warmup", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_ranks_seen"] == [0]
+    assert d["weights_broadcast"]["bytes"] == 11020296
+    assert len(d["per_rank_images_per_s"]) == 1 and len(d["per_rank_roofline_frac"]) == 1
+    assert abs(d["scaling_efficiency_vs_rank_mean"] - 1.0) < 1e-3 and d["bit_identical_to_serial"] is True
+
+
 def test_wide_rows_sorted_random_maps(dev):
     """Rows wider than one staged LDS row (4500 floats / bytes) with irregular but sorted maps: column tiles; same bits."""
     from attwarp_amd import checkpoint_utils as cu
@@ -2243,6 +2348,48 @@ def test_overlapped_warp_equals_serial(dev, pattern):
     buf = torch.empty(B, 2 * S, device=dev)
     with pytest.raises(ValueError):     # a strided view would be overwritten as if it were dense
         pipeline.axis_maps_from_attention_steps(steps, (S, S), maps_out=(buf[:, :S], torch.empty(B, S, device=dev)))
+
+
+@pytest.mark.parametrize("pattern", ["serial", "branches", "fused"])
+@pytest.mark.parametrize("case", [(3, 96, 80, 5), (2, 336, 500, 6), (5, 64, 64, 3)])
+def test_mask_chain_stream_equals_warp_from_masks(dev, pattern, case):
+    """pipeline.MaskChainStream (the main_batched chain as a batch stream) gives, for every batch of the stream, the bytes
+    of pipeline.warp_from_masks on that batch -- for every pattern, over a ring shorter and longer than the pipeline depth,
+    including the first (primed) and the last (drained) batches."""
+    from attwarp_amd import pipeline
+    B, S, So, n = case
+    g = torch.Generator(device=dev).manual_seed(S + n)
+    nb = 11
+    imgs = [torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(nb)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(nb)]
+    refs = [pipeline.warp_from_masks(imgs[j], msk[j], (So, So + 4)) for j in range(nb)]
+    ring_i = [torch.empty_like(imgs[0]) for _ in range(n)]
+    ring_m = [torch.empty_like(msk[0]) for _ in range(n)]
+    try:
+        mc = pipeline.MaskChainStream(ring_i, ring_m, (So, So + 4), pattern=pattern)
+    except _lib.AttWarpError:
+        assert pattern == "fused"
+        pytest.skip("one-launch chain step not eligible for this shape")
+    d = mc.depth
+    if n < d + 1:
+        pytest.skip("ring shorter than the pipeline")
+    for j in range(min(d, nb)):
+        ring_m[j % n].copy_(msk[j])
+    mc.prime()
+    got = []
+    for k in range(nb - d):
+        ring_i[k % n].copy_(imgs[k])
+        if k + d < nb:
+            ring_m[(k + d) % n].copy_(msk[k + d])
+        got.append(mc.step().clone())
+    # the tail: images of the last d batches, then the remaining stages serially
+    for k in range(nb - d, nb):
+        ring_i[k % n].copy_(imgs[k])
+    mc.drain()
+    for k in range(nb - d, nb):
+        got.append(mc.outs[k % n].clone())
+    for j in range(nb):
+        assert torch.equal(got[j], refs[j]), (pattern, j)
 
 
 def test_randomised_differential_runs(dev):

@@ -116,6 +116,9 @@ def test_stream_step_abi_validation_without_gpu(lib):
     assert fcall(steps_out=p) == -1                      # aliases steps_in
     assert fcall(map_x_next=p) == -1                     # aliases the maps being read
     assert fcall(kv_len=100) == -1
+    # steps_out of one call is steps_in [T,B,g*g] of the next: both pieces present => ntok must equal g*g
+    assert fcall(ntok=572) == -2 and b"g*g" in lib.attwarp_last_error()
+    assert fcall(ntok=572, steps_in=None) != -2 or b"g*g" not in lib.attwarp_last_error()   # A alone: any multiple of 4
 
 
 def test_probe_abi_validation_without_gpu(lib):
