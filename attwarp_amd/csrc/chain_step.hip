@@ -1,0 +1,264 @@
+// One step of the main_batched chain (AGW/main_batched.py:243-287: revise_mask -> x255 uint8 -> PIL LANCZOS -> float64
+// marginals -> cumsum CDF -> np.interp -> uint8 cv2.remap) for a STREAM of equally shaped batches, as ONE launch.
+//
+// The five stages of the chain depend on each other only through a batch's own intermediates, so in the steady state of
+// a stream they can belong to five different batches:
+//     R(k)    integer cv2 resample of batch k             remap_rows_u8i_block           HBM + LDS gathers + issue
+//     F(k+1)  profile -> CDF -> inverse maps of batch k+1  attention_maps_finalize_block  a latency chain (one lane's cumsum)
+//     P(k+2)  float64 marginals of the mask of batch k+2   profiles_u8_block              VALU (float64 adds in numpy's orders)
+//     L(k+3)  x255 + LANCZOS up-sampling, batch k+3        lanczos_strip_block            VALU (7 integer MADs per pixel)
+//     V(k+4)  revise_mask of batch k+4                     mask_postproc_block            a latency chain (576 numbers)
+// Launched one behind the other (what pipeline.warp_from_masks does for one batch) every boundary costs a drain and a
+// dispatch ramp and nothing overlaps although the stages are bound by different units; as branches of a HIP graph the
+// hardware overlaps them but pays five launches and a fork / join per step.  Here they are block ranges of one grid:
+// the F and V blocks first (the longest dependent chains start at once), then P, L and R blocks INTERLEAVED in
+// proportion to their counts -- the VALU-bound and the HBM-bound blocks are resident on every CU side by side for the
+// whole launch instead of one kind after the other -- in units of 8 consecutive blocks, so that block % 8 keeps naming
+// the XCD for the resample's XCD-aware order.  Every body is the stand-alone kernel's body (same arithmetic, bit for
+// bit); LDS is one pool sized for the largest of them.
+#include "common.hpp"
+#include "mask_blocks.hpp"
+#include "profiles_blocks.hpp"
+#include "remap_u8_block.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace attwarp {
+
+constexpr int CHAIN_NT = 256;
+constexpr int CHAIN_Q = 32;                 // octets per period of the P / L / R interleave
+constexpr int CHAIN_ORDER_DEFAULT = 0;      // see build_interleave
+constexpr int CHAIN_WAVES_DEFAULT = 6;      // waves per SIMD the register allocation leaves room for
+
+struct ChainStepArgs {
+  int B;
+  int nF8, nV8;                             // octets (8 blocks) of the F and V ranges
+  int nPfirst8;                             // octets of P laid out as one range right behind them (0: P is interleaved)
+  int nP, nL, nR;                           // blocks of P, L, R
+  // interleave: `periods` periods of CHAIN_Q octets, each holding q[t] octets of type t (0 = P, 1 = L, 2 = R) at the
+  // positions type[] says (rank[] = how many octets of the same type precede inside the period); then the leftovers of
+  // P, of L and of R one after the other
+  int periods, q[3], left8[3];
+  unsigned char type[CHAIN_Q], rank[CHAIN_Q];
+  // V: masks [B,g,g] -> rev_out
+  const float* masks; int g, ks; float coe; float* rev_out;
+  // L: la.mf (the rev of batch k+3) -> la.out (mota)
+  LanczosStripArgs la; int l_bx;            // l_bx = nstrips * nchunks blocks per image
+  // P: mota_in [B,H,W] -> col_out, ls_out
+  const uint8_t* mota_in; double* col_out; double* ls_out;
+  // F: fa.col / fa.ls -> fa.map_x / fa.map_y
+  MapsFinalizeArgs fa;
+  // R
+  u8k::Params rp;
+};
+
+template <int KI, int KD, int PD, int MINW>
+__global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const ChainStepArgs a, const PairwisePlan Pw,
+                                                                         const PairwisePlan Ph) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
+  const int blk = blockIdx.x, l8 = blk & 7;
+  int oct = blk >> 3;
+  if (oct < a.nF8) {
+    if (blk < 2 * a.B) attention_maps_finalize_block(Pw, Ph, a.fa, blk >> 1, blk & 1, reinterpret_cast<double*>(pool));
+    return;
+  }
+  oct -= a.nF8;
+  if (oct < a.nV8) {
+    const int j = oct * 8 + l8;
+    if (j < a.B) {
+      float* x = reinterpret_cast<float*>(pool);
+      double* red = reinterpret_cast<double*>(pool + 32 * 32 * sizeof(float));
+      float* fred = reinterpret_cast<float*>(red + CHAIN_NT / WAVE);
+      mask_postproc_block(a.masks, a.g, a.ks, a.coe, a.rev_out, j, x, red, fred);
+    }
+    return;
+  }
+  oct -= a.nV8;
+  int t, idx8;
+  const int inter = a.periods * CHAIN_Q;
+  if (oct < a.nPfirst8) {
+    t = 0; idx8 = oct;
+  } else if ((oct -= a.nPfirst8) < inter) {
+    const int per = oct / CHAIN_Q, pos = oct - per * CHAIN_Q;
+    t = a.type[pos];
+    idx8 = per * a.q[t] + a.rank[pos];
+  } else {
+    int r = oct - inter;
+    if (r < a.left8[0]) { t = 0; idx8 = a.periods * a.q[0] + r; }
+    else if ((r -= a.left8[0]) < a.left8[1]) { t = 1; idx8 = a.periods * a.q[1] + r; }
+    else { t = 2; idx8 = a.periods * a.q[2] + (r - a.left8[1]); }
+  }
+  const int j = idx8 * 8 + l8;
+  if (t == 0) {
+    if (j < a.nP) {
+      const int b = j / Pw.nleaves, leaf = j - b * Pw.nleaves;
+      profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw, a.col_out,
+                                            a.ls_out, leaf, b, pool);
+    }
+  } else if (t == 1) {
+    if (j < a.nL) {
+      const int b = j / a.l_bx, bx = j - b * a.l_bx;
+      lanczos_strip_block<8>(a.la, bx, b, pool);
+    }
+  } else {
+    if (j < a.nR) u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
+  }
+}
+
+// proportional interleave of three block kinds inside a period of CHAIN_Q octets (largest-remainder rounding, then an
+// even spread: position i goes to the kind that is furthest behind its share)
+// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved
+static void build_interleave(ChainStepArgs& a, int order) {
+  const bool sequential = order == 1;
+  int n8[3] = {(a.nP + 7) / 8, (a.nL + 7) / 8, (a.nR + 7) / 8};
+  a.nPfirst8 = 0;
+  if (order == 2) { a.nPfirst8 = n8[0]; n8[0] = 0; }
+  const long long tot = (long long)n8[0] + n8[1] + n8[2];
+  int q[3] = {0, 0, 0};
+  a.periods = 0;
+  if (!sequential && tot > 0) {
+    int used = 0;
+    double frac[3];
+    for (int t = 0; t < 3; ++t) {
+      const double share = (double)CHAIN_Q * n8[t] / (double)tot;
+      q[t] = (int)share;
+      if (n8[t] > 0 && q[t] == 0) q[t] = 1;
+      frac[t] = share - (int)share;
+      used += q[t];
+    }
+    while (used < CHAIN_Q) {
+      int best = 0;
+      for (int t = 1; t < 3; ++t) if (frac[t] > frac[best]) best = t;
+      ++q[best]; frac[best] = -1.0; ++used;
+    }
+    while (used > CHAIN_Q) {
+      int big = 0;
+      for (int t = 1; t < 3; ++t) if (q[t] > q[big]) big = t;
+      --q[big]; --used;
+    }
+    int periods = 0x7fffffff;
+    for (int t = 0; t < 3; ++t) if (q[t] > 0) periods = std::min(periods, n8[t] / q[t]);
+    a.periods = periods == 0x7fffffff ? 0 : periods;
+    int placed[3] = {0, 0, 0};
+    for (int i = 0; i < CHAIN_Q; ++i) {
+      int best = -1;
+      double lag = -1e30;
+      for (int t = 0; t < 3; ++t) {
+        if (placed[t] >= q[t]) continue;
+        const double l = (double)(i + 1) * q[t] / CHAIN_Q - placed[t];
+        if (l > lag) { lag = l; best = t; }
+      }
+      a.type[i] = (unsigned char)best;
+      a.rank[i] = (unsigned char)placed[best];
+      ++placed[best];
+    }
+  } else {
+    memset(a.type, 0, sizeof(a.type));
+    memset(a.rank, 0, sizeof(a.rank));
+  }
+  for (int t = 0; t < 3; ++t) {
+    a.q[t] = q[t];
+    a.left8[t] = n8[t] - a.periods * q[t];
+  }
+}
+
+template <int KI, int KD>
+static int launch_chain_kikd(const ChainStepArgs& a, const PairwisePlan& Pw, const PairwisePlan& Ph, size_t lds, unsigned grid,
+                             hipStream_t st) {
+  constexpr int PD = KI <= 2 ? 4 : 2;       // as launch_u8i_depth (remap_u8.hip)
+#ifdef ATTWARP_TUNING
+  if (tune(TUNE_CHAIN_WAVES) == 14 - CHAIN_WAVES_DEFAULT) {     // the other of {6, 8}
+    hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, 14 - CHAIN_WAVES_DEFAULT>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
+    return check_launch("mask_chain_step_kernel");
+  }
+#endif
+  hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, CHAIN_WAVES_DEFAULT>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
+  return check_launch("mask_chain_step_kernel");
+}
+template <int KI>
+static int launch_chain_ki(const ChainStepArgs& a, const PairwisePlan& Pw, const PairwisePlan& Ph, size_t lds, unsigned grid,
+                           int kd, hipStream_t st) {
+  if (kd <= 1) return launch_chain_kikd<KI, 1>(a, Pw, Ph, lds, grid, st);
+  if (kd == 2) return launch_chain_kikd<KI, 2>(a, Pw, Ph, lds, grid, st);
+  if (kd == 3) return launch_chain_kikd<KI, 3>(a, Pw, Ph, lds, grid, st);
+  return launch_chain_kikd<KI, 4>(a, Pw, Ph, lds, grid, st);
+}
+
+}  // namespace attwarp
+
+using namespace attwarp;
+
+extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int B, int C, int H, int W, int H_out, int W_out,
+                                       const float* map_x, const float* map_y,
+                                       const void* sums_in, float* map_x_next, float* map_y_next,
+                                       const uint8_t* mota_in, void* sums_out,
+                                       const float* rev_in, const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
+                                       const int32_t* bounds_y, const int32_t* kk_y, int ksize_y, uint8_t* mota_out,
+                                       const float* masks, int g, int kernel_size, float enhance_coe, float* rev_out,
+                                       void* stream) {
+  ATTWARP_REQUIRE(images && out && map_x && map_y, "mask_chain_step: null image / map pointer");
+  ATTWARP_REQUIRE(sums_in && map_x_next && map_y_next && mota_in && sums_out && rev_in && bounds_x && kk_x && bounds_y && kk_y &&
+                  mota_out && masks && rev_out, "mask_chain_step: null stage pointer");
+  ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0 && g > 0, "mask_chain_step: non-positive size");
+  ATTWARP_REQUIRE(kernel_size > 0 && (kernel_size & 1), "mask_chain_step: kernel_size must be odd (got %d)", kernel_size);
+  ATTWARP_REQUIRE(map_x_next != map_x && map_y_next != map_y, "mask_chain_step: the next maps must not alias the current ones");
+  ATTWARP_REQUIRE(sums_out != sums_in && mota_out != mota_in && rev_out != rev_in,
+                  "mask_chain_step: a stage's output buffer must not alias the buffer the next stage reads in the same launch");
+  if (g > 32 || kernel_size > 7 || B > 65535) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: g <= 32, kernel_size <= 7, B <= 65535");
+  // L: the column-strip kernel's conditions (attwarp_mask_upsample_lanczos)
+  if (W == g || H == g || W % 4 != 0 || ksize_x > 8 || ksize_y != 8 || (reinterpret_cast<uintptr_t>(mota_out) & 3u) != 0 ||
+      lanczos_strip_lds_bytes(g, g) > 48 * 1024)
+    return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: the mask up-sampling of this shape does not run on the column-strip kernel");
+  // P: the byte-packed profile kernel's conditions (launch_profiles_u8)
+  PairwisePlan Pw, Ph;
+  if (!pw_build(W, Pw) || !pw_build(H, Ph)) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: max(H,W) > 16384");
+  if ((reinterpret_cast<uintptr_t>(mota_in) & 3u) != 0)
+    return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: the mask buffers must be 4-byte aligned");
+  for (int j = 0; j < Pw.nleaves; ++j)
+    if (Pw.len[j] < 8 || Pw.len[j] % 4 != 0) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: W=%d does not split into leaves of multiples of 4", W);
+  ChainStepArgs a;
+  memset(&a, 0, sizeof(a));
+  // R: the integer cv2 kernel's conditions
+  if (!u8i_params(a.rp, images, out, ATTWARP_HWC, B, C, H, W, H_out, W_out, map_x, map_y))
+    return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: this image shape / alignment does not run on the integer cv2 resample");
+  a.B = B;
+  a.masks = masks; a.g = g; a.ks = kernel_size; a.coe = enhance_coe; a.rev_out = rev_out;
+  {   // L geometry: as attwarp_mask_upsample_lanczos
+    const int nstrips = (W + MASK_NT - 1) / MASK_NT;
+    long long nchunks = (4096 + (long long)B * nstrips - 1) / ((long long)B * nstrips);
+    const int max_chunks = (H + 63) / 64;
+    if (nchunks > max_chunks) nchunks = max_chunks;
+    if (nchunks < 1) nchunks = 1;
+    const int rows_per_chunk = (int)((H + nchunks - 1) / nchunks);
+    nchunks = (H + rows_per_chunk - 1) / rows_per_chunk;
+    a.la = LanczosStripArgs{rev_in, nullptr, g, g, H, W, bounds_x, kk_x, ksize_x, bounds_y, kk_y, (int)nchunks, rows_per_chunk, mota_out};
+    a.l_bx = nstrips * (int)nchunks;
+  }
+  a.mota_in = mota_in;
+  a.col_out = static_cast<double*>(sums_out);
+  a.ls_out = a.col_out + (size_t)B * W;
+  const double* col_in = static_cast<const double*>(sums_in);
+  a.fa = MapsFinalizeArgs{col_in, col_in + (size_t)B * W, H, W, W_out, H_out, ATTWARP_T_IDENTITY, 1.0, 1.0, 0, map_x_next, map_y_next,
+                          pw_depth(Pw)};
+  a.nF8 = (2 * B + 7) / 8;
+  a.nV8 = (B + 7) / 8;
+  a.nP = Pw.nleaves * B;
+  a.nL = a.l_bx * B;
+  a.nR = a.rp.nblocks;
+  build_interleave(a, tune(TUNE_CHAIN_SEQ) >= 0 ? tune(TUNE_CHAIN_SEQ) : CHAIN_ORDER_DEFAULT);
+  const long long octs = (long long)a.nF8 + a.nV8 + a.nPfirst8 + (long long)a.periods * CHAIN_Q + a.left8[0] + a.left8[1] + a.left8[2];
+  if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");
+  size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
+                        std::max(maps_finalize_lds_bytes(H, W, Pw, Ph), std::max(lanczos_strip_lds_bytes(g, g), mask_postproc_lds_bytes())));
+  if (lds > LDS_DEFAULT_MAX) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: %zu bytes of LDS per workgroup (> %zu)", lds, LDS_DEFAULT_MAX);
+  const int ki = ((a.rp.VL >> 2) + u8k::NT - 1) / u8k::NT, kd = ((a.rp.OVL >> 2) + u8k::NT - 1) / u8k::NT;
+  hipStream_t st = as_stream(stream);
+  const unsigned grid = (unsigned)(octs * 8);
+  switch (ki) {
+    case 1: return launch_chain_ki<1>(a, Pw, Ph, lds, grid, kd, st);
+    case 2: return launch_chain_ki<2>(a, Pw, Ph, lds, grid, kd, st);
+    case 3: return launch_chain_ki<3>(a, Pw, Ph, lds, grid, kd, st);
+    default: return launch_chain_ki<4>(a, Pw, Ph, lds, grid, kd, st);
+  }
+}

@@ -24,13 +24,12 @@
 //     to an LDS output row; the row is written to global as dwords, 256 contiguous bytes per wave
 //     instruction, after the NEXT row's barrier (the barrier between the two passes is the only one per row).
 #include "common.hpp"
+#include "remap_u8_block.hpp"
 
 namespace attwarp {
 
 namespace u8k {
 
-constexpr int NT = 256;
-constexpr int RMAX = 64;
 
 struct Taps {
   int i0, i1;
@@ -70,22 +69,6 @@ __device__ __forceinline__ float hblend_biased(float v0, float v1, float f) {
   return fadd(lerp_rn(v0, v1, f), 8388608.0f);   // round half to even: the low byte of (x + 2^23) for 0 <= x <= 255
 }
 
-struct Params {
-  const uint8_t* src;
-  uint8_t* dst;
-  const float* mx;
-  const float* my;
-  int H, W, Ho, Wo;
-  int NP, CS;
-  int row_len, orow_len;   // bytes per plane row
-  int VL, OVL;             // bytes per virtual row (all planes)
-  long long img_stride, plane_stride, oimg_stride, oplane_stride;
-  int R, nblk, nblocks;
-  int wpi;   // integer cv2 kernel: workgroups per image; workgroup j owns row blocks j, j + wpi, ... (else == nblk)
-  int grp;   // integer cv2 kernel, block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g
-  int ntiles;              // TILED: column tiles per row (each KO*NT output bytes), else 1
-  int map_div;             // maps belong to image b / map_div (planes of a planar image dispatched as images)
-};
 
 // KI = dwords of the source row per thread, KO = output bytes per thread, KS = output dwords per thread
 // TILED (rows wider than 4096 bytes, one plane): a workgroup owns a column tile of KO*NT output bytes of its rows,
@@ -324,199 +307,11 @@ static int launch_ko(const Params& p, hipStream_t st) {
   }
 }
 
-// ---- CV2 mode, integer form (rows of <= 4096 bytes) ----------------------------------------------------------------
-// OpenCV's uint8 path is exact integer arithmetic (see the header of this file), so it does not need the float
-// pipeline above.  This kernel keeps the same decomposition (workgroup = R output rows of one image, vertical pass
-// into LDS, horizontal gather) but
-//   * vertical: a thread owns dwords of the two source rows; bytes (0,2) and (1,3) of a dword are two packed 16-bit
-//     pairs, v = (32-ky)*top + ky*bottom <= 8160 is one v_pk_mul_lo_u16 + one v_pk_mad_u16 per pair -- 10 VALU
-//     instructions per 4 source bytes (the float form: 4 + 4 conversions and 12 lerp operations) -- and the LDS row holds
-//     16-bit values (half the LDS bytes), in the order [e0, e2, e1, e3] per group of 4 (no re-interleaving: the tap
-//     offsets know the order);
-//   * horizontal: a lane produces 4 CONSECUTIVE output bytes: 8 ds_read_u16, per byte
-//     ((32 - kx)*v0 + kx*v1 + 512) >> 10 (one v_dot2_u32_u16 on the tap pair), packed and stored as one dword -- no LDS
-//     output row, no flush pass;
-//     tap 1 is always "tap 0's pixel + 1" with kx forced to 0 where OpenCV clamps both taps to the same pixel (integer
-//     arithmetic: a zero weight is exact), so the clamped cases need no second offset logic.
-// Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
-// Output dwords are written once and never read by this kernel: nontemporal stores (cache-policy bit 1 of the buffer
-// instruction) leave L2 / Infinity Cache to the source rows.  Measured in one process (tools/u8_nt_probe.py, B=256):
-// 336 -> 500 95.8 -> 76.2 us, 1024 -> 1024 343.6 -> 336.4, 1024 -> 500 156.0 -> 155.0; nontemporal LOADS lose
-// everywhere (the row shared with the neighbouring output row then misses: 1024 -> 1024 459.7 us).  The float32 kernels
-// do not respond to either (docs/experiments.md).
-constexpr int U8I_STORE_NT = 2;
-constexpr int U8I_VLP = 4096 + 16;      // u16 elements per LDS row buffer: rows of <= 4096 bytes + one pixel of slack
-
+// ---- CV2 mode, integer form (rows of <= 4096 bytes): body remap_rows_u8i_block (remap_u8_block.hpp) ----
 template <int KI, int KD, bool HWC, int PD>
 __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_my = smem;                                               // RMAX
-  // two row buffers a COMPILE-TIME distance apart: tap offsets then fold into the 16-bit offset field of the LDS
-  // instructions (with a run-time stride every one of the 8 reads per output dword cost a v_add_u32 for its address)
-  uint16_t* vrow0 = reinterpret_cast<uint16_t*>(smem + RMAX);
-  uint16_t* vrow1 = vrow0 + U8I_VLP;
-  const int tid = threadIdx.x;
-  int bid = blockIdx.x;
-  {     // block order, as in remap_rows_kernel.hpp
-    const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    if (p.grp == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
-    else if (p.grp >= 2) {
-      const int g = p.grp, per = 8 * g, grp = idx / g, within = idx - grp * g, cand = grp * per + xcd * g + within;
-      bid = cand < (n / per) * per ? cand : bid;
-    }
-  }
-  const int b = bid / p.wpi, rb0 = bid - b * p.wpi;
-  // per-image buffer descriptors (block uniform; images are < 2 GiB: plane_stride * NP is checked by the host)
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(p.src + (long long)b * p.img_stride), 0, (int)p.img_stride, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)b * p.oimg_stride, 0,
-                                                                        (int)p.oimg_stride, 0x00020000);
-
-  // source dwords this thread owns (clamped: padding lanes repeat the last dword)
-  unsigned goff[KI];                // byte offset inside the image (row 0): unsigned, so the loads take the SGPR-base form
-  int voff[KI];                     // u16 index in the LDS row
-  {
-    const int dpr = p.row_len >> 2, nd = p.VL >> 2;
-#pragma unroll
-    for (int k = 0; k < KI; ++k) {
-      const int d = min(tid + NT * k, nd - 1);
-      const int pl = HWC ? 0 : d / dpr;
-      goff[k] = (unsigned)(pl * p.plane_stride) + 4u * (unsigned)(d - pl * dpr);
-      voff[k] = 4 * d;
-    }
-  }
-  // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
-  // order) and kx
-  unsigned t0[KD][4], t1[KD][4], wpk[KD][4];    // wpk: (32 - kx) | kx << 16, the two weights of v_dot2_u32_u16
-  int soff[KD];
-  {
-    const int dpo = p.orow_len >> 2, ndo = p.OVL >> 2;
-    // u16 element e of the row lives at position [e0, e2, e1, e3] of its group of four (the vertical pass produces the
-    // pairs (0,2) and (1,3) of a source dword; no re-interleaving).  (Swapping the two dwords of a group in every other
-    // 64-dword window, so that lanes l and l + 32 of a slope-1 gather use different banks, was measured: no effect --
-    // the kernel is bound by VALU issue -- and cost two selects per source dword; taken out.)
-    // t0 / t1 hold ABSOLUTE LDS addresses (of the tap in row buffer 0): as offsets from the buffer pointer every one of
-    // the 8 reads per output dword paid a v_add_u32 with the (link-time) base of the dynamic LDS block.
-    const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint16_t*)vrow0;
-    auto lds_off = [vbase](unsigned e) -> unsigned { return vbase + 2u * ((e & ~3u) | (((e & 1u) << 1) | ((e >> 1) & 1u))); };
-#pragma unroll
-    for (int k = 0; k < KD; ++k) {
-      const int d = min(tid + NT * k, ndo - 1);
-      const int pl = HWC ? 0 : d / dpo;
-      const int r0 = 4 * (d - pl * dpo);                            // first byte of the dword inside its plane row
-      soff[k] = (int)(pl * p.oplane_stride) + r0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = r0 + j, x = r / p.CS, c = r - x * p.CS;
-        const float m = p.mx[(long long)b * p.Wo + x];
-        const int q = cv_round_q5(m);                               // cvRound
-        const int i = q >> 5;
-        const int i0 = min(max(i, 0), p.W - 1), i1 = min(max(i + 1, 0), p.W - 1);
-        const unsigned kx = (i0 == i1) ? 0u : (unsigned)(q & 31);  // both taps on one pixel: weight of tap 1 is moot
-        const unsigned e0 = (unsigned)(pl * p.row_len + i0 * p.CS + c);
-        const unsigned e1 = (i0 == i1) ? e0 : (unsigned)(pl * p.row_len + i1 * p.CS + c);
-        t0[k][j] = lds_off(e0);
-        t1[k][j] = lds_off(e1);
-        // opaque, or address-mode sinking moves the "+ base" back in front of every read of the row loop
-        asm volatile("" : "+v"(t0[k][j]), "+v"(t1[k][j]));
-        wpk[k][j] = (32u - kx) | (kx << 16);
-      }
-    }
-  }
-
-  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-  typedef __attribute__((address_space(3))) const uint16_t lds_cu16;
-  auto row_taps = [&](float m, int& i0, int& i1, unsigned& ky) {
-    const int q = cv_round_q5(m);
-    const int i = q >> 5;
-    i0 = min(max(i, 0), p.H - 1);
-    i1 = min(max(i + 1, 0), p.H - 1);
-    ky = (unsigned)(q & 31);
-  };
-  int ci0, ci1;
-  // PD register sets: the two source rows of output row q sit in set q % PD, requested PD rows ahead
-  unsigned ky[PD];                  // their vertical fractions
-  uint32_t A[PD][KI], C[PD][KI];
-  int y0 = 0, nrows = 0;
-  /* buffer loads / stores: image base in an SGPR descriptor, row offset in the scalar offset, the thread's dword in the
-     32-bit vector offset -- no per-access 64-bit address arithmetic (a v_lshl_add_u64 per load and store before) */
-#define ATTWARP_U8I_FETCH(AX, CX)                                                                      \
-  {                                                                                                    \
-    const int ra_ = ci0 * p.row_len, rc_ = ci1 * p.row_len;      /* block uniform: SGPRs */              \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
-      AX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], ra_, 0);                         \
-      CX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], rc_, 0);                         \
-    }                                                                                                  \
-  }
-  /* One output row.  Its two source rows were requested PD rows ahead (a workgroup's own row takes about a microsecond
-     with eight of them sharing a CU, less than the loaded HBM latency: with PD = 1 the kernel waits for memory in
-     every row); the vertical pass writes LDS row buffer q & 1, one barrier, the horizontal pass gathers from it.
-     Horizontal pass: (32 - kx) * v0 + kx * v1 + 512 is one v_dot2_u32_u16 on the tap pair.  Measured and dropped: both
-     taps into one register with ds_read_u16_d16 / _d16_hi -- on this part (SRAM ECC) a d16 load clears the other half
-     instead of preserving it. */
-#define ATTWARP_U8I_ROW(q_, vbuf, VOFF, AX, CX, KY)                                                    \
-  {                                                                                                    \
-    const unsigned w1_ = KY, w0_ = 32u - KY;                                                           \
-    const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
-      const uint32_t a02_ = AX[k] & 0x00ff00ffu, a13_ = (AX[k] >> 8) & 0x00ff00ffu;                      \
-      const uint32_t c02_ = CX[k] & 0x00ff00ffu, c13_ = (CX[k] >> 8) & 0x00ff00ffu;                      \
-      const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
-      const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
-      uint2 st_;                                                                                       \
-      st_.x = __builtin_bit_cast(uint32_t, v02_);                                                      \
-      st_.y = __builtin_bit_cast(uint32_t, v13_);                                                      \
-      *reinterpret_cast<uint2*>((vbuf) + voff[k]) = st_;                                               \
-    }                                                                                                  \
-    if ((q_) + PD < nrows) { /* this register set is free: request the rows of output row q + PD */   \
-      row_taps(s_my[(q_) + PD], ci0, ci1, KY);                                                         \
-      ATTWARP_U8I_FETCH(AX, CX)                                                                        \
-    }                                                                                                  \
-    __syncthreads();                                                                                   \
-    const int orow_ = (y0 + (q_)) * p.orow_len;                                                        \
-    _Pragma("unroll") for (int k = 0; k < KD; ++k) {                                                    \
-      unsigned v0_[4], v1_[4];                                                                         \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
-        v0_[j] = *(lds_cu16*)(uintptr_t)(t0[k][j] + (VOFF));                                           \
-        v1_[j] = *(lds_cu16*)(uintptr_t)(t1[k][j] + (VOFF));                                           \
-      }                                                                                                \
-      unsigned o_ = 0;                                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {   /* (32 - kx) * v0 + kx * v1 + 512: one v_dot2_u32_u16 */ \
-        const us2 pr_ = {(unsigned short)v0_[j], (unsigned short)v1_[j]};                               \
-        const unsigned in_ = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u, false); \
-        o_ |= (in_ >> 10) << (8 * j);                                                                  \
-      }                                                                                                \
-      if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, U8I_STORE_NT); \
-    }                                                                                                  \
-  }
-  // Row blocks of this workgroup: rb0, rb0 + wpi, ... -- the column-tap prologue above (a cvRound and two integer
-  // divisions per output byte) is paid once for all of them, while the workgroups of an image sweep it together as
-  // one compact window of rows (DRAM page locality), as in remap_rows_kernel.hpp.
-  for (int rb = rb0; rb < p.nblk; rb += p.wpi) {
-    y0 = rb * p.R;
-    nrows = min(y0 + p.R, p.Ho) - y0;
-    if (rb != rb0) __syncthreads();          // the previous block's last gather is done with s_my and the row buffers
-    if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < PD; ++u)
-      if (u < nrows) {
-        row_taps(s_my[u], ci0, ci1, ky[u]);
-        ATTWARP_U8I_FETCH(A[u], C[u])
-      }
-    int q = 0;
-    for (; q + 3 < nrows; q += 4) {          // unrolled by 4: LDS buffer q & 1 and register set q % PD are compile-time
-      ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
-      ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
-      ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
-      ATTWARP_U8I_ROW(q + 3, vrow1, 2u * U8I_VLP, A[3 % PD], C[3 % PD], ky[3 % PD])
-    }
-    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
-    if (q + 1 < nrows) ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
-    if (q + 2 < nrows) ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
-  }
-#undef ATTWARP_U8I_ROW
-#undef ATTWARP_U8I_FETCH
+  remap_rows_u8i_block<KI, KD, HWC, PD>(p, blockIdx.x, smem);
 }
 
 template <int KI, int PD>
@@ -572,12 +367,12 @@ static int launch_mode(const Params& p, bool tiled, hipStream_t st) {
 
 }  // namespace u8k
 
-// Returns via *handled whether the uint8 fast path took the request.
-int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
-                         const float* mx, const float* my, int mode, hipStream_t st, bool* handled) {
-  *handled = false;
-  if (tune(TUNE_REMAP_VARIANT) == 1) return ATTWARP_OK;
-  u8k::Params p;
+// Launch geometry of the uint8 staged kernels.  Returns false when the request takes the generic gather kernel;
+// otherwise fills p and says which family serves it (*tiled: column tiles of the float pipeline; *integer_form: the
+// integer cv2 kernel).
+static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
+                    const float* mx, const float* my, int mode, bool* tiled_out, bool* integer_out) {
+  if (tune(TUNE_REMAP_VARIANT) == 1) return false;
   p.src = src; p.dst = dst; p.mx = mx; p.my = my;
   p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
   if (layout == ATTWARP_HWC) { p.NP = 1; p.CS = C; } else { p.NP = C; p.CS = 1; }
@@ -585,21 +380,21 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.orow_len = Wo * p.CS;
   const long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
   // dword loads / stores: every plane row must start on a 4-byte boundary, both sides
-  if (p.row_len % 4 != 0 || p.orow_len % 4 != 0) return ATTWARP_OK;
-  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0) return ATTWARP_OK;
+  if (p.row_len % 4 != 0 || p.orow_len % 4 != 0) return false;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0) return false;
   if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
                             : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0)
-    return ATTWARP_OK;
+    return false;
   p.map_div = 1;
   p.ntiles = 1;
   p.grp = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : 0;
   // up to 4096 bytes per staged row (16-bit LDS offsets); wider rows run in column tiles, planar ones plane by plane
   const bool tiled = VL > 4096 || OVL > 4096;
   if (tiled) {
-    if (tune(TUNE_REMAP_TILED) == 0) return ATTWARP_OK;
+    if (tune(TUNE_REMAP_TILED) == 0) return false;
     if ((long long)p.row_len > 2147483647LL / 8 || (long long)p.orow_len > 2147483647LL / 8 ||
         (long long)B * C > 2147483647LL)
-      return ATTWARP_OK;
+      return false;
     if (p.NP > 1) {          // every plane becomes a one-channel image served by the maps of image b / C
       p.map_div = C;
       B *= C;
@@ -615,7 +410,7 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
   p.oplane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)Ho * Wo;
   p.img_stride = (long long)H * W * C;
   p.oimg_stride = (long long)Ho * Wo * C;
-  if (p.plane_stride * p.NP > 2147483647LL || p.oplane_stride * p.NP > 2147483647LL) return ATTWARP_OK;
+  if (p.plane_stride * p.NP > 2147483647LL || p.oplane_stride * p.NP > 2147483647LL) return false;
   int R = (OVL >= 2048) ? 32 : 16;   // measured: 1024x1024x3 R=32 7 % faster than 16, 336->500 equal
   constexpr int TILE_KO = 8;                   // as in launch_mode
   // (2048x2048x3 uint8, B=64: tiled R=32 0.51 ms, R=16 0.55, R=8 0.67; generic gather kernel 2.32 ms)
@@ -644,12 +439,29 @@ int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, in
     p.wpi = (p.nblk + cpw - 1) / cpw;
   }
   const long long nb = (long long)p.wpi * B * p.ntiles;
-  if (nb > 2147483647LL) return ATTWARP_OK;
+  if (nb > 2147483647LL) return false;
   p.nblocks = (int)nb;
-  *handled = true;
+  *tiled_out = tiled;
+  *integer_out = integer_form;
+  return true;
+}
+
+// Returns via *handled whether the uint8 fast path took the request.
+int launch_remap_rows_u8(const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
+                         const float* mx, const float* my, int mode, hipStream_t st, bool* handled) {
+  u8k::Params p;
+  bool tiled = false, integer_form = false;
+  *handled = plan_u8(p, src, dst, layout, B, C, H, W, Ho, Wo, mx, my, mode, &tiled, &integer_form);
+  if (!*handled) return ATTWARP_OK;
   if (integer_form) return u8k::launch_u8i(p, st);
   if (mode == ATTWARP_CV2) return u8k::launch_mode<ATTWARP_CV2>(p, tiled, st);
   return u8k::launch_mode<ATTWARP_EXACT>(p, tiled, st);
+}
+
+bool u8i_params(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
+                const float* mx, const float* my) {
+  bool tiled = false, integer_form = false;
+  return plan_u8(p, src, dst, layout, B, C, H, W, Ho, Wo, mx, my, ATTWARP_CV2, &tiled, &integer_form) && integer_form;
 }
 
 }  // namespace attwarp

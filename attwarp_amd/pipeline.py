@@ -234,6 +234,69 @@ def clip_preprocess(images_u8: torch.Tensor, size: int = 336, dtype: torch.dtype
     return out
 
 
+def random_clip_vision_tower(device, dtype: torch.dtype = torch.float16, seed: int = 0):
+    """The architecture of LLaVA-1.5's vision tower (openai/clip-vit-large-patch14-336: ViT-L/14 at 336 x 336, 24 layers,
+    hidden 1024, 16 heads, MLP 4096) from ``transformers`` with SEEDED RANDOM weights -- the checkpoint, the ``llava``
+    package and TextVQA are absent here (no network), so BASELINE configs[4] can be closed as a data flow with the right
+    shapes and dtypes, not as an accuracy number.  Stock PyTorch-ROCm ops (MFMA-class library GEMMs): outside the
+    hand-kernel scope, like MarginalNet's convolutions (SURVEY 8d "bounding roofline")."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    cfg = CLIPVisionConfig(image_size=336, patch_size=14, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                           intermediate_size=4096, projection_dim=768)
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        tower = CLIPVisionModel(cfg)
+    finally:
+        torch.random.set_rng_state(gen_state)
+    return tower.to(device=device, dtype=dtype).eval()
+
+
+@torch.no_grad()
+def vision_tower_features(tower, pixel_values: torch.Tensor, select_layer: int = -2) -> torch.Tensor:
+    """LLaVA-1.5's feature selection (``mm_vision_select_layer = -2``, ``mm_vision_select_feature = "patch"``; the reference
+    feeds the warped image through it at AGW/evaluate_accuracy.py:157-178): pixel_values [B,3,336,336] ->
+    ``hidden_states[-2][:, 1:]`` [B,576,1024] -> the token map [B,1024,24,24] MarginalNet consumes (MN/model.py:55-68)."""
+    out = tower(pixel_values=pixel_values.to(next(tower.parameters()).dtype), output_hidden_states=True)
+    tok = out.hidden_states[select_layer][:, 1:]
+    B, n, d = tok.shape
+    g = int(round(n ** 0.5))
+    return tok.transpose(1, 2).reshape(B, d, g, g)
+
+
+@torch.no_grad()
+def config5_chain(tower, net, images_u8: torch.Tensor, txt_tok: torch.Tensor, txt_mask: torch.Tensor, out_size=(500, 500),
+                  mode: str = "cv2", record=None):
+    """BASELINE configs[4] as a device-resident data flow (nothing leaves the GPU, no PNG round trip):
+
+        images_u8 [B,H,W,3] -> CLIP tensor -> vision tower -> token map [B,1024,24,24]                  (the model's own pass)
+          -> MarginalNet(1024, 4096, 256)(token map, text tokens) -> px, py [B,24]                     MN/model.py:55-95
+          -> A8 + A9 + A11 -> A12: warp of the uint8 images to ``out_size``                             MN/trainer.py:285-289
+          -> CLIP tensor of the WARPED images [B,3,336,336] -> vision tower -> features [B,1024,24,24]  evaluate_accuracy.py:157-178
+
+    ``record``: a callable ``record(name)`` invoked after each leg (bench.py records HIP events there).  Returns a dict of
+    every intermediate.  Parity of each hand-written leg is pinned elsewhere (clip_preprocess, MarginalNet tail, the warp);
+    TextVQA accuracy parity is unobtainable here: LLaVA-1.5-7B's weights, the ``llava`` package and the dataset are absent."""
+    rec = record or (lambda name: None)
+    dtype = next(tower.parameters()).dtype
+    pix0 = clip_preprocess(images_u8, 336, dtype, pad_to_square=True)
+    rec("clip_tensor_in")
+    fmap = vision_tower_features(tower, pix0)
+    rec("tower_in")
+    px, py = net(fmap, GRID, GRID, txt_tok, txt_mask)
+    rec("marginalnet")
+    B, H, W, _ = images_u8.shape
+    mx, my = axis_maps_from_pdf(px, py, (H, W), out_size)
+    warped = cu.remap_separable(images_u8, mx, my, mode=mode, channels_last=True)
+    rec("warp")
+    pix1 = clip_preprocess(warped, 336, dtype, pad_to_square=True)
+    rec("clip_tensor_warped")
+    feats = vision_tower_features(tower, pix1)
+    rec("tower_warped")
+    return {"pixel_values_in": pix0, "token_map": fmap, "px": px, "py": py, "map_x": mx, "map_y": my, "warped": warped,
+            "pixel_values_warped": pix1, "features_warped": feats}
+
+
 def capture_step(fn, *args, warmup: int = 2):
     """Capture ``fn(*args)`` (a function made only of this package's launches on static tensors) into a
     HIP graph; returns (graph, output).  ``graph.replay()`` re-runs the step with one host call."""
@@ -625,8 +688,25 @@ class MaskChainStream:
                            out=self.outs[j % self.n])
 
     def _fused_launch(self, k, dry=False):
-        """R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as ONE launch."""
-        raise _lib.AttWarpError("mask chain: the one-launch step is not built")
+        """R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as ONE launch (attwarp_mask_chain_step).  ``dry``: the eligibility
+        trial of the constructor -- the stages write the buffers of the parities they would write in step k, from whatever
+        the inputs hold; prime() overwrites all of it."""
+        if self.mode != "cv2" or self.transform != "identity" or self.apply_inverse:
+            raise _lib.AttWarpError("mask chain step: cv2 mode and the identity transform only (what main_batched.py passes)")
+        (bx, kx, ksx), (by, ky, ksy) = self._tx, self._ty
+        if bx is None or by is None:
+            raise _lib.AttWarpError("mask chain step: the mask must be up-sampled on both axes")
+        p, q = k & 1, (k + 1) & 1
+        mx, my = self.maps[p]
+        nx, ny = self.maps[q]
+        with torch.cuda.device(self._dev):
+            call("attwarp_mask_chain_step", ptr(self.images[k % self.n]), ptr(self.outs[k % self.n]), self.B, self.C, self.H,
+                 self.W, self.Ho, self.Wo, ptr(mx), ptr(my),
+                 ptr(self.ws[q]), ptr(nx), ptr(ny),                      # F(k+1)
+                 ptr(self.mota[p]), ptr(self.ws[p]),                      # P(k+2)
+                 ptr(self.rev[q]), ptr(bx), ptr(kx), ksx, ptr(by), ptr(ky), ksy, ptr(self.mota[q]),   # L(k+3)
+                 ptr(self.masks[(k + 4) % self.n]), self.g, self.kernel_size, self.enhance_coe, ptr(self.rev[p]),   # V(k+4)
+                 stream_ptr(self._dev))
 
     # ---- driving ----
     def prime(self):
@@ -692,11 +772,9 @@ class MaskChainStream:
 
     def run(self, n: int, unroll: int = 8) -> torch.Tensor:
         """n steps on the buffers as they are (steady-state measurement / a producer that stays ahead of the ring): graphs
-        of ``unroll`` steps (one host call each; a multiple of lcm(2, ring length), so the graph is re-used), then single
-        steps."""
-        import math
-        period = math.lcm(2, self.n)
-        unroll = max(period, unroll - unroll % period)
+        of ``unroll`` steps (one host call each), then single steps.  A graph is keyed by the ring position it starts at
+        (mod lcm(2, ring length)), so a stream that is reset() and run again replays the graphs of the first pass."""
+        unroll = max(2, unroll - unroll % 2)
         while n >= unroll:
             self._graph(unroll).replay()
             self.k += unroll

@@ -510,16 +510,187 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn
     return res, wall, wall_local, st, ow
 
 
+def traffic_note(roof):
+    """`traffic` of a secondary line: a committed counter pass if profiles/pmc_traffic.json holds one for exactly this
+    variant, else null WITH the reason (no silent nulls)."""
+    if roof.get("traffic") is None:
+        roof["traffic_source"] = "null: no rocprofv3 --pmc pass committed for this variant (profiles/pmc_traffic.json)"
+    else:
+        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on an earlier lease)"
+    return roof
+
+
+def _event_ms(torch, fn, n, warm=3):
+    """Median duration of fn() over n runs, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def leg_main_batched(dev, torch, pipeline, K):
+    """The chain the reference's batched driver runs per image (AGW/main_batched.py:243-287, BATCH_SIZE = 32 at :42, 500 x 500
+    output at :62-63): revise_mask -> x255 uint8 -> PIL LANCZOS -> float64 marginals -> CDF -> np.interp -> uint8 cv2.remap,
+    on uint8 [B,S,S,3] images + [B,24,24] float32 attention maps.  Per case: `serial` = pipeline.warp_from_masks (five
+    dependent launches per batch, eager), `stream` = pipeline.MaskChainStream (the same five stages on five consecutive
+    batches, graph replay), both over a ring of independent batches of >= 2 GiB (every step streams from HBM), exactly K
+    steps in the timed region.  Chain-level algorithmic bytes per image: S*S mask written + S*S mask read by
+    the marginals + 3*S*S image read + 3*So*So written."""
+    out = {"workload": "uint8 images [B,S,S,3] + attention maps [B,24,24] -> main_batched chain -> [B,500,500,3] uint8, mode=cv2, "
+                       "transform=identity (main_batched.py:280-287)", "unit": "images/s", "steps": K, "cases": []}
+    for (B, S, So) in ((32, 336, 500), (64, 336, 500), (256, 336, 500), (32, 1024, 500), (64, 1024, 500), (256, 1024, 500)):
+        slot = B * (3 * S * S + 3 * So * So)
+        n = max(6, min(64, -(-(2 << 30) // slot)))
+        n += n & 1
+        g = torch.Generator(device=dev).manual_seed(77 + B + S)
+        images = [torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+        masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+        bytes_img = 2 * S * S + 3 * S * S + 3 * So * So
+        # serial: the drop-in itself, batch after batch over the ring
+        for i in range(3):
+            pipeline.warp_from_masks(images[i % n], masks[i % n], (So, So))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            o = pipeline.warp_from_masks(images[i % n], masks[i % n], (So, So))
+        torch.cuda.synchronize()
+        t_serial = (time.perf_counter() - t0) / K
+        del o
+        # stream
+        mc = pipeline.MaskChainStream(images, masks, (So, So))
+        def run():
+            mc.reset(); mc.prime(); mc.run(K - mc.depth); mc.drain()      # exactly K of every stage
+        run(); run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        t_stream = (time.perf_counter() - t0) / K
+        same = all(bool(torch.equal(mc.outs[i], pipeline.warp_from_masks(images[i], masks[i], (So, So)))) for i in range(min(n, K)))
+        case = {"B": B, "S": S, "S_out": So, "ring_batches": n, "pattern": mc.pattern,
+                "chain_algorithmic_bytes_per_image": bytes_img,
+                "stream": {"ms_per_step": round(t_stream * 1e3, 4), "images_per_s": round(B / t_stream, 1),
+                           "step_TBps": round(B * bytes_img / t_stream / 1e12, 3),
+                           "step_frac_of_hbm_peak": round(B * bytes_img / t_stream / 1e9 / HBM_PEAK_GBS, 4)},
+                "serial": {"ms_per_step": round(t_serial * 1e3, 4), "images_per_s": round(B / t_serial, 1),
+                           "step_frac_of_hbm_peak": round(B * bytes_img / t_serial / 1e9 / HBM_PEAK_GBS, 4)},
+                "bit_identical_to_serial": same}
+        out["cases"].append(case)
+        del mc, images, masks
+        torch.cuda.empty_cache()
+    ref = [c for c in out["cases"] if (c["B"], c["S"]) == (32, 336)][0]
+    out["value"] = ref["stream"]["images_per_s"]
+    out["value_is"] = "the stream step at the reference's own scale: B=32, 336 -> 500"
+    return out
+
+
+def leg_pool_input(dev, torch, pipeline, B, S, mode, K):
+    """SURVEY 8d config 3's other input form: full-resolution attention [B,1,S,S] float32 -> F.adaptive_avg_pool2d to 24 x 24
+    (MN/trainer.py:197 + sanitise :202) -> gt_marginals (MN/checkpoint_utils.py:43-51) -> right-inverse PDF -> CDF ->
+    inverse maps -> warp of [B,S,S,3] float32, stage by stage with HIP events."""
+    from attwarp_amd import checkpoint_utils as cu
+    g = torch.Generator(device=dev).manual_seed(2)
+    A = torch.rand((B, 1, S, S), device=dev, generator=g)
+    img = torch.rand((B, S, S, 3), device=dev, generator=g)
+    outb = torch.empty_like(img)
+    st = {}
+    a24 = pipeline.adaptive_avg_pool2d(A, (24, 24), sanitize=True)
+    px, py = cu.gt_marginals(a24)
+    mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
+    st["adaptive_pool_kernel"] = _event_ms(torch, lambda: pipeline.adaptive_avg_pool2d(A, (24, 24), sanitize=True), K)
+    st["gt_marginals_24x24"] = _event_ms(torch, lambda: cu.gt_marginals(a24), K)
+    st["axis_maps_from_pdf_kernel"] = _event_ms(torch, lambda: pipeline.axis_maps_from_pdf(px, py, (S, S)), K)
+    st["remap_rows_kernel"] = _event_ms(torch, lambda: cu.remap_separable(img, mx, my, mode=mode, channels_last=True, out=outb), K)
+    def whole():
+        a = pipeline.adaptive_avg_pool2d(A, (24, 24), sanitize=True)
+        p, q = cu.gt_marginals(a)
+        x, y = pipeline.axis_maps_from_pdf(p, q, (S, S))
+        cu.remap_separable(img, x, y, mode=mode, channels_last=True, out=outb)
+    ms = _event_ms(torch, whole, K)
+    pool_bytes = 4.0 * S * S * B
+    return {"workload": f"full-resolution attention [{B},1,{S},{S}] float32 -> 24x24 pool -> marginals -> maps -> warp of [{B},{S},{S},3] "
+                        f"float32, mode={mode}", "value": round(B / (ms * 1e-3), 1), "unit": "images/s",
+            "ms_per_step": round(ms, 4), "stages_ms": {k: round(v, 4) for k, v in st.items()},
+            "roofline_pool": {"bound": "hbm", "kernel": "adaptive_pool_kernel", "algorithmic_bytes_per_launch": pool_bytes,
+                              "achieved": round(pool_bytes / (st["adaptive_pool_kernel"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(pool_bytes / (st["adaptive_pool_kernel"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
+def leg_config5(dev, torch, pipeline, B, K):
+    """BASELINE configs[4] as a device-resident data flow (pipeline.config5_chain): per-leg milliseconds, so the share of the
+    hand-written path in an end-to-end step is a number.  The vision tower has the architecture of LLaVA-1.5's
+    (CLIP ViT-L/14-336) with seeded RANDOM weights; TextVQA accuracy parity is unobtainable here (no weights, no llava
+    package, no dataset)."""
+    from attwarp_amd.model import MarginalNet
+    tower = pipeline.random_clip_vision_tower(dev, torch.float16, seed=0)
+    torch.manual_seed(5)
+    net = MarginalNet(1024, 4096, 256).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(55)
+    imgs = torch.randint(0, 256, (B, 500, 500, 3), device=dev, dtype=torch.uint8, generator=g)
+    txt = torch.randn(B, 32, 4096, device=dev, generator=g)
+    mask = torch.ones(B, 32, device=dev)
+    legs = ["clip_tensor_in", "tower_in", "marginalnet", "warp", "clip_tensor_warped", "tower_warped"]
+    acc = {k: 0.0 for k in legs}
+    total = 0.0
+    for it in range(K + 2):
+        evs = [torch.cuda.Event(enable_timing=True)]
+        evs[0].record()
+        def rec(name):
+            e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+        r = pipeline.config5_chain(tower, net, imgs, txt, mask, (500, 500), record=rec)
+        torch.cuda.synchronize()
+        if it >= 2:
+            for i, k in enumerate(legs):
+                acc[k] += evs[i].elapsed_time(evs[i + 1])
+            total += evs[0].elapsed_time(evs[-1])
+    legs_ms = {k: round(v / K, 4) for k, v in acc.items()}
+    ms = total / K
+    path_ms = legs_ms["clip_tensor_in"] + legs_ms["warp"] + legs_ms["clip_tensor_warped"]
+    finite = bool(torch.isfinite(r["features_warped"].float()).all())
+    del tower, net
+    torch.cuda.empty_cache()
+    return {"workload": f"configs[4] data flow, B={B}: uint8 500x500 images -> CLIP tensor -> ViT-L/14-336 tower (random weights, fp16) -> "
+                        "[B,1024,24,24] -> MarginalNet(1024,4096,256) -> px,py -> warp -> CLIP tensor -> tower",
+            "value": round(B / (ms * 1e-3), 1), "unit": "images/s", "ms_per_step": round(ms, 4), "legs_ms": legs_ms,
+            "hand_written_path_ms": round(path_ms, 4), "hand_written_path_share": round(path_ms / ms, 4),
+            "features_finite": finite,
+            "accuracy_parity": "unobtainable here: LLaVA-1.5-7B weights, the llava package and TextVQA are absent (no network)"}
+
+
+# secondary measurements attached to the default (1024) line on one GPU; `--legs a,b` selects, `--list-legs` prints
+LEGS = {
+    "exact": "the main batch in the other arithmetic mode (also_exact / also_cv2)",
+    "chw": "the main batch in the other layout (also_chw / also_hwc)",
+    "fused": "the 1024 step as ONE launch (also_fused)",
+    "distributions": "SURVEY 8d value distributions: peaked and all-zero attention (also_peaked, also_zero_attention)",
+    "336": "BASELINE configs[1] and configs[3]'s per-rank batch as graph-replayed one-launch steps (also, also_336x256)",
+    "fp16_attention": "configs[3]'s per-rank batch with float16 attention rows (also_336x256_fp16_attention)",
+    "main_batched": "the reference's own uint8 chain (main_batched.py:243-287) as a stream step vs its serial launches (also_main_batched)",
+    "pool_input": "configs[2]'s other input form: full-resolution attention [B,1,S,S] -> 24x24 pool -> maps -> warp (also_pool_input)",
+    "config5": "configs[4] data flow with a random-weight CLIP ViT-L/14-336 tower, per-leg ms (also_config5)",
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="1024")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["config5", "main_batched"], default="1024")
     ap.add_argument("--mode", choices=["cv2", "exact"], default="cv2", help="resample arithmetic of the main line")
     ap.add_argument("--layout", choices=["hwc", "chw"], default="hwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the secondary measurements (exact / CHW / 336)")
+    ap.add_argument("--no-also", action="store_true", help="skip every secondary measurement (the also_* legs)")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated secondary legs to run beside the main line (see --list-legs); 'all' (default) or 'none'")
+    ap.add_argument("--list-legs", action="store_true", help="print the names of the secondary legs and exit")
     ap.add_argument("--dist-backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="force the GPU index (smoke-testing the N>1 path on a one-GPU box with --dist-backend gloo)")
@@ -529,10 +700,34 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: rendezvous, weight broadcast, counters and the JSON line only (CPU tests)")
     args = ap.parse_args()
+    if args.list_legs:
+        for name, doc in LEGS.items():
+            print(f"{name:28s} {doc}")
+        return
+    want = set(LEGS) if args.legs == "all" else set() if args.legs == "none" else set(args.legs.split(","))
+    if want - set(LEGS):
+        raise SystemExit(f"bench.py: unknown leg(s) {sorted(want - set(LEGS))}; --list-legs names them")
+    if args.no_also:
+        want = set()
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no torch import, no GPU call
 
+    if args.workload in ("config5", "main_batched"):
+        import torch
+        from attwarp_amd import _lib, pipeline
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+        _lib.load()
+        dev = torch.device("cuda", args.device or 0)
+        torch.cuda.set_device(dev)
+        res = leg_config5(dev, torch, pipeline, 64, max(args.steps // 4, 3)) if args.workload == "config5" else \
+            leg_main_batched(dev, torch, pipeline, max(args.steps, 48))
+        print(json.dumps(dict({"metric": "warped images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+                               "dtype": "u8" if args.workload == "main_batched" else "f16 tower / f32 MarginalNet / u8 warp",
+                               "config": {"workload": res["workload"]}}, **res)), flush=True)
+        return
     B, S, cfg_idx = WORKLOADS[args.workload]
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     rank_env = int(os.environ.get("RANK", "0"))
@@ -724,14 +919,16 @@ def main():
                                      f"{S}x{S} images for ~10 s; sum of per-process rates"),
         }
 
-    if world == 1 and not args.no_also and not small:
+    one_gpu_1024 = world == 1 and not small
+    if one_gpu_1024 and "exact" in want:
         other = "exact" if args.mode == "cv2" else "cv2"
         step.mode = other                                     # same buffers, the other arithmetic
         w2, _ = time_steps(step, args.steps, args.warmup, D)
         result[f"also_{other}"] = {"workload": f"same batch, mode={other}", "value": round(B * args.steps / w2, 1),
                                    "unit": "images/s", "ms_per_step": round(w2 / args.steps * 1e3, 4),
-                                   "roofline": roofline_of(step, load_pmc_traffic(args.workload, other))}
+                                   "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, other)))}
         step.mode = args.mode
+    if one_gpu_1024 and "chw" in want:
         # the other layout (CHW is what warp_from_cdf_torch receives, MN/checkpoint_utils.py:152)
         lay2 = "chw" if args.layout == "hwc" else "hwc"
         step.set_layout(lay2)
@@ -739,7 +936,10 @@ def main():
         result[f"also_{lay2}"] = {"workload": f"same batch as [B,3,S,S] planar float32, mode={args.mode}" if lay2 == "chw"
                                   else f"same batch as [B,S,S,3], mode={args.mode}",
                                   "value": round(B * args.steps / w3, 1), "unit": "images/s",
-                                  "ms_per_step": round(w3 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+                                  "ms_per_step": round(w3 / args.steps * 1e3, 4),
+                                  "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{lay2}")))}
+        step.set_layout(args.layout)
+    if one_gpu_1024 and "fused" in want:
         # the same step as ONE launch (attwarp_warp_step_fused through pipeline.OverlappedWarp): at this size it only
         # hides the map construction and two launch boundaries behind the resample
         step.set_layout(args.layout)
@@ -755,6 +955,7 @@ def main():
                                 "step_TBps": round(step_bytes(B, S) / (w5 / args.steps) / 1e12, 3)}
         del ow
         torch.cuda.empty_cache()
+    if one_gpu_1024 and "distributions" in want:
         # SURVEY 8d "value distributions to also run": peaked attention (one 3x3 hot spot x100: strong magnification
         # there, minification elsewhere) and all-zero attention (the uniform fallback, AGW/new_method.py:231-239 /
         # clamp_min(1e-6) in MN/checkpoint_utils.py:36) on the same images
@@ -769,14 +970,15 @@ def main():
                    "one 3x3 hot spot x100 per image: magnified there, minified elsewhere (two source rows per output row)"
             result[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}", "note": note,
                                       "value": round(B * args.steps / w4, 1), "unit": "images/s",
-                                      "ms_per_step": round(w4 / args.steps * 1e3, 4), "roofline": roofline_of(step)}
+                                      "ms_per_step": round(w4 / args.steps * 1e3, 4),
+                                      "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{name}")))}
             step.sets = keep
             del rows
     del step
     torch.cuda.empty_cache()
 
-    if world == 1 and args.workload == "1024" and not args.no_also:
-        n2 = max(args.steps, 48)
+    n2 = max(args.steps, 48)
+    if world == 1 and args.workload == "1024" and "336" in want:
         for key, wl in (("also", "336"), ("also_336x256", "336x256")):
             B2, S2, cfg2 = WORKLOADS[wl]
             res2, _, _, st2, ow2 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline)
@@ -785,6 +987,7 @@ def main():
             result[key] = res2
             del st2, ow2
             torch.cuda.empty_cache()
+    if world == 1 and args.workload == "1024" and "fp16_attention" in want:
         # the same per-rank batch with the attention rows in float16, the dtype LLaVA-1.5 emits (half the reduce's bytes)
         B2, S2, cfg2 = WORKLOADS["336x256"]
         res3, _, _, st3, ow3 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline,
@@ -794,6 +997,13 @@ def main():
              "value": res3["images_per_s"], "unit": "images/s", "steps": n2}, **res3)
         del st3, ow3
         torch.cuda.empty_cache()
+    if world == 1 and args.workload == "1024":
+        if "main_batched" in want:
+            result["also_main_batched"] = leg_main_batched(dev, torch, pipeline, n2)
+        if "pool_input" in want:
+            result["also_pool_input"] = leg_pool_input(dev, torch, pipeline, B, S, args.mode, args.steps)
+        if "config5" in want:
+            result["also_config5"] = leg_config5(dev, torch, pipeline, 32, 3)
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -249,6 +249,29 @@ ATTWARP_API int attwarp_attn_reduce_and_maps(int attn_dtype, const void* rows, i
                                  const void* steps_in, int T, int B, int g, int W, int H, int W_out, int H_out,
                                  const double* inv_x, const double* inv_y, float* map_x, float* map_y, void* stream);
 
+/* ---- one step of the main_batched chain (AGW/main_batched.py:243-287: revise_mask -> x255 uint8 -> PIL LANCZOS ->
+ * float64 marginals -> CDF -> np.interp -> uint8 cv2.remap, transform "identity" as that driver passes it) for a STREAM
+ * of equally shaped batches, as ONE launch.  The five stages run on five different batches (block ranges of one grid):
+ *   R(k)    images [B,H,W,C] uint8 + map_x [B,W_out], map_y [B,H_out]         -> out [B,H_out,W_out,C]   (mode cv2)
+ *   F(k+1)  sums_in (axis sums of the mask of batch k+1, written by P)        -> map_x_next, map_y_next
+ *   P(k+2)  mota_in [B,H,W] uint8 (up-sampled mask of batch k+2)              -> sums_out
+ *   L(k+3)  rev_in [B,g,g] float32 (revised mask of batch k+3) + Pillow tables (ksize_y == 8, zero padded) -> mota_out
+ *   V(k+4)  masks [B,g,g] float32 (aggregated attention of batch k+4)         -> rev_out
+ * sums_*: attwarp_axis_sums_workspace_bytes(B,H,W) bytes each.  An output buffer must not alias the buffer the next
+ * stage reads in the same launch (double buffer each intermediate by batch parity).  Every stage computes what
+ * attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8, identity) /
+ * attwarp_remap_bilinear(U8, HWC, CV2) compute, bit for bit.  ATTWARP_E_UNSUPPORTED when one of the stages would not
+ * run on its staged kernel for this shape (rows wider than 4096 bytes, W not a multiple of 4, W or H equal to g, ...):
+ * use the separate entry points then. */
+ATTWARP_API int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int B, int C, int H, int W, int H_out, int W_out,
+                            const float* map_x, const float* map_y,
+                            const void* sums_in, float* map_x_next, float* map_y_next,
+                            const uint8_t* mota_in, void* sums_out,
+                            const float* rev_in, const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
+                            const int32_t* bounds_y, const int32_t* kk_y, int ksize_y, uint8_t* mota_out,
+                            const float* masks, int g, int kernel_size, float enhance_coe, float* rev_out,
+                            void* stream);
+
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.
  * ws: workspace of attwarp_axis_sums_workspace_bytes(B,h,w) bytes. */

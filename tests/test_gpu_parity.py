@@ -1530,6 +1530,60 @@ def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
         assert np.array_equal(a8_h[i], C.remap_bilinear_u8(img8_h[i], mx_h[b], my_h[b], mode)), (b, "uint8")
 
 
+@pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
+@pytest.mark.parametrize("adt", [torch.float32, torch.float16])
+def test_stack_chain_full_size_vs_oracle(dev, cfg, adt):
+    """The exact chain bench.py times, at its full sizes, FROM THE STACK: attention rows [T=20, B, 32 heads, kv=640]
+    (float32, and float16 as LLaVA emits them), image tokens at 35 + b mod 8 -> A1 -> A2 .. A11 -> A12 on [B,S,S,3] float32.
+    The aggregated 24 x 24 maps, the 1-D maps and the pixels of every image (336) / a stratified 33 (1024) against the
+    oracle chain (numpy A1/A2 in the row dtype, oracle/warp_ref.c for everything behind it; float32 rows also through
+    warp_ref.c's own whole-path entry point).  The stream forms (pipeline.OverlappedWarp patterns "am" and "fused") must
+    produce the same bytes as the serial launches for ALL images."""
+    import subprocess
+    from attwarp_amd import pipeline
+    from oracle import c_oracle as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    B, S = cfg
+    T_, heads, kv = 20, 32, 640
+    gen = torch.Generator(device=dev).manual_seed(1234 + S)
+    img = torch.rand((B, S, S, 3), device=dev, generator=gen)
+    rows = torch.empty((T_, B, heads, kv), device=dev)
+    for t in range(T_):
+        rows[t] = torch.softmax(torch.randn((B, heads, kv), device=dev, generator=gen), dim=-1)
+    rows = rows.to(adt)
+    starts = (35 + torch.arange(B, device=dev) % 8).to(torch.int32)
+    steps = pipeline.attention_step_maps(rows, starts)
+    mx, my, att = pipeline.axis_maps_from_attention_steps(steps, (S, S), return_attention=True)
+    out = pipeline.warp_from_attention_stack(img, rows, starts, channels_last=True, mode="cv2")
+    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
+    idx = torch.tensor(sel, device=dev)
+    rows_h, st_h = N(rows[:, idx]), N(starts[idx])
+    att_o = O.attn_reduce_stack(rows_h, st_h)                     # numpy A1 + A2 in the row dtype
+    assert att_o.dtype == (np.float32 if adt == torch.float32 else np.float16)
+    assert np.array_equal(N(att[idx]), att_o.astype(np.float32))
+    inv = O.right_inverse_core(24, S)
+    mx_h, my_h, img_h, out_h = N(mx[idx]), N(my[idx]), N(img[idx]), N(out[idx])
+    for i, b in enumerate(sel):
+        a24 = att_o[i].astype(np.float32).reshape(24, 24)
+        opx, opy = C.marginals(a24)
+        omx = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opx, S, inv, clamp0=True)), S)
+        omy = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opy, S, inv, clamp0=True)), S)
+        assert np.array_equal(mx_h[i], omx) and np.array_equal(my_h[i], omy), b
+        assert np.array_equal(out_h[i], C.remap_bilinear(img_h[i], omx, omy, "hwc", "cv2")), b
+        if adt == torch.float32 and i % 4 == 0:                    # the C oracle's own whole path (its A1 included)
+            assert np.array_equal(out_h[i], C.warp_from_attention_stack(img_h[i], rows_h[:, i], st_h[i], inv, inv, "hwc", "cv2")), b
+    del img_h, out_h
+    for pattern in ("am", "fused"):
+        ow = pipeline.OverlappedWarp(img, rows, starts, channels_last=True, mode="cv2", pattern=pattern)
+        ow.reset(); ow.prime(); ow.prime2()
+        got = ow.step()
+        assert ow.pattern == pattern and torch.equal(got, out), pattern
+        got = ow.step()                                            # second step: the maps built INSIDE the first one
+        assert torch.equal(got, out), pattern
+        del ow, got
+
+
 @pytest.mark.parametrize("cfg", [(64, 336), (8, 1024)])
 @pytest.mark.parametrize("layout", ["hwc", "chw"])
 @pytest.mark.parametrize("kind", ["peaked", "wild"])
@@ -2091,6 +2145,45 @@ def test_marginalnet_tail_shapes(dev):
         t = N(model.masked_token_mean(T(tok, dev), T(mask, dev)))
         assert np.array_equal(t, O.masked_token_mean(tok, mask))
         assert not t[0].any()
+
+
+def test_config5_data_flow_with_random_clip_tower(dev):
+    """BASELINE configs[4] as far as it can be built here: uint8 images -> CLIP tensor -> ViT-L/14-336 vision tower (the
+    architecture of LLaVA-1.5's, SEEDED RANDOM weights: the checkpoint is absent) -> hidden_states[-2][:, 1:] ->
+    [B,1024,24,24] -> MarginalNet(1024, 4096, 256) -> px, py -> warp -> CLIP tensor -> tower.  The product's CLIP tensors
+    equal the HF processor's bit for bit (float32; float16 = its rounding), so the tower sees identical inputs and returns
+    identical features; the hand-written legs inside the chain equal their stand-alone calls.  TextVQA accuracy parity is
+    unobtainable (no weights, no dataset)."""
+    from transformers.models.clip.image_processing_pil_clip import CLIPImageProcessorPil
+    from attwarp_amd import pipeline
+    from attwarp_amd.model import MarginalNet
+    tower = pipeline.random_clip_vision_tower(dev, torch.float16, seed=0)
+    torch.manual_seed(5)
+    net = MarginalNet(1024, 4096, 256).to(dev).eval()
+    imgs = np.stack([clip_input("sq500"), clip_input("sq500")[::-1, ::-1].copy()])
+    x = T(imgs, dev)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    txt = torch.randn(2, 12, 4096, generator=g).to(dev)
+    mask = torch.ones(2, 12, device=dev); mask[1, 7:] = 0
+    r = pipeline.config5_chain(tower, net, x, txt, mask, out_size=(500, 500))
+    assert r["token_map"].shape == (2, 1024, 24, 24) and r["features_warped"].shape == (2, 1024, 24, 24)
+    assert r["px"].shape == (2, 24) and abs(float(r["px"][0].sum()) - 1.0) < 1e-5
+    assert r["warped"].shape == (2, 500, 500, 3) and r["warped"].dtype == torch.uint8
+    assert bool(torch.isfinite(r["features_warped"].float()).all())
+    # the HF processor (PIL backend, as LLaVA-1.5 configures it) on the same uint8 images: identical tensors
+    proc = CLIPImageProcessorPil(size={"shortest_edge": 336}, crop_size={"height": 336, "width": 336})
+    hf_in = proc.preprocess([im for im in imgs], return_tensors="np")["pixel_values"]
+    assert np.array_equal(N(pipeline.clip_preprocess(x, 336, torch.float32)), hf_in)
+    assert torch.equal(r["pixel_values_in"], T(hf_in, dev).half())
+    hf_w = proc.preprocess([w for w in N(r["warped"])], return_tensors="np")["pixel_values"]
+    assert torch.equal(r["pixel_values_warped"], T(hf_w, dev).half())
+    # identical inputs -> identical tower features (same kernels, same shapes: run-to-run deterministic)
+    assert torch.equal(pipeline.vision_tower_features(tower, T(hf_in, dev).half()), r["token_map"])
+    assert torch.equal(pipeline.vision_tower_features(tower, T(hf_w, dev).half()), r["features_warped"])
+    # the legs inside the chain are the stand-alone calls
+    px, py = net(r["token_map"], 24, 24, txt, mask)
+    assert torch.equal(px, r["px"]) and torch.equal(py, r["py"])
+    assert torch.equal(pipeline.warp_from_pdf(x, px, py, (500, 500), channels_last=True), r["warped"])
 
 
 def test_marginalnet_to_warp_chain(dev, golden):

@@ -121,6 +121,36 @@ def test_stream_step_abi_validation_without_gpu(lib):
     assert fcall(ntok=572, steps_in=None) != -2 or b"g*g" not in lib.attwarp_last_error()   # A alone: any multiple of 4
 
 
+def test_mask_chain_step_abi_validation_without_gpu(lib):
+    """attwarp_mask_chain_step (the one-launch step of the main_batched chain) validates before it enqueues."""
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    base = (ctypes.addressof(buf) + 15) & ~15
+    P = [ctypes.c_void_p(base + 1024 * i) for i in range(16)]
+    names = ["images", "out", "B", "C", "H", "W", "H_out", "W_out", "map_x", "map_y", "sums_in", "map_x_next", "map_y_next",
+             "mota_in", "sums_out", "rev_in", "bounds_x", "kk_x", "ksize_x", "bounds_y", "kk_y", "ksize_y", "mota_out", "masks",
+             "g", "kernel_size", "enhance_coe", "rev_out", "stream"]
+    ok = dict(images=P[0], out=P[1], B=2, C=3, H=64, W=64, H_out=80, W_out=80, map_x=P[2], map_y=P[3], sums_in=P[4],
+              map_x_next=P[5], map_y_next=P[6], mota_in=P[7], sums_out=P[8], rev_in=P[9], bounds_x=P[10], kk_x=P[11], ksize_x=8,
+              bounds_y=P[12], kk_y=P[13], ksize_y=8, mota_out=P[14], masks=P[15], g=24, kernel_size=3, enhance_coe=10.0,
+              rev_out=ctypes.c_void_p(base + 1024 * 16), stream=None)
+    f = lib.attwarp_mask_chain_step
+    def call(**kw):
+        a = dict(ok, **kw)
+        return f(*[a[k] for k in names])
+    assert call(images=None) == -1 and b"null" in lib.attwarp_last_error()
+    assert call(masks=None) == -1
+    assert call(B=0) == -1
+    assert call(kernel_size=4) == -1 and b"odd" in lib.attwarp_last_error()
+    assert call(map_x_next=P[2]) == -1 and b"alias" in lib.attwarp_last_error()
+    assert call(sums_out=P[4]) == -1 and call(mota_out=P[7]) == -1 and call(rev_out=P[9]) == -1
+    assert call(g=40) == -2
+    assert call(W=66) == -2                              # W % 4 != 0: not the column-strip up-sampler
+    assert call(W=24) == -2                              # no horizontal up-sampling
+    assert call(ksize_y=7) == -2
+    assert call(W=2048, H=8) == -2                       # rows wider than 4096 bytes: not the integer resample
+
+
 def test_probe_abi_validation_without_gpu(lib):
     import ctypes
     p = ctypes.cast(ctypes.create_string_buffer(4096), ctypes.c_void_p)
