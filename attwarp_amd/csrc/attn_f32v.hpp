@@ -161,7 +161,11 @@ constexpr size_t attn_v4_lds_bytes() { return (size_t)(ATTN_NT / WAVE) * NV * 4 
 // One 256-thread workgroup per (pseudo-)sample b.  Wave w takes heads w, w+4, ...; lane l owns tokens 4l..4l+3 (+256
 // per vector, NV = ceil(ntok / 256)); HU heads are in flight per wave.  part: LDS, attn_v4_lds_bytes<NV>().
 // (Measured and dropped: requesting the rows of the next HU heads before the current HU heads are reduced -- two register
-// sets of raw rows -- 53.0-53.9 us against 52.0-52.2 for float16 rows.)
+// sets of raw rows -- 53.0-53.9 us against 52.0-52.2 for float16 rows.  Round 4: the 64-token tails of the four heads in
+// flight sharing ONE vector (lane 16 u + j = tail chunk j of head u; rows moved to lanes 0..15 with v_permlane16/32_swap so
+// that the summation order is unchanged; bit-identical): SQ_INSTS_VALU 21.42 M -> 21.22 M per launch for float16 rows at
+// T*B = 5120 -- the row moves, per-lane denominators and per-lane row addresses cost what the three saved vectors gain --
+// and 55.7-57.6 us against 55.1-57.0 on the same lease: docs/experiments.md.)
 template <typename T, int NV, int HU>
 __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, int b, float* part) {
   constexpr int NT = ATTN_NT, PW = NV * 4 * WAVE, NW = NT / WAVE;
@@ -320,5 +324,6 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
     a.out[(int64_t)b * ntok + t] = from_f32<T>(round_to<T>(m) / nheads);    // mean = sum / N in dtype T
   }
 }
+
 
 }  // namespace attwarp

@@ -28,8 +28,8 @@ namespace attwarp {
 
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_Q = 32;                 // octets per period of the P / L / R interleave
-constexpr int CHAIN_ORDER_DEFAULT = 0;      // see build_interleave
-constexpr int CHAIN_WAVES_DEFAULT = 6;      // waves per SIMD the register allocation leaves room for
+constexpr int CHAIN_ORDER_DEFAULT = 2;      // see build_interleave
+constexpr int CHAIN_WAVES_DEFAULT = 8;      // waves per SIMD the register allocation leaves room for
 
 struct ChainStepArgs {
   int B;

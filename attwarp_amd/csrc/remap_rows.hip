@@ -121,55 +121,111 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
 
 using namespace attwarp;
 
-extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
-                                       int W_out, const float* map_x, const float* map_y, int mode,
-                                       int attn_dtype, const void* steps_in, int T, int g, const double* inv_x,
-                                       const double* inv_y, float* map_x_next, float* map_y_next,
-                                       const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
-                                       int starts_mod, int ntok, void* steps_out, void* stream) {
-  ATTWARP_REQUIRE(src && dst && map_x && map_y, "warp_step_fused: null image / map pointer");
+namespace {
+// one slot of a fused step: the buffers of the three pieces (a piece is absent when its first pointer is null)
+struct SlotPtrs {
+  const float* src; float* dst; const float* map_x; const float* map_y;           // R
+  const void* steps_in; float* map_x_next; float* map_y_next;                      // M
+  const void* rows; const int32_t* starts; void* steps_out;                        // A
+};
+
+int step_fused_impl(const SlotPtrs* sl, int nslots, int layout, int B, int C, int H, int W, int H_out, int W_out, int mode,
+                    int attn_dtype, int T, int g, const double* inv_x, const double* inv_y, int n_rows, int heads, int kv_len,
+                    int starts_mod, int ntok, void* stream) {
+  ATTWARP_REQUIRE(nslots == 1 || nslots == 2, "warp_step_fused: nslots must be 1 or 2 (got %d)", nslots);
+  const SlotPtrs& s0 = sl[0];
+  for (int k = 0; k < nslots; ++k) {
+    ATTWARP_REQUIRE(sl[k].src && sl[k].dst && sl[k].map_x && sl[k].map_y, "warp_step_fused: null image / map pointer");
+    ATTWARP_REQUIRE((sl[k].steps_in != nullptr) == (s0.steps_in != nullptr) && (sl[k].rows != nullptr) == (s0.rows != nullptr),
+                    "warp_step_fused: both slots must carry the same pieces");
+  }
   ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0, "warp_step_fused: non-positive size");
   ATTWARP_REQUIRE(layout == ATTWARP_HWC || layout == ATTWARP_CHW, "warp_step_fused: unknown layout %d", layout);
   ATTWARP_REQUIRE(mode == ATTWARP_EXACT || mode == ATTWARP_CV2, "warp_step_fused: unknown mode %d", mode);
   if (C > 4 || B > 65535 || H_out > 65535 || (long long)W_out * C > 2147483647LL / 2 ||
       (long long)H * W * C > 2147483647LL)
     return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: image shape outside the staged resample's limits");
-  if (steps_in || rows)
+  if (s0.steps_in || s0.rows)
     ATTWARP_REQUIRE(attn_dtype == ATTWARP_F32 || attn_dtype == ATTWARP_F16 || attn_dtype == ATTWARP_BF16,
                     "warp_step_fused: attn_dtype must be F32, F16 or BF16 (got %d)", attn_dtype);
+  if (nslots == 2) {
+    // 16-byte vector loads of the resample: the geometry is planned on slot 0, slot 1 must satisfy the same alignment
+    ATTWARP_REQUIRE(((reinterpret_cast<uintptr_t>(sl[1].src) ^ reinterpret_cast<uintptr_t>(s0.src)) & 15u) == 0,
+                    "warp_step_fused: both slots' images must have the same 16-byte alignment");
+    ATTWARP_REQUIRE(sl[1].dst != s0.dst && sl[1].map_x_next != s0.map_x_next && sl[1].steps_out != s0.steps_out,
+                    "warp_step_fused: the two slots must write different buffers");
+  }
   StepExtra ex;
   memset(&ex, 0, sizeof(ex));
-  if (steps_in) {      // M: per-step maps of the NEXT batch -> its inverse maps
-    ATTWARP_REQUIRE(inv_x && inv_y && map_x_next && map_y_next, "warp_step_fused: null map-construction pointer");
+  ex.nslots = nslots;
+  if (s0.steps_in) {      // M: per-step maps of a later batch -> its inverse maps
+    ATTWARP_REQUIRE(inv_x && inv_y, "warp_step_fused: null map-construction pointer");
+    for (int k = 0; k < nslots; ++k) {
+      ATTWARP_REQUIRE(sl[k].map_x_next && sl[k].map_y_next, "warp_step_fused: null map-construction pointer");
+      for (int q = 0; q < nslots; ++q)
+        ATTWARP_REQUIRE(sl[k].map_x_next != sl[q].map_x && sl[k].map_y_next != sl[q].map_y,
+                        "warp_step_fused: the next maps must not alias the current ones");
+    }
     ATTWARP_REQUIRE(T > 0 && g > 0, "warp_step_fused: non-positive T / g");
-    ATTWARP_REQUIRE(map_x_next != map_x && map_y_next != map_y, "warp_step_fused: the next maps must not alias the current ones");
     if (g > 32 || std::max(W, H) > 8192) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: g > 32 or max(W,H) > 8192");
-    ex.maps.steps = steps_in; ex.maps.step_dtype = attn_dtype; ex.maps.T = T; ex.maps.B = B; ex.maps.g = g; ex.maps.W = W; ex.maps.H = H;
+    ex.maps.steps = s0.steps_in; ex.maps.step_dtype = attn_dtype; ex.maps.T = T; ex.maps.B = B; ex.maps.g = g; ex.maps.W = W; ex.maps.H = H;
     ex.maps.W_out = W_out; ex.maps.H_out = H_out; ex.maps.inv_x = inv_x; ex.maps.inv_y = inv_y;
-    ex.maps.map_x = map_x_next; ex.maps.map_y = map_y_next; ex.maps.att_out = nullptr;
-    ex.nM8 = (2 * B + 7) / 8;
+    ex.maps.map_x = s0.map_x_next; ex.maps.map_y = s0.map_y_next; ex.maps.att_out = nullptr;
+    ex.nM8 = (nslots * 2 * B + 7) / 8;
   }
-  if (rows) {          // A: attention rows of the batch after next -> its per-step maps
-    ATTWARP_REQUIRE(starts && steps_out, "warp_step_fused: null attention pointer");
+  if (s0.rows) {          // A: attention rows of a later batch -> its per-step maps
+    for (int k = 0; k < nslots; ++k) {
+      ATTWARP_REQUIRE(sl[k].starts && sl[k].steps_out, "warp_step_fused: null attention pointer");
+      for (int q = 0; q < nslots; ++q)
+        ATTWARP_REQUIRE(sl[k].steps_out != sl[q].steps_in, "warp_step_fused: steps_out must not alias steps_in");
+    }
     ATTWARP_REQUIRE(n_rows > 0 && heads > 0 && kv_len > 0 && ntok > 0 && starts_mod > 0, "warp_step_fused: non-positive attention size");
     ATTWARP_REQUIRE(ntok <= kv_len, "warp_step_fused: ntok=%d > kv_len=%d", ntok, kv_len);
-    ATTWARP_REQUIRE(steps_out != steps_in, "warp_step_fused: steps_out must not alias steps_in");
     if (ntok % 4 != 0 || ntok > 3 * 4 * WAVE)
       return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok must be a multiple of 4 and <= 768");
-    // A writes steps_out as [n_rows, ntok]; the next step's M reads that buffer as [T, B, g * g]
-    if (steps_in && ntok != g * g)
+    // A writes steps_out as [n_rows, ntok]; a later step's M reads that buffer as [T, B, g * g]
+    if (s0.steps_in && ntok != g * g)
       return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: ntok=%d must equal g*g=%d when both pieces are present", ntok, g * g);
-    ex.attn.attn = rows; ex.attn.dtype = attn_dtype; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
-    ex.attn.row_off = 0; ex.attn.starts = starts; ex.attn.starts_mod = starts_mod; ex.attn.max_start = kv_len - ntok;
-    ex.attn.ntok = ntok; ex.attn.out = steps_out;
+    ex.attn.attn = s0.rows; ex.attn.dtype = attn_dtype; ex.attn.heads = heads; ex.attn.sb = (int64_t)heads * kv_len; ex.attn.sh = kv_len;
+    ex.attn.row_off = 0; ex.attn.starts = s0.starts; ex.attn.starts_mod = starts_mod; ex.attn.max_start = kv_len - ntok;
+    ex.attn.ntok = ntok; ex.attn.out = s0.steps_out;
     ex.nA = n_rows;
-    ex.nA8 = (n_rows + 7) / 8;
+    ex.nA8 = (nslots * n_rows + 7) / 8;
+  }
+  if (nslots == 2) {
+    const SlotPtrs& t = sl[1];
+    ex.s1 = StepSlot2{t.src, t.dst, t.map_x, t.map_y, t.steps_in, t.map_x_next, t.map_y_next, t.rows, t.starts, t.steps_out};
   }
   bool handled = false;
-  const int rc = launch_remap_rows(src, dst, layout, B, C, H, W, H_out, W_out, map_x, map_y, mode, as_stream(stream),
+  const int rc = launch_remap_rows(s0.src, s0.dst, layout, B, C, H, W, H_out, W_out, s0.map_x, s0.map_y, mode, as_stream(stream),
                                    &handled, &ex);
   if (!handled && rc == ATTWARP_OK)
     return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: this image shape / alignment takes the generic resample; use the three separate launches");
   return rc;
 }
+}  // namespace
 
+extern "C" int attwarp_warp_step_fused(const float* src, float* dst, int layout, int B, int C, int H, int W, int H_out,
+                                       int W_out, const float* map_x, const float* map_y, int mode,
+                                       int attn_dtype, const void* steps_in, int T, int g, const double* inv_x,
+                                       const double* inv_y, float* map_x_next, float* map_y_next,
+                                       const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
+                                       int starts_mod, int ntok, void* steps_out, void* stream) {
+  const SlotPtrs s{src, dst, map_x, map_y, steps_in, map_x_next, map_y_next, rows, starts, steps_out};
+  return step_fused_impl(&s, 1, layout, B, C, H, W, H_out, W_out, mode, attn_dtype, T, g, inv_x, inv_y, n_rows, heads, kv_len,
+                         starts_mod, ntok, stream);
+}
+
+extern "C" int attwarp_warp_step_fused_slots(const attwarp_step_slot* slots, int nslots, int layout, int B, int C, int H, int W,
+                                             int H_out, int W_out, int mode, int attn_dtype, int T, int g, const double* inv_x,
+                                             const double* inv_y, int n_rows, int heads, int kv_len, int starts_mod, int ntok,
+                                             void* stream) {
+  ATTWARP_REQUIRE(slots, "warp_step_fused_slots: null slot table");
+  ATTWARP_REQUIRE(nslots == 1 || nslots == 2, "warp_step_fused_slots: nslots must be 1 or 2 (got %d)", nslots);
+  SlotPtrs s[2];
+  for (int k = 0; k < nslots; ++k)
+    s[k] = SlotPtrs{slots[k].src, slots[k].dst, slots[k].map_x, slots[k].map_y, slots[k].steps_in, slots[k].map_x_next,
+                    slots[k].map_y_next, slots[k].rows, slots[k].starts, slots[k].steps_out};
+  return step_fused_impl(s, nslots, layout, B, C, H, W, H_out, W_out, mode, attn_dtype, T, g, inv_x, inv_y, n_rows, heads, kv_len,
+                         starts_mod, ntok, stream);
+}

@@ -467,10 +467,20 @@ __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
 // batches larger than the Infinity Cache (tools/ab_step.py, same-box alternating builds): B=64 0.059 ms per step
 // against 0.076 (three graph branches) and 0.089 (three eager launches); B=256 0.209 against 0.228 / 0.233; reduce and
 // resample chunks interleaved evenly instead: 0.064 / 0.216; 4 heads in flight per reduce wave: 0.069 / 0.233.
+// A second set of buffers for the same step geometry: with nslots == 2 one launch serves TWO consecutive batches of the
+// stream per piece -- R(k), R(k+1) | M(k+2), M(k+3) | A(k+4), A(k+5) -- and the ramp and the tail of the launch (about 8 us
+// of a 60 us step at B=64 336x336) are paid once per two batches.
+struct StepSlot2 {
+  const float* src; float* dst; const float* mx; const float* my;      // R
+  const void* steps; float* map_x; float* map_y;                        // M
+  const void* attn; const int32_t* starts; void* out;                   // A
+};
 struct StepExtra {
-  StepsMapsArgs maps;      // nM8 * 8 >= 2 * maps.B blocks (0: no map work)
-  AttnStepArgsAny attn;    // nA reduce blocks (0: none); its dtype is also the dtype of maps.steps
-  int nM8, nA, nA8, nR8;   // blocks / 8 of the three ranges: ceil(2B / 8), ceil(nA / 8), ceil(nR / 8)
+  StepsMapsArgs maps;      // nM8 * 8 >= nslots * 2 * maps.B blocks (0: no map work)
+  AttnStepArgsAny attn;    // nA reduce blocks per slot (0: none); its dtype is also the dtype of maps.steps
+  int nM8, nA, nA8, nR8;   // blocks / 8 of the ranges: ceil(nslots * 2B / 8), ceil(nslots * nA / 8), ceil(nR / 8) PER SLOT
+  int nslots;              // 1 or 2
+  StepSlot2 s1;            // slot 1 (slot 0 = the pointers of RowsParams / maps / attn)
 };
 
 // Waves per SIMD the register allocation must leave room for: the appended map / reduce blocks must not cost the
@@ -487,25 +497,41 @@ __global__ __launch_bounds__(NT, step_min_waves(KI, KO, AFF)) void warp_step_ker
   __shared__ float s_tmp[64], s_pm[64];
   const int blk = blockIdx.x;
   if (blk < ex.nM8 * 8) {
-    if (blk < 2 * ex.maps.B) {
+    if (blk < ex.nslots * 2 * ex.maps.B) {
+      const bool s1 = blk >= 2 * ex.maps.B;                     // block uniform
+      const int jj = blk - (s1 ? 2 * ex.maps.B : 0);
+      StepsMapsArgs m = ex.maps;
+      if (s1) { m.steps = ex.s1.steps; m.map_x = ex.s1.map_x; m.map_y = ex.s1.map_y; }
       double* sd = reinterpret_cast<double*>(smem);
-      if (ex.maps.step_dtype == ATTWARP_F32) axis_maps_from_steps_block<8, float>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
-      else if (ex.maps.step_dtype == ATTWARP_F16) axis_maps_from_steps_block<8, __half>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
-      else axis_maps_from_steps_block<8, __hip_bfloat16>(ex.maps, blk >> 1, blk & 1, sd, s_tmp, s_pm);
+      if (m.step_dtype == ATTWARP_F32) axis_maps_from_steps_block<8, float>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
+      else if (m.step_dtype == ATTWARP_F16) axis_maps_from_steps_block<8, __half>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
+      else axis_maps_from_steps_block<8, __hip_bfloat16>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
     }
     return;
   }
   const int j = blk - ex.nM8 * 8;
   if (j < ex.nA8 * 8) {
-    if (j < ex.nA) {
-      if (ex.attn.dtype == ATTWARP_F32) attn_reduce_v4_block<float, 3, 2>(ex.attn.as<float>(), j, smem);
-      else if (ex.attn.dtype == ATTWARP_F16) attn_reduce_v4_block<__half, 3, 2>(ex.attn.as<__half>(), j, smem);
-      else attn_reduce_v4_block<__hip_bfloat16, 3, 2>(ex.attn.as<__hip_bfloat16>(), j, smem);
+    if (j < ex.nslots * ex.nA) {
+      const bool s1 = j >= ex.nA;
+      const int jj = j - (s1 ? ex.nA : 0);
+      AttnStepArgsAny at = ex.attn;
+      if (s1) { at.attn = ex.s1.attn; at.starts = ex.s1.starts; at.out = ex.s1.out; }
+      if (at.dtype == ATTWARP_F32) attn_reduce_v4_block<float, 3, 2>(at.as<float>(), jj, smem);
+      else if (at.dtype == ATTWARP_F16) attn_reduce_v4_block<__half, 3, 2>(at.as<__half>(), jj, smem);
+      else attn_reduce_v4_block<__hip_bfloat16, 3, 2>(at.as<__hip_bfloat16>(), jj, smem);
     }
     return;
   }
-  const int rb = j - ex.nA8 * 8;       // a multiple of 8 blocks precede: block % 8 still names the XCD
-  if (rb < p.nblocks) remap_rows_block<NT, KI, KO, HWC, AFF, false, MODE, SINGLE>(p, rb, smem);
+  // every slot's resample range is padded to a multiple of 8 blocks (and a multiple of 8 blocks precedes): block % 8 still
+  // names the XCD
+  int rb = j - ex.nA8 * 8;
+  const bool s1 = rb >= ex.nR8 * 8;
+  rb -= s1 ? ex.nR8 * 8 : 0;
+  if (rb < p.nblocks) {
+    RowsParams q = p;
+    if (s1) { q.src = ex.s1.src; q.dst = ex.s1.dst; q.mx = ex.s1.mx; q.my = ex.s1.my; }
+    remap_rows_block<NT, KI, KO, HWC, AFF, false, MODE, SINGLE>(q, rb, smem);
+  }
 }
 
 template <int MODE, bool SINGLE>
@@ -527,7 +553,7 @@ static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* e
     if (lds > LDS_DEFAULT_MAX)
       return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: %zu bytes of LDS per workgroup (> %zu): use the separate launches", lds,
                   LDS_DEFAULT_MAX);
-    const dim3 g((unsigned)((ex->nM8 + ex->nA8 + ex->nR8) * 8));
+    const dim3 g((unsigned)((ex->nM8 + ex->nA8 + ex->nslots * ex->nR8) * 8));
     if (p.NP == 1 && p.OVL == KO * NT)
       hipLaunchKernelGGL((warp_step_kernel<NT, KI, KO, true, true, MODE, SINGLE>), g, t, lds, st, p, *ex);
     else if (p.NP == 1)

@@ -578,6 +578,145 @@ class OverlappedWarp:
         return self.flush()
 
 
+class _StepSlot(__import__("ctypes").Structure):
+    """``attwarp_step_slot`` of include/attwarp.h (device pointers)."""
+    _fields_ = [(n, __import__("ctypes").c_void_p) for n in ("src", "dst", "map_x", "map_y", "steps_in", "map_x_next", "map_y_next",
+                                                             "rows", "starts", "steps_out")]
+
+
+class PairedStepWarp:
+    """``OverlappedWarp`` pattern "fused" with TWO batches of the stream per piece and launch
+    (attwarp_warp_step_fused_slots):
+
+        launch p:   R(2p), R(2p+1)  |  M(2p+2), M(2p+3)  |  A(2p+4), A(2p+5)
+
+    Every dependency is on an earlier launch, and the launch's ramp and tail -- about 8 us of a 60 us step at B=64
+    336x336 -- are paid once per two batches.  Per-step maps and step-map buffers exist four times (batch j uses set
+    j % 4); ``images`` / ``rows`` are rings of n >= 2 static buffers (even n), batch k in slot k % n, output in
+    ``outs[k % n]``.  float32 images on the staged resample, attention rows float32 / float16 / bfloat16.
+
+        pw = PairedStepWarp(images, rows, starts)
+        rows[0..3] <- attention of batches 0..3;  pw.prime()         # reduce of 0..3, maps of 0, 1 (serial launches)
+        for p in 0 .. N/2 - 1:
+            images[2p % n], images[(2p+1) % n] <- batches 2p, 2p+1;  rows[(2p+4) % n], rows[(2p+5) % n] <- attention ahead
+            pw.step()                                                  # -> outs[2p % n], outs[(2p+1) % n]
+        pw.tail()                                                      # the last four batches without further attention
+
+    Bit-identical, batch by batch, to ``warp_from_attention_stack`` (same kernels bodies, same arguments)."""
+
+    def __init__(self, images, rows, starts: torch.Tensor, out_size=None, channels_last: bool = False, mode: str = "cv2"):
+        self.images, self.rows = list(images), list(rows)
+        if len(self.images) != len(self.rows) or len(self.images) < 2 or len(self.images) % 2:
+            raise ValueError("PairedStepWarp: images and rows must be rings of the same even length >= 2")
+        dev = require_gpu(*self.images, *self.rows, starts)
+        img0, r0 = self.images[0], self.rows[0]
+        if any(i.dtype != torch.float32 or i.shape != img0.shape or not i.is_contiguous() for i in self.images):
+            raise TypeError("PairedStepWarp: contiguous float32 image buffers of one shape expected")
+        if any(r.dtype not in (torch.float32, torch.float16, torch.bfloat16) or r.dtype != r0.dtype or r.shape != r0.shape
+               or r.dim() != 4 or not r.is_contiguous() for r in self.rows):
+            raise TypeError("PairedStepWarp: contiguous attention rows [T,B,heads,kv] of one shape and dtype expected")
+        self.n = len(self.images)
+        self.channels_last, self.mode, self._dev = channels_last, mode, dev
+        H, W = (img0.shape[1], img0.shape[2]) if channels_last else (img0.shape[2], img0.shape[3])
+        self.C = img0.shape[3] if channels_last else img0.shape[1]
+        self.B, self.H, self.W = img0.shape[0], H, W
+        self.Ho, self.Wo = (H, W) if out_size is None else (int(out_size[0]), int(out_size[1]))
+        T = r0.shape[0]
+        self.starts = starts.clone()
+        self.starts_tiled = starts.repeat(T).contiguous()
+        shape = (self.B, self.Ho, self.Wo, self.C) if channels_last else (self.B, self.C, self.Ho, self.Wo)
+        self.outs = [torch.empty(shape, device=dev, dtype=torch.float32) for _ in range(self.n)]
+        self.steps = [torch.empty(T, self.B, ae.NUM_IMAGE_TOKENS, device=dev, dtype=r0.dtype) for _ in range(4)]
+        self.maps = [(torch.empty(self.B, self.Wo, device=dev, dtype=torch.float32),
+                      torch.empty(self.B, self.Ho, device=dev, dtype=torch.float32)) for _ in range(4)]
+        g = int(round(ae.NUM_IMAGE_TOKENS ** 0.5))
+        self.g = g
+        self._inv = (_tables.right_inverse_inv(g, W, 1e-8, dev), _tables.right_inverse_inv(g, H, 1e-8, dev))
+        self.k = 0
+        self._graphs = {}
+        self._launch(0)                        # eligibility (raises AttWarpError) + lazy module loading, outside any capture
+        torch.cuda.synchronize(dev)
+
+    def _launch(self, k):
+        """R(k), R(k+1) | M(k+2), M(k+3) | A(k+4), A(k+5)"""
+        import ctypes
+        T, B, heads, kv = self.rows[0].shape
+        slots = (_StepSlot * 2)()
+        for s in (0, 1):
+            j = k + s
+            mx, my = self.maps[j % 4]
+            nx, ny = self.maps[(j + 2) % 4]
+            slots[s] = _StepSlot(ptr(self.images[j % self.n]), ptr(self.outs[j % self.n]), ptr(mx), ptr(my),
+                                 ptr(self.steps[(j + 2) % 4]), ptr(nx), ptr(ny),
+                                 ptr(self.rows[(j + 4) % self.n]), ptr(self.starts_tiled), ptr(self.steps[j % 4]))
+        with torch.cuda.device(self._dev):
+            call("attwarp_warp_step_fused_slots", ctypes.cast(slots, ctypes.c_void_p), 2,
+                 _lib.HWC if self.channels_last else _lib.CHW, B, self.C, self.H, self.W, self.Ho, self.Wo, _lib.MODE_IDS[self.mode],
+                 _lib.dtype_id(self.rows[0]), T, self.g, ptr(self._inv[0]), ptr(self._inv[1]), T * B, heads, kv, T * B,
+                 ae.NUM_IMAGE_TOKENS, stream_ptr(self._dev))
+
+    def _reduce(self, j):
+        T, B, heads, kv = self.rows[0].shape
+        ae.attn_reduce_step(self.rows[j % self.n].view(T * B, heads, 1, kv), self.starts_tiled, ae.NUM_IMAGE_TOKENS,
+                            out=self.steps[j % 4].view(T * B, ae.NUM_IMAGE_TOKENS))
+
+    def _maps(self, j):
+        axis_maps_from_attention_steps(self.steps[j % 4], (self.H, self.W), (self.Ho, self.Wo), maps_out=self.maps[j % 4])
+
+    def _resample(self, j):
+        cu.remap_separable(self.images[j % self.n], *self.maps[j % 4], mode=self.mode, channels_last=self.channels_last,
+                           out=self.outs[j % self.n])
+
+    def reset(self):
+        self.k = 0
+
+    def prime(self):
+        k = self.k
+        for j in range(k, k + 4):
+            self._reduce(j)
+        self._maps(k); self._maps(k + 1)
+
+    def _graph(self, pairs):
+        import math
+        key = (self.k % math.lcm(4, self.n), pairs)
+        if key not in self._graphs:
+            g = torch.cuda.CUDAGraph()
+            main = torch.cuda.Stream(device=self._dev)
+            main.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(main):
+                with torch.cuda.graph(g, stream=main):
+                    for q in range(pairs):
+                        self._launch(self.k + 2 * q)
+            torch.cuda.current_stream().wait_stream(main)
+            self._graphs[key] = g
+        return self._graphs[key]
+
+    def step(self):
+        """One launch = two batches."""
+        self._graph(1).replay()
+        self.k += 2
+
+    def run(self, n_batches: int, unroll_pairs: int = 4):
+        """n_batches (even) batches: graphs of ``unroll_pairs`` launches, then single launches."""
+        if n_batches % 2:
+            raise ValueError("PairedStepWarp.run: an even number of batches")
+        pairs = n_batches // 2
+        while pairs >= unroll_pairs:
+            self._graph(unroll_pairs).replay()
+            self.k += 2 * unroll_pairs
+            pairs -= unroll_pairs
+        for _ in range(pairs):
+            self.step()
+
+    def tail(self):
+        """The last four batches of a stream that ends: R(k), R(k+1), M + R of k+2, k+3 (their reduce is done)."""
+        k = self.k
+        self._resample(k); self._resample(k + 1)
+        self._maps(k + 2); self._maps(k + 3)
+        self._resample(k + 2); self._resample(k + 3)
+        self.k += 4
+
+
 class MaskChainStream:
     """Steady-state form of :func:`warp_from_masks` -- the chain ``main_batched.py:243-287`` runs per image -- for a STREAM
     of equally shaped batches.  The stages of the chain belong to different batches and are independent:

@@ -635,7 +635,7 @@ def leg_config5(dev, torch, pipeline, B, K):
     g = torch.Generator(device=dev).manual_seed(55)
     imgs = torch.randint(0, 256, (B, 500, 500, 3), device=dev, dtype=torch.uint8, generator=g)
     txt = torch.randn(B, 32, 4096, device=dev, generator=g)
-    mask = torch.ones(B, 32, device=dev)
+    mask = torch.ones(B, 32, 1, device=dev)
     legs = ["clip_tensor_in", "tower_in", "marginalnet", "warp", "clip_tensor_warped", "tower_warped"]
     acc = {k: 0.0 for k in legs}
     total = 0.0

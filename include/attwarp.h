@@ -239,6 +239,22 @@ ATTWARP_API int attwarp_warp_step_fused(const float* src, float* dst, int layout
                             const void* rows, int n_rows, int heads, int kv_len, const int32_t* starts,
                             int starts_mod, int ntok, void* steps_out, void* stream);
 
+/* ---- the same one-launch step for TWO consecutive batches of the stream per piece ("slots"): R(k), R(k+1) | M(k+2),
+ * M(k+3) | A(k+4), A(k+5) -- every dependency is on an earlier launch, and the launch's ramp and tail are paid once per two
+ * batches.  `slots` is a HOST array of nslots (1 or 2) pointer sets (device pointers, meanings as the arguments of
+ * attwarp_warp_step_fused; `starts` per slot); geometry, dtype and mode are shared.  nslots == 1 equals
+ * attwarp_warp_step_fused.  Both slots must carry the same pieces, write different buffers, and their images must share
+ * their 16-byte alignment. */
+typedef struct attwarp_step_slot {
+  const float* src; float* dst; const float* map_x; const float* map_y;      /* R: resample of this slot's batch       */
+  const void* steps_in; float* map_x_next; float* map_y_next;                 /* M: step maps [T,B,g*g] -> its maps     */
+  const void* rows; const int32_t* starts; void* steps_out;                   /* A: rows [n_rows,heads,kv] -> step maps */
+} attwarp_step_slot;
+ATTWARP_API int attwarp_warp_step_fused_slots(const attwarp_step_slot* slots, int nslots, int layout, int B, int C, int H, int W,
+                                  int H_out, int W_out, int mode, int attn_dtype, int T, int g, const double* inv_x,
+                                  const double* inv_y, int n_rows, int heads, int kv_len, int starts_mod, int ntok,
+                                  void* stream);
+
 /* ---- the attention reduce of batch k+2 and the map construction of batch k+1 of a batch stream in ONE launch (for
  * large images, where the resample keeps its own launch): rows [n_rows = T*B, heads, kv_len] -> steps_out [T*B, ntok];
  * steps_in [T,B,g*g] (the previous call's steps_out buffer of the other parity) -> map_x [B,W_out], map_y [B,H_out].

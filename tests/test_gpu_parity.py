@@ -124,6 +124,38 @@ def test_attn_step_16bit_rows_full_three_vectors(dev, dt):
                 assert torch.equal(got, ae.attn_reduce_step(wide[..., ::2], T(starts, dev), ntok)), (kv, off)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+def test_attn_step_tail_lengths_and_head_counts(dev, dt):
+    """512 < ntok <= 576 (the third 256-token vector of a row carries <= 64 tokens): every tail length, head counts that do
+    and do not fill the last group of heads in flight (1 .. 33), odd and even slice starts and row strides, slices with and
+    without room behind them, rows with zeros / values far below the shared division's range -- against the oracle bit for
+    bit (float32 / float16) or the one-token-per-lane kernel (bfloat16).  (Written for the round-4 shared-tail-vector
+    experiment, docs/experiments.md; kept because no other test varies the head count.)"""
+    from attwarp_amd import attention_extraction as ae
+    rng = np.random.default_rng(79)
+    for ntok in (516, 540, 572, 576):
+        for heads in (1, 3, 5, 13, 16, 32, 33):
+            kv = ntok + (7 if heads % 2 else 4)
+            B = 4
+            a = rng.random((B, heads, 1, kv), dtype=np.float32) ** 5
+            a[0, :, :, ::7] = 0.0                                      # zeros among the numerators
+            a[1, heads // 2] *= 1e-30                                  # one head far below the shared division's range
+            a /= np.maximum(a.sum(-1, keepdims=True), 1e-30)
+            starts = np.array([s0 % (kv - ntok + 1) for s0 in (0, 1, 3, 7)], np.int32)
+            for off in (0, 1):
+                buf = torch.zeros(off + a.size, device=dev, dtype=dt)
+                view = buf[off:].view(B, heads, 1, kv)
+                view.copy_(T(a, dev).to(dt))
+                got = ae.attn_reduce_step(view, T(starts, dev), ntok)
+                if dt == torch.bfloat16:
+                    wide = torch.zeros(B, heads, 1, 2 * kv, device=dev, dtype=dt)
+                    wide[..., ::2] = view
+                    assert torch.equal(got, ae.attn_reduce_step(wide[..., ::2], T(starts, dev), ntok)), (ntok, heads, off)
+                else:
+                    ref = O.attn_reduce_step(N(view), starts, starts + ntok)
+                    assert np.array_equal(N(got).view(np.uint8), ref.view(np.uint8)), (ntok, heads, off)
+
+
 def test_axis_kernels_long_axis_dynamic_lds(dev):
     """An axis of 8192 pixels needs ~100 KB of LDS per workgroup: above the 64 KB a launch gets by default, so the launchers
     grant it to the kernel first.  Same results as the oracle chain; the stream entry points either grant it
@@ -2164,7 +2196,7 @@ def test_config5_data_flow_with_random_clip_tower(dev):
     x = T(imgs, dev)
     g = torch.Generator(device="cpu").manual_seed(6)
     txt = torch.randn(2, 12, 4096, generator=g).to(dev)
-    mask = torch.ones(2, 12, device=dev); mask[1, 7:] = 0
+    mask = torch.ones(2, 12, 1, device=dev); mask[1, 7:] = 0          # [B,Lt,1] as the reference passes it (MN/model.py:77)
     r = pipeline.config5_chain(tower, net, x, txt, mask, out_size=(500, 500))
     assert r["token_map"].shape == (2, 1024, 24, 24) and r["features_warped"].shape == (2, 1024, 24, 24)
     assert r["px"].shape == (2, 24) and abs(float(r["px"][0].sum()) - 1.0) < 1e-5
@@ -2181,9 +2213,11 @@ def test_config5_data_flow_with_random_clip_tower(dev):
     assert torch.equal(pipeline.vision_tower_features(tower, T(hf_in, dev).half()), r["token_map"])
     assert torch.equal(pipeline.vision_tower_features(tower, T(hf_w, dev).half()), r["features_warped"])
     # the legs inside the chain are the stand-alone calls
-    px, py = net(r["token_map"], 24, 24, txt, mask)
-    assert torch.equal(px, r["px"]) and torch.equal(py, r["py"])
-    assert torch.equal(pipeline.warp_from_pdf(x, px, py, (500, 500), channels_last=True), r["warped"])
+    with torch.no_grad():
+        px, py = net(r["token_map"], 24, 24, txt, mask)
+    # (MarginalNet's convolutions are library kernels: the algorithm MIOpen picks may differ between two calls)
+    assert torch.allclose(px, r["px"], rtol=1e-4, atol=1e-7) and torch.allclose(py, r["py"], rtol=1e-4, atol=1e-7)
+    assert torch.equal(pipeline.warp_from_pdf(x, r["px"], r["py"], (500, 500), channels_last=True), r["warped"])
 
 
 def test_marginalnet_to_warp_chain(dev, golden):
@@ -2483,6 +2517,53 @@ def test_mask_chain_stream_equals_warp_from_masks(dev, pattern, case):
         got.append(mc.outs[k % n].clone())
     for j in range(nb):
         assert torch.equal(got[j], refs[j]), (pattern, j)
+
+
+@pytest.mark.parametrize("S,B,layout,mode,adt,n", [(96, 5, "hwc", "cv2", torch.float32, 4), (336, 3, "hwc", "cv2", torch.float16, 6),
+                                                  (64, 2, "chw", "exact", torch.bfloat16, 2), (128, 4, "hwc", "exact", torch.float32, 8)])
+def test_paired_step_warp_equals_serial(dev, S, B, layout, mode, adt, n):
+    """pipeline.PairedStepWarp (one launch = R(2p), R(2p+1) | M(2p+2), M(2p+3) | A(2p+4), A(2p+5)) over a stream of 12
+    DIFFERENT batches copied through rings of n static buffers: every batch equals warp_from_attention_stack on it."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(S + n)
+    nb = 12
+    hwc = layout == "hwc"
+    shape = (B, S, S, 3) if hwc else (B, 3, S, S)
+    imgs = [torch.rand(shape, device=dev, generator=g) for _ in range(nb)]
+    rows = [torch.softmax(torch.randn(3, B, 8, 600, device=dev, generator=g) * 2, -1).to(adt) for _ in range(nb)]
+    starts = (3 + torch.arange(B, device=dev) % 5).to(torch.int32)
+    refs = [pipeline.warp_from_attention_stack(imgs[j], rows[j], starts, channels_last=hwc, mode=mode) for j in range(nb)]
+    ring_i = [torch.empty_like(imgs[0]) for _ in range(n)]
+    ring_r = [torch.empty_like(rows[0]) for _ in range(n)]
+    pw = pipeline.PairedStepWarp(ring_i, ring_r, starts, channels_last=hwc, mode=mode)
+    if n < 6:
+        # the attention runs four batches ahead of the images and a launch reads two slots of each ring: with fewer than
+        # six slots the copies below would overwrite rows a launch still needs -- only the steady state on static data
+        for i in range(n):
+            ring_i[i].copy_(imgs[i % 2]); ring_r[i].copy_(rows[i % 2])
+        pw.prime(); pw.run(8); pw.tail()
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert torch.equal(pw.outs[i], refs[i % 2]), i
+        return
+    for j in range(4):
+        ring_r[j % n].copy_(rows[j])
+    pw.prime()
+    got = {}
+    for k in range(0, nb - 4, 2):
+        for s in (0, 1):
+            ring_i[(k + s) % n].copy_(imgs[k + s])
+            ring_r[(k + 4 + s) % n].copy_(rows[k + 4 + s])
+        pw.step()
+        for s in (0, 1):
+            got[k + s] = pw.outs[(k + s) % n].clone()
+    for k in range(nb - 4, nb):
+        ring_i[k % n].copy_(imgs[k])
+    pw.tail()
+    for k in range(nb - 4, nb):
+        got[k] = pw.outs[k % n].clone()
+    for j in range(nb):
+        assert torch.equal(got[j], refs[j]), j
 
 
 def test_randomised_differential_runs(dev):

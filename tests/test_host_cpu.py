@@ -121,6 +121,40 @@ def test_stream_step_abi_validation_without_gpu(lib):
     assert fcall(ntok=572, steps_in=None) != -2 or b"g*g" not in lib.attwarp_last_error()   # A alone: any multiple of 4
 
 
+def test_step_slots_abi_validation_without_gpu(lib):
+    """attwarp_warp_step_fused_slots (two batches per piece and launch) validates before it enqueues."""
+    import ctypes
+    from attwarp_amd.pipeline import _StepSlot
+    buf = ctypes.create_string_buffer(1 << 16)
+    base = (ctypes.addressof(buf) + 15) & ~15
+    P = [base + 1024 * i for i in range(24)]
+    def slots(**kw):
+        a = (_StepSlot * 2)()
+        a[0] = _StepSlot(P[0], P[1], P[2], P[3], P[4], P[5], P[6], P[7], P[8], P[9])
+        a[1] = _StepSlot(P[10], P[11], P[12], P[13], P[14], P[15], P[16], P[17], P[8], P[19])
+        for k, v in kw.items():
+            setattr(a[1], k, v)
+        return a
+    f = lib.attwarp_warp_step_fused_slots
+    def call(a, nslots=2, **kw):
+        args = dict(layout=0, B=2, C=3, H=64, W=64, H_out=64, W_out=64, mode=1, attn_dtype=0, T=1, g=24, inv_x=P[20], inv_y=P[21],
+                    n_rows=2, heads=4, kv_len=640, starts_mod=2, ntok=576)
+        args.update(kw)
+        return f(ctypes.cast(a, ctypes.c_void_p) if a is not None else None, nslots, *[args[k] for k in
+                 ("layout", "B", "C", "H", "W", "H_out", "W_out", "mode", "attn_dtype", "T", "g", "inv_x", "inv_y", "n_rows", "heads",
+                  "kv_len", "starts_mod", "ntok")], None)
+    assert call(None) == -1 and b"slot table" in lib.attwarp_last_error()
+    assert call(slots(), nslots=3) == -1
+    assert call(slots(src=None)) == -1
+    assert call(slots(dst=P[1])) == -1 and b"different buffers" in lib.attwarp_last_error()
+    assert call(slots(src=P[10] + 4)) == -1 and b"alignment" in lib.attwarp_last_error()
+    assert call(slots(rows=None)) == -1 and b"same pieces" in lib.attwarp_last_error()
+    assert call(slots(map_x_next=P[2])) == -1 and b"alias" in lib.attwarp_last_error()      # slot 1 writes the maps slot 0 reads
+    assert call(slots(steps_out=P[4])) == -1                                                  # ... the step maps slot 0's M reads
+    assert call(slots(), ntok=572) == -2
+    assert call(slots(), mode=9) == -1
+
+
 def test_mask_chain_step_abi_validation_without_gpu(lib):
     """attwarp_mask_chain_step (the one-launch step of the main_batched chain) validates before it enqueues."""
     import ctypes

@@ -1,0 +1,60 @@
+"""Dev tool: same-box A/B of builds of libattwarp_hip.so (alternating subprocesses, one build per process).
+usage: python tools/ab.py <target> libA.so libB.so [...]     targets: attn | remap | step
+(variants inside ONE build are compared with attwarp_debug_set through the tools that take key=value / tune= arguments)"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if "--child" in sys.argv:
+    target = sys.argv[sys.argv.index("--child") + 1]
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from attwarp_amd import _lib
+    _lib.LIB_PATH = os.environ["AB_LIB"]
+    tag = os.path.basename(os.environ["AB_LIB"])
+    import torch
+    from attwarp_amd import pipeline
+    dev = torch.device("cuda:0")
+    if target == "attn":
+        B = 256
+        rows = torch.softmax(torch.randn(20, B, 32, 640, device=dev), -1)
+        starts = (35 + torch.arange(B, device=dev) % 8).int()
+        st = starts.repeat(20)
+        res = []
+        for name, r in (("fp32", rows), ("fp16", rows.half()), ("bf16", rows.bfloat16())):
+            for _ in range(5): pipeline.attention_step_maps(r, starts, 576, st)
+            torch.cuda.synchronize(); ts = []
+            for _ in range(40):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); pipeline.attention_step_maps(r, starts, 576, st); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            res.append(f"{name} {sorted(ts)[len(ts)//2]*1e3:.1f}us")
+        print(tag, " ".join(res), flush=True)
+    elif target == "remap":
+        import remap_bench as rb
+        for rep in range(2):
+            rb.bench(256, 1024, "chw", "uniform", "cv2", tag=tag)
+            rb.bench(256, 1024, "chw", "uniform", "exact", tag=tag)
+            rb.bench(64, 336, "hwc", "uniform", "cv2", 100, tag=tag)
+            rb.bench(256, 336, "hwc", "uniform", "cv2", 50, tag=tag)
+            rb.bench(256, 336, "hwc", "uniform", "exact", 50, tag=tag)
+            rb.bench(256, 336, "chw", "uniform", "cv2", 50, tag=tag)
+        rb.bench(256, 512, "hwc", "uniform", "cv2", 50, tag=tag)
+        rb.bench(256, 336, "hwc", "peaked", "cv2", 50, tag=tag)
+        rb.bench(256, 1024, "chw", "peaked", "cv2", tag=tag)
+        rb.bench(256, 1024, "hwc", "uniform", "cv2", tag=tag)
+    elif target == "step":
+        import bench
+        from attwarp_amd import dist as D
+        for (B, S, K) in ((64, 336, 48), (256, 336, 24)):
+            res, *_ = bench.small_workload(B, S, dev, 5, "cv2", "hwc", K, 2, D, torch, pipeline)
+            print(f"{tag:12s} B={B} S={S}: fused {res['ms_per_step']:.4f} ms/step {res['step_TBps']:.3f} TB/s  same={res['bit_identical_to_serial']}  "
+                  f"eager {res['eager']['ms_per_step']:.4f} stages {res['eager']['stages_ms']}", flush=True)
+            torch.cuda.empty_cache()
+    else:
+        raise SystemExit(__doc__)
+else:
+    if len(sys.argv) < 3:
+        raise SystemExit(__doc__)
+    target = sys.argv[1]
+    libs = [os.path.abspath(p) for p in sys.argv[2:] if p.endswith(".so")]
+    for rep in range(3 if target != "step" else 2):
+        for lib in libs:
+            subprocess.run([sys.executable, __file__, "--child", target], env=dict(os.environ, AB_LIB=lib))

@@ -3,8 +3,8 @@ under profiles/: kernel-stats table, HBM traffic of the resample kernel from the
 bench lines, stage / chain benches.   usage: make_profiles.py [src_tag] [name]   (default r2 round2)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src_tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
-tag = sys.argv[2] if len(sys.argv) > 2 else "round3"
+src_tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[2] if len(sys.argv) > 2 else "round4"
 SRC = os.path.join(ROOT, "gpurun_out", src_tag)
 DST = os.path.join(ROOT, "profiles")
 

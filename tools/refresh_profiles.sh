@@ -3,7 +3,7 @@
 # under gpurun_out/<tag>/.  tools/make_profiles.py turns it into the committed summaries.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"   # (on the GPU box; gpurun merges into the local gpurun_out/, where older files may remain)
 cd /tmp && export TMPDIR=/tmp
@@ -26,7 +26,7 @@ python3 $ROOT/tools/stage_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/stage_bench.
 python3 $ROOT/tools/chain_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
 python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.txt
 python3 $ROOT/tools/remap_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_bench.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_trace -- python3 $ROOT/tools/chain_once.py 256 1024 500 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_trace -- python3 $ROOT/tools/prof.py chain 256 1024 500 > /dev/null 2>&1
 python3 $ROOT/tools/kstats.py $(find $OUT/chain_trace -name "*kernel_stats.csv" | head -1) > $OUT/chain_kernel_stats.txt
 # keep only the summaries (traces are large)
 for d in trace trace_full pmc_fetch_cv2 pmc_write_cv2 pmc_fetch_exact pmc_write_exact; do
