@@ -80,9 +80,13 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // the image: the column-tap prologue is paid once per cpw blocks (peaked maps 0.97 -> 0.93 ms, 768x768x3 0.84 -> 0.76).
   int group = 0, cpw = 1;
   if (!tiled && row_bytes >= 10 * 1024) {
+    // round 4 (profiles/round4_remap_pmc.txt, round4_order_sweep_*.txt): cv2 groups of 8 with 3 row blocks per workgroup
+    // instead of groups of 4 with 2 -- the halo rows that cross XCDs drop from 1/4 to 1/8 of the seams (fabric reads
+    // 1.090 -> 1.051 x algorithmic, total traffic 1.045 -> 1.025 x), +0.7-1 % on both kinds of lease, peaked maps +3 %;
+    // larger groups (12, 16, 24) and more rows per block (5, 6) lose; exact mode is fastest as it was (groups of 3; 8 loses 7 %)
     R = 3;
-    group = mode == ATTWARP_CV2 ? 4 : 3;
-    cpw = mode == ATTWARP_CV2 ? 2 : 1;
+    group = mode == ATTWARP_CV2 ? 8 : 3;
+    cpw = mode == ATTWARP_CV2 ? 3 : 1;
   } else if (!tiled && row_bytes >= 5 * 1024 && mode == ATTWARP_CV2) {
     cpw = 4;
   } else if (!tiled && split) {

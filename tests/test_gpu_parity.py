@@ -1349,6 +1349,60 @@ def test_pipeline_masks_chain_main_batched(dev, golden):
     assert bad <= 1e-4 * out.size
 
 
+@pytest.mark.parametrize("cfg", [(64, 336, 500), (256, 1024, 500)])
+@pytest.mark.parametrize("form", ["serial", "stream"])
+def test_main_batched_chain_full_size_vs_oracle(dev, cfg, form):
+    """The reference's own chain (AGW/main_batched.py:243-287) at full size -- every image of B=64 @ 336 -> 500, a
+    stratified 33 of B=256 @ 1024 -> 500 -- against the oracle STAGE BY STAGE: the revised mask (<= 1 ulp), the uint8
+    LANCZOS mask given the GPU's revised mask (bit-exact; from the oracle's own revised mask at most a few cells flip by
+    1 LSB where the x255 truncation sits on a 1-ulp difference), the float32 maps given the mask (bit-exact), the uint8
+    pixels given the maps (bit-exact), for pipeline.warp_from_masks and for the one-launch stream step
+    (pipeline.MaskChainStream), whose outputs must equal the serial ones for ALL images."""
+    import subprocess
+    from attwarp_amd import pipeline, attention_extraction as ae, new_method as nm
+    from oracle import c_oracle as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    B, S, So = cfg
+    g = torch.Generator(device=dev).manual_seed(300 + S)
+    imgs = torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g)
+    att = torch.rand(B, 24, 24, device=dev, generator=g) ** 3
+    att = att / att.sum((1, 2), keepdim=True)
+    out = pipeline.warp_from_masks(imgs, att, (So, So))
+    if form == "stream":
+        ring_i = [imgs, imgs.flip(0).contiguous()] * 3
+        ring_m = [att, att.flip(0).contiguous()] * 3
+        mc = pipeline.MaskChainStream(ring_i, ring_m, (So, So))
+        assert mc.pattern == "fused"
+        mc.prime(); mc.run(2); mc.drain()
+        assert torch.equal(mc.outs[0], out) and torch.equal(mc.outs[4], out)
+        assert torch.equal(mc.outs[1], pipeline.warp_from_masks(ring_i[1], ring_m[1], (So, So)))
+        return
+    rev = ae.revise_mask(att)
+    mota = ae.upsample_mask_lanczos(rev, (S, S))
+    mx, my = nm.attention_axis_maps(mota, So, So, "identity")
+    assert torch.equal(nm.remap_hwc(imgs, mx, my, "cv2"), out)           # the drop-in is these four launches
+    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
+    idx = torch.tensor(sel, device=dev)
+    att_h, rev_h, mota_h, mx_h, my_h = N(att[idx]), N(rev[idx]), N(mota[idx]), N(mx[idx]), N(my[idx])
+    img_h, out_h = N(imgs[idx]), N(out[idx])
+    flips = 0
+    for i, b in enumerate(sel):
+        orev = O.revise_mask(att_h[i], 3, 10)
+        u = np.abs(rev_h[i].view(np.int32).astype(np.int64) - orev.view(np.int32).astype(np.int64))
+        assert u.max() <= 1, b
+        # given the GPU's revised mask everything downstream is bit-exact
+        assert np.array_equal(mota_h[i], O.lanczos_resize_u8(O.mask_to_u8(rev_h[i]), S, S)), b
+        omx, omy = O.maps_from_attention(mota_h[i], So, So, "identity")
+        assert np.array_equal(mx_h[i], omx) and np.array_equal(my_h[i], omy), b
+        assert np.array_equal(out_h[i], C.remap_bilinear_u8(img_h[i], omx, omy, "cv2")), b
+        # from the oracle's own revised mask: 24 x 24 cells may flip by one grey level, nothing else
+        d = np.abs(O.mask_to_u8(orev).astype(int) - O.mask_to_u8(rev_h[i]).astype(int))
+        assert d.max() <= 1
+        flips += int((d > 0).sum())
+    assert flips <= 1e-3 * len(sel) * 576
+
+
 def test_config1_single_image_chain(dev, golden):
     """BASELINE configs[0] on the GPU: the reference's single-image case (main.py): attention map -> mask ->
     LANCZOS -> float64 marginals -> maps -> uint8 warp, against the maps captured from the reference and the

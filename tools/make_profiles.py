@@ -59,7 +59,7 @@ def pmc(dirname, counter):
 B, S = 256, 1024
 alg = 2 * B * S * S * 3 * 4
 traffic = {}
-for mode in ("cv2", "exact"):
+for mode in ("cv2", "exact", "cv2_chw"):
     fetch, write = pmc(f"pmc_fetch_{mode}", "FETCH_SIZE"), pmc(f"pmc_write_{mode}", "WRITE_SIZE")
     f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
     total = (2 * f_kb + w_kb) * 1024
@@ -67,15 +67,17 @@ for mode in ("cv2", "exact"):
         "remap_rows_kernel_bytes_per_launch": total, "ratio_to_algorithmic": total / alg, "FETCH_SIZE_KB_raw": f_kb,
         "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": min(len(fetch), len(write)),
         "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline "
-                f"--no-also --steps 5 --mode {mode}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
+                f"--no-also --steps 5 --mode {mode.split('_')[0]}{' --layout chw' if mode.endswith('_chw') else ''}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
                 f"MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}
     print(mode, "traffic ratio", total / alg)
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 bench_line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, f"{tag}_bench.json"), "w").write(bench_line)
-for name in ("bench_336", "bench_336x256"):
+for name in ("bench_336", "bench_336x256", "bench_main_batched", "bench_config5", "bench_force_dist"):
     if os.path.exists(os.path.join(SRC, f"{name}.json")):
         open(os.path.join(DST, f"{tag}_{name}.json"), "w").write([l for l in open(os.path.join(SRC, f"{name}.json")) if l.startswith("{")][-1])
-for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench"):
-    shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
+for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench", "chain_stream",
+             "pair_step", "chain_step_kernel_stats"):
+    if os.path.exists(os.path.join(SRC, f"{name}.txt")):
+        shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)

@@ -2,7 +2,7 @@
 itself after `--`: rocprofv3 ... -- python3 tools/prof.py <target> [args]).  AB_LIB=<path> profiles another build.
 
 targets
-  remap [B S kind] [noswz]   float32 resample at BASELINE configs[2] (kind: uniform | peaked)
+  remap [B S] [peaked] [key=value ...]   float32 resample at BASELINE configs[2]; key=value: attwarp_debug_set overrides
   chain [B S So]             every kernel of the main_batched chain (pipeline.warp_from_masks), default 256 1024 500
   chain_step [B S So]        the one-launch chain step (pipeline.MaskChainStream pattern "fused")
   attn                       attention reduce, float32 + float16 rows, bench shape
@@ -46,7 +46,8 @@ if target == "remap":
     py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * sc, 1)
     mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
     img = torch.rand((B, S, S, 3), device=dev); out = torch.empty_like(img)
-    with _lib.debug_override(remap_noswz=int("noswz" in args)) if "noswz" in args else __import__("contextlib").nullcontext():
+    over = {k: int(v) for k, v in (a.split("=") for a in args[1:] if "=" in a)}      # attwarp_debug_set overrides, e.g. remap_noswz=8
+    with _lib.debug_override(**over) if over else __import__("contextlib").nullcontext():
         for _ in range(5):
             cu.remap_separable(img, mx, my, channels_last=True, out=out)
 elif target in ("chain", "chain_step"):

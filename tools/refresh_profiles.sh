@@ -18,6 +18,9 @@ for MODE in cv2 exact; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$MODE -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode $MODE > /dev/null 2>&1
 done
+# the planar layout of the also_chw line (key 1024_cv2_chw of profiles/pmc_traffic.json)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_cv2_chw -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode cv2 --layout chw > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_cv2_chw -- python3 $ROOT/bench.py --no-cpu-baseline --no-also --steps 5 --mode cv2 --layout chw > /dev/null 2>&1
 python3 $ROOT/bench.py --workload 336 --no-cpu-baseline > $OUT/bench_336.json 2> $OUT/bench_336.err
 python3 $ROOT/bench.py --workload 336x256 --no-cpu-baseline > $OUT/bench_336x256.json 2> $OUT/bench_336x256.err
 python3 $ROOT/tools/attn_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/attn_bench.txt
@@ -26,10 +29,18 @@ python3 $ROOT/tools/stage_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/stage_bench.
 python3 $ROOT/tools/chain_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt
 python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.txt
 python3 $ROOT/tools/remap_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_bench.txt
+python3 $ROOT/tools/chain_stream_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_stream.txt
+python3 $ROOT/tools/pair_step_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/pair_step.txt
+python3 $ROOT/bench.py --workload main_batched > $OUT/bench_main_batched.json 2> $OUT/bench_main_batched.err
+python3 $ROOT/bench.py --workload config5 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+python3 $ROOT/bench.py --gpus 1 --force-dist --no-cpu-baseline --legs none > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_step_trace -- python3 $ROOT/tools/prof.py chain_step 256 1024 500 > /dev/null 2>&1
+python3 $ROOT/tools/kstats.py $(find $OUT/chain_step_trace -name "*kernel_stats.csv" | head -1) > $OUT/chain_step_kernel_stats.txt
+rm -rf $OUT/chain_step_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_trace -- python3 $ROOT/tools/prof.py chain 256 1024 500 > /dev/null 2>&1
 python3 $ROOT/tools/kstats.py $(find $OUT/chain_trace -name "*kernel_stats.csv" | head -1) > $OUT/chain_kernel_stats.txt
 # keep only the summaries (traces are large)
-for d in trace trace_full pmc_fetch_cv2 pmc_write_cv2 pmc_fetch_exact pmc_write_exact; do
+for d in trace trace_full pmc_fetch_cv2 pmc_write_cv2 pmc_fetch_exact pmc_write_exact pmc_fetch_cv2_chw pmc_write_cv2_chw; do
   mkdir -p $OUT/keep/$d
   find $OUT/$d -name "*kernel_stats.csv" -exec cp {} $OUT/keep/$d/ \;
   [ "$d" = trace ] && find $OUT/$d -name "*kernel_trace.csv" -exec cp {} $OUT/keep/$d/ \;
