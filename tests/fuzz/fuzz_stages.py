@@ -214,7 +214,23 @@ def g_chain_u8():
     ok = np.array_equal(got, O.warp_image_by_attention(img, att, nw, nh, tr, mode=mode))
     return ok, (h, w, nw, nh, tr, mode)
 
-for name, gen in (("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
+def g_mask_chain_stream():
+    """pipeline.MaskChainStream (the main_batched chain as a batch stream: the one-launch step where the shape is eligible,
+    graph branches otherwise) against pipeline.warp_from_masks batch by batch, and the first batch against the oracle."""
+    B = int(rng.integers(1, 5)); S = 4 * int(rng.integers(8, 180)); So = 4 * int(rng.integers(2, 180)); Ho = int(rng.integers(3, 700))
+    n = int(rng.choice([5, 6, 8])); nb = n + int(rng.integers(0, 4))
+    imgs = [T(rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)) for _ in range(n)]
+    msk = [T(rng.random((B, 24, 24), dtype=np.float32) ** int(rng.integers(1, 5))) for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, So))
+    mc.prime(); mc.run(nb - mc.depth if nb > mc.depth else 0, unroll=int(rng.choice([2, 4])));
+    if nb >= mc.depth: mc.drain()
+    done = min(nb, n) if nb >= mc.depth else 0
+    ok = True
+    for j in range(max(0, nb - n), nb if nb >= mc.depth else 0):
+        ok = ok and bool(torch.equal(mc.outs[j % n], pipeline.warp_from_masks(imgs[j % n], msk[j % n], (Ho, So))))
+    return ok, (B, S, So, Ho, n, nb, mc.pattern)
+
+for name, gen in (("MaskChainStream vs warp_from_masks", g_mask_chain_stream), ("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
                   ("warp_image_by_attention chain", g_chain_u8), ("attention stack -> warp (bench path)", g_stack_chain),
                   ("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
                   ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),

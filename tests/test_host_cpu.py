@@ -421,3 +421,18 @@ def test_golden_marginalnet_full_recipe():
     sd = marginalnet_full_state({k: tuple(v.shape) for k, v in net.state_dict().items()})
     assert abs(sum(v.double().sum().item() for v in sd.values()) - float(g["sd_checksum"])) < 1e-6
     assert sum(v.numel() for v in sd.values()) == int(g["n_params"])
+
+
+def test_bench_lists_and_validates_legs():
+    """bench.py --list-legs names every secondary leg; an unknown leg is refused before anything touches a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--list-legs"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    names = [l.split()[0] for l in r.stdout.splitlines() if l.strip()]
+    assert {"exact", "chw", "fused", "distributions", "336", "fp16_attention", "main_batched", "pool_input", "config5"} <= set(names)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--legs", "no_such_leg"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode != 0 and "unknown leg" in (r.stderr + r.stdout)
+
