@@ -108,9 +108,14 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
       const int pl = HWC ? 0 : d / dpo;
       const int r0 = 4 * (d - pl * dpo);                            // first byte of the dword inside its plane row
       soff[k] = (int)(pl * p.oplane_stride) + r0;
+      // (x, c) of the dword's four bytes: ONE division per dword, then a carry per byte (the division of every byte by
+      // the run-time channel count was 240 of the ~600 instructions of this prologue, which is half of a workgroup's
+      // work at 336 x 336 -> 500 x 500: 16 rows per block)
+      int xj = r0 / p.CS, cj = r0 - xj * p.CS;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int r = r0 + j, x = r / p.CS, c = r - x * p.CS;
+        const int x = xj, c = cj;
+        if (++cj >= p.CS) { cj = 0; ++xj; }
         const float m = p.mx[(long long)b * p.Wo + x];
         const int q = cv_round_q5(m);                               // cvRound
         const int i = q >> 5;

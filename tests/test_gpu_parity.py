@@ -2620,6 +2620,29 @@ def test_paired_step_warp_equals_serial(dev, S, B, layout, mode, adt, n):
         assert torch.equal(got[j], refs[j]), j
 
 
+@pytest.mark.parametrize("case", [dict(S=50, So=33, Ho=47, transform="identity"),          # W % 4 != 0: nothing runs on a staged kernel
+                                  dict(S=96, So=80, Ho=80, transform="sqrt"),               # a transform the one-launch step does not take
+                                  dict(S=24, So=64, Ho=64, transform="identity"),           # no up-sampling of the mask
+                                  dict(S=96, So=80, Ho=80, transform="identity", mode="exact")])
+def test_mask_chain_stream_falls_back_to_branches(dev, case):
+    """Shapes / options attwarp_mask_chain_step refuses (ATTWARP_E_UNSUPPORTED) take the graph-branch pattern of
+    MaskChainStream -- the stand-alone kernels -- and still equal warp_from_masks batch by batch; asking for "fused"
+    explicitly raises."""
+    from attwarp_amd import pipeline
+    S, So, Ho, tr, mode = case["S"], case["So"], case["Ho"], case["transform"], case.get("mode", "cv2")
+    g = torch.Generator(device=dev).manual_seed(S + So)
+    n, B = 4, 3
+    imgs = [torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, So), transform=tr, mode=mode)
+    assert mc.pattern == "branches" and mc.depth == 2
+    mc.prime(); mc.run(6); mc.drain()
+    for j in range(n):
+        assert torch.equal(mc.outs[j], pipeline.warp_from_masks(imgs[j], msk[j], (Ho, So), transform=tr, mode=mode)), j
+    with pytest.raises(_lib.AttWarpError):
+        pipeline.MaskChainStream(imgs, msk, (Ho, So), transform=tr, mode=mode, pattern="fused")
+
+
 def test_randomised_differential_runs(dev):
     """A short run of the two fuzzers (tests/fuzz/fuzz_remap.py, tests/fuzz/fuzz_stages.py: random shapes, dtypes, layouts, modes,
     hostile values; every stage entry point against the oracle): no mismatch.  The long runs behind DESIGN section 4 are
