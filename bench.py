@@ -700,6 +700,86 @@ def leg_config5(dev, torch, pipeline, B, K):
             "accuracy_parity": "unobtainable here: LLaVA-1.5-7B weights, the llava package and TextVQA are absent (no network)"}
 
 
+def leg_other_mode(step, args, D, torch, pipeline, B):
+    """The main batch in the other arithmetic mode (same buffers)."""
+    other = "exact" if args.mode == "cv2" else "cv2"
+    step.mode = other
+    w2, _ = time_steps(step, args.steps, args.warmup, D)
+    out = {f"also_{other}": {"workload": f"same batch, mode={other}", "value": round(B * args.steps / w2, 1),
+                             "unit": "images/s", "ms_per_step": round(w2 / args.steps * 1e3, 4),
+                             "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, other)))}}
+    step.mode = args.mode
+    return out
+
+
+def leg_other_layout(step, args, D, torch, pipeline, B):
+    """The main batch in the other layout (CHW is what warp_from_cdf_torch receives, MN/checkpoint_utils.py:152)."""
+    lay2 = "chw" if args.layout == "hwc" else "hwc"
+    step.set_layout(lay2)
+    w3, _ = time_steps(step, args.steps, args.warmup, D)
+    out = {f"also_{lay2}": {"workload": f"same batch as [B,3,S,S] planar float32, mode={args.mode}" if lay2 == "chw"
+                            else f"same batch as [B,S,S,3], mode={args.mode}",
+                            "value": round(B * args.steps / w3, 1), "unit": "images/s",
+                            "ms_per_step": round(w3 / args.steps * 1e3, 4),
+                            "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{lay2}")))}}
+    step.set_layout(args.layout)
+    return out
+
+
+def leg_fused_1024(step, args, D, torch, pipeline, B):
+    """The 1024 step as ONE launch (attwarp_warp_step_fused through pipeline.OverlappedWarp): at this size it only hides the
+    map construction and two launch boundaries behind the resample."""
+    hwc = args.layout == "hwc"
+    ow = pipeline.OverlappedWarp([x[0] for x in step.sets], [x[1] for x in step.sets], step.starts,
+                                 channels_last=hwc, mode=args.mode, pattern="fused")
+    w5, _ = time_overlapped(ow, args.steps, args.warmup, D)
+    same = bool(torch.equal(ow.outs[0], pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
+                                                                        channels_last=hwc, mode=args.mode)))
+    out = {"also_fused": {"workload": "same batch; reduce + maps + resample of a step as one launch (pattern "
+                                      f"'{ow.pattern}'), HIP-graph replay, exactly {args.steps} of each kernel",
+                          "value": round(B * args.steps / w5, 1), "unit": "images/s",
+                          "ms_per_step": round(w5 / args.steps * 1e3, 4), "bit_identical_to_serial": same,
+                          "step_TBps": round(step_bytes(B, step.S) / (w5 / args.steps) / 1e12, 3)}}
+    del ow
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_distributions(step, args, D, torch, pipeline, B):
+    """SURVEY 8d "value distributions to also run": peaked attention (one 3x3 hot spot x100: strong magnification there,
+    minification elsewhere) and all-zero attention (the uniform fallback, AGW/new_method.py:231-239 / clamp_min(1e-6) in
+    MN/checkpoint_utils.py:36) on the same images."""
+    out = {}
+    for name, rows in (("peaked", peaked_rows(step, torch)), ("zero_attention", torch.zeros_like(step.rows))):
+        keep = step.sets
+        step.sets = [(img, rows, o) for (img, _, o) in keep]
+        w4, _ = time_steps(step, args.steps, args.warmup, D)
+        note = ("all-zero attention collapses the CDF (clamp_min(1e-6), MN/checkpoint_utils.py:36): every output pixel "
+                "maps to the last source rows, the kernel reads almost nothing and is bound by its writes alone -- "
+                "`frac` is against the nominal 2*S*S*3*4 bytes and exceeds what was moved") if name == "zero_attention" else \
+               "one 3x3 hot spot x100 per image: magnified there, minified elsewhere (two source rows per output row)"
+        out[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}", "note": note,
+                               "value": round(B * args.steps / w4, 1), "unit": "images/s",
+                               "ms_per_step": round(w4 / args.steps * 1e3, 4),
+                               "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{name}")))}
+        step.sets = keep
+        del rows
+    return out
+
+
+def leg_small(wl, dev, args, K, D, torch, pipeline, attn_dtype=None):
+    """BASELINE configs[1] / configs[3]'s per-rank batch as a secondary line of the 1024 run (graph-replayed stream step)."""
+    B2, S2, cfg2 = WORKLOADS[wl]
+    res, _, _, st, ow = small_workload(B2, S2, dev, 99, args.mode, args.layout, K, args.warmup, D, torch, pipeline,
+                                       attn_dtype=attn_dtype)
+    what = (f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[{cfg2}]), mode={args.mode}" if attn_dtype is None else
+            f"batch-{B2} {S2}x{S2} per GPU, attention rows float16 (images float32), mode={args.mode}")
+    out = dict({"workload": what, "value": res["images_per_s"], "unit": "images/s", "steps": K}, **res)
+    del st, ow
+    torch.cuda.empty_cache()
+    return out
+
+
 # secondary measurements attached to the default (1024) line on one GPU; `--legs a,b` selects, `--list-legs` prints
 LEGS = {
     "exact": "the main batch in the other arithmetic mode (also_exact / also_cv2)",
@@ -956,83 +1036,26 @@ def main():
         }
 
     one_gpu_1024 = world == 1 and not small
-    if one_gpu_1024 and "exact" in want:
-        other = "exact" if args.mode == "cv2" else "cv2"
-        step.mode = other                                     # same buffers, the other arithmetic
-        w2, _ = time_steps(step, args.steps, args.warmup, D)
-        result[f"also_{other}"] = {"workload": f"same batch, mode={other}", "value": round(B * args.steps / w2, 1),
-                                   "unit": "images/s", "ms_per_step": round(w2 / args.steps * 1e3, 4),
-                                   "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, other)))}
-        step.mode = args.mode
-    if one_gpu_1024 and "chw" in want:
-        # the other layout (CHW is what warp_from_cdf_torch receives, MN/checkpoint_utils.py:152)
-        lay2 = "chw" if args.layout == "hwc" else "hwc"
-        step.set_layout(lay2)
-        w3, _ = time_steps(step, args.steps, args.warmup, D)
-        result[f"also_{lay2}"] = {"workload": f"same batch as [B,3,S,S] planar float32, mode={args.mode}" if lay2 == "chw"
-                                  else f"same batch as [B,S,S,3], mode={args.mode}",
-                                  "value": round(B * args.steps / w3, 1), "unit": "images/s",
-                                  "ms_per_step": round(w3 / args.steps * 1e3, 4),
-                                  "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{lay2}")))}
-        step.set_layout(args.layout)
-    if one_gpu_1024 and "fused" in want:
-        # the same step as ONE launch (attwarp_warp_step_fused through pipeline.OverlappedWarp): at this size it only
-        # hides the map construction and two launch boundaries behind the resample
-        step.set_layout(args.layout)
-        ow = pipeline.OverlappedWarp([x[0] for x in step.sets], [x[1] for x in step.sets], step.starts,
-                                     channels_last=(args.layout == "hwc"), mode=args.mode, pattern="fused")
-        w5, _ = time_overlapped(ow, args.steps, args.warmup, D)
-        same = bool(torch.equal(ow.outs[0], pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
-                                                                            channels_last=(args.layout == "hwc"), mode=args.mode)))
-        result["also_fused"] = {"workload": "same batch; reduce + maps + resample of a step as one launch (pattern "
-                                            f"'{ow.pattern}'), HIP-graph replay, exactly {args.steps} of each kernel",
-                                "value": round(B * args.steps / w5, 1), "unit": "images/s",
-                                "ms_per_step": round(w5 / args.steps * 1e3, 4), "bit_identical_to_serial": same,
-                                "step_TBps": round(step_bytes(B, S) / (w5 / args.steps) / 1e12, 3)}
-        del ow
-        torch.cuda.empty_cache()
-    if one_gpu_1024 and "distributions" in want:
-        # SURVEY 8d "value distributions to also run": peaked attention (one 3x3 hot spot x100: strong magnification
-        # there, minification elsewhere) and all-zero attention (the uniform fallback, AGW/new_method.py:231-239 /
-        # clamp_min(1e-6) in MN/checkpoint_utils.py:36) on the same images
-        step.set_layout(args.layout)
-        for name, rows in (("peaked", peaked_rows(step, torch)), ("zero_attention", torch.zeros_like(step.rows))):
-            keep = step.sets
-            step.sets = [(img, rows, out) for (img, _, out) in keep]
-            w4, _ = time_steps(step, args.steps, args.warmup, D)
-            note = ("all-zero attention collapses the CDF (clamp_min(1e-6), MN/checkpoint_utils.py:36): every output pixel "
-                    "maps to the last source rows, the kernel reads almost nothing and is bound by its writes alone -- "
-                    "`frac` is against the nominal 2*S*S*3*4 bytes and exceeds what was moved") if name == "zero_attention" else \
-                   "one 3x3 hot spot x100 per image: magnified there, minified elsewhere (two source rows per output row)"
-            result[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}", "note": note,
-                                      "value": round(B * args.steps / w4, 1), "unit": "images/s",
-                                      "ms_per_step": round(w4 / args.steps * 1e3, 4),
-                                      "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{name}")))}
-            step.sets = keep
-            del rows
+    if one_gpu_1024:
+        ctx = dict(step=step, args=args, D=D, torch=torch, pipeline=pipeline, B=B)
+        if "exact" in want:
+            result.update(leg_other_mode(**ctx))
+        if "chw" in want:
+            result.update(leg_other_layout(**ctx))
+        if "fused" in want:
+            result.update(leg_fused_1024(**ctx))
+        if "distributions" in want:
+            result.update(leg_distributions(**ctx))
     del step
     torch.cuda.empty_cache()
 
     n2 = max(args.steps, 48)
     if world == 1 and args.workload == "1024" and "336" in want:
         for key, wl in (("also", "336"), ("also_336x256", "336x256")):
-            B2, S2, cfg2 = WORKLOADS[wl]
-            res2, _, _, st2, ow2 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline)
-            res2 = dict({"workload": f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[{cfg2}]), mode={args.mode}",
-                         "value": res2["images_per_s"], "unit": "images/s", "steps": n2}, **res2)
-            result[key] = res2
-            del st2, ow2
-            torch.cuda.empty_cache()
+            result[key] = leg_small(wl, dev, args, n2, D, torch, pipeline)
     if world == 1 and args.workload == "1024" and "fp16_attention" in want:
-        # the same per-rank batch with the attention rows in float16, the dtype LLaVA-1.5 emits (half the reduce's bytes)
-        B2, S2, cfg2 = WORKLOADS["336x256"]
-        res3, _, _, st3, ow3 = small_workload(B2, S2, dev, 99, args.mode, args.layout, n2, args.warmup, D, torch, pipeline,
-                                              attn_dtype=torch.float16)
-        result["also_336x256_fp16_attention"] = dict(
-            {"workload": f"batch-{B2} {S2}x{S2} per GPU, attention rows float16 (images float32), mode={args.mode}",
-             "value": res3["images_per_s"], "unit": "images/s", "steps": n2}, **res3)
-        del st3, ow3
-        torch.cuda.empty_cache()
+        # configs[3]'s per-rank batch with the attention rows in float16, the dtype LLaVA-1.5 emits (half the reduce's bytes)
+        result["also_336x256_fp16_attention"] = leg_small("336x256", dev, args, n2, D, torch, pipeline, attn_dtype=torch.float16)
     if world == 1 and args.workload == "1024":
         # (a failure inside one of these legs -- e.g. `transformers` missing for the vision tower -- must not cost the main line)
         for key, leg in (("main_batched", lambda: leg_main_batched(dev, torch, pipeline, n2)),
