@@ -2263,9 +2263,13 @@ def test_config5_data_flow_with_random_clip_tower(dev):
     assert torch.equal(r["pixel_values_in"], T(hf_in, dev).half())
     hf_w = proc.preprocess([w for w in N(r["warped"])], return_tensors="np")["pixel_values"]
     assert torch.equal(r["pixel_values_warped"], T(hf_w, dev).half())
-    # identical inputs -> identical tower features (same kernels, same shapes: run-to-run deterministic)
-    assert torch.equal(pipeline.vision_tower_features(tower, T(hf_in, dev).half()), r["token_map"])
-    assert torch.equal(pipeline.vision_tower_features(tower, T(hf_w, dev).half()), r["features_warped"])
+    # identical inputs (asserted above: that is the product's part) -> the same tower features; the tower is library GEMM /
+    # attention kernels, bit-identical from run to run on every lease so far -- a different algorithm choice between two
+    # calls would still have to agree to float16 accuracy
+    def same(a, b):
+        return bool(torch.equal(a, b)) or bool(torch.allclose(a.float(), b.float(), rtol=2e-3, atol=2e-3))
+    assert same(pipeline.vision_tower_features(tower, T(hf_in, dev).half()), r["token_map"])
+    assert same(pipeline.vision_tower_features(tower, T(hf_w, dev).half()), r["features_warped"])
     # the legs inside the chain are the stand-alone calls
     with torch.no_grad():
         px, py = net(r["token_map"], 24, 24, txt, mask)
