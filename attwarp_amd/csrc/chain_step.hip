@@ -108,12 +108,18 @@ __global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const C
 
 // proportional interleave of three block kinds inside a period of CHAIN_Q octets (largest-remainder rounding, then an
 // even spread: position i goes to the kind that is furthest behind its share)
-// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved
+// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved;
+// 3 / 4: see below (measured, not the default)
 static void build_interleave(ChainStepArgs& a, int order) {
   const bool sequential = order == 1;
   int n8[3] = {(a.nP + 7) / 8, (a.nL + 7) / 8, (a.nR + 7) / 8};
   a.nPfirst8 = 0;
   if (order == 2) { a.nPfirst8 = n8[0]; n8[0] = 0; }
+  // 3 = P and R interleaved, then all of L; 4 = P and L interleaved, then all of R (the excluded kind is laid out behind
+  // the interleaved part as one range)
+  const int excl = order == 3 ? 1 : order == 4 ? 2 : -1;
+  const int n8_excl = excl >= 0 ? n8[excl] : 0;
+  if (excl >= 0) n8[excl] = 0;
   const long long tot = (long long)n8[0] + n8[1] + n8[2];
   int q[3] = {0, 0, 0};
   a.periods = 0;
@@ -161,6 +167,7 @@ static void build_interleave(ChainStepArgs& a, int order) {
     a.q[t] = q[t];
     a.left8[t] = n8[t] - a.periods * q[t];
   }
+  if (excl >= 0) a.left8[excl] = n8_excl;
 }
 
 template <int KI, int KD>
