@@ -239,7 +239,6 @@ template <int TR>
 __device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ A, int H, int W, const XfAttention<TR>& xf,
                                                   const PairwisePlan& P, double* __restrict__ col,
                                                   double* __restrict__ ls, int leaf, int b, uint8_t* lds) {
-  constexpr int NT = PROF_NT;
   constexpr bool ARITH = (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE);
   uint8_t (*tile)[U8_RB * U8_STR] = reinterpret_cast<uint8_t (*)[U8_RB * U8_STR]>(lds);
   double* lut = reinterpret_cast<double*>(lds + 2 * U8_RB * U8_STR);
