@@ -717,6 +717,27 @@ class PairedStepWarp:
         self.k += 4
 
 
+def pair_slots(ring):
+    """Views of a ring of equally shaped [B, ...] buffers as a ring of half the length of [2B, ...] buffers: slot i = the
+    batches 2i and 2i+1 as ONE batch, for running two batches of a stream per launch (``MaskChainStream(pair_slots(images),
+    pair_slots(masks), ...)``: a launch's ramp and tail, and at small batches its unfilled machine, are then paid once per
+    two batches; the reference's BATCH_SIZE = 32 is a memory choice of the LLaVA pass, the warp is free to take two).
+    Needs an even number of slots with slot 2i+1 directly behind slot 2i in memory, e.g. ``ring = list(torch.empty(n, B,
+    ...))``.  The outputs of such a stream are [2B, ...] too: ``out[:B]`` / ``out[B:]``."""
+    ring = list(ring)
+    if len(ring) % 2:
+        raise ValueError("pair_slots: an even number of slots expected")
+    out = []
+    for a, b in zip(ring[0::2], ring[1::2]):
+        if (a.shape != b.shape or a.dtype != b.dtype or a.device != b.device or not (a.is_contiguous() and b.is_contiguous())
+                or b.data_ptr() != a.data_ptr() + a.numel() * a.element_size()
+                or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()):
+            raise ValueError("pair_slots: slot 2i+1 must lie directly behind slot 2i in the same allocation "
+                             "(allocate the ring as one tensor [n, B, ...])")
+        out.append(torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset()))
+    return out
+
+
 class MaskChainStream:
     """Steady-state form of :func:`warp_from_masks` -- the chain ``main_batched.py:243-287`` runs per image -- for a STREAM
     of equally shaped batches.  The stages of the chain belong to different batches and are independent:

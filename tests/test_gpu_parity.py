@@ -2647,6 +2647,25 @@ def test_mask_chain_stream_falls_back_to_branches(dev, case):
         pipeline.MaskChainStream(imgs, msk, (Ho, So), transform=tr, mode=mode, pattern="fused")
 
 
+def test_mask_chain_two_batches_per_launch(dev):
+    """pipeline.pair_slots: slots 2i, 2i+1 of rings allocated as one tensor, run as ONE batch of 2B through MaskChainStream
+    (two batches of the stream per launch), give the bytes of the one-batch-per-launch stream and of warp_from_masks."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(8)
+    n, B, S, So = 12, 3, 96, 80
+    imgs = torch.randint(0, 256, (n, B, S, S, 3), device=dev, dtype=torch.uint8, generator=g)
+    msk = torch.rand(n, B, 24, 24, device=dev, generator=g)
+    mc2 = pipeline.MaskChainStream(pipeline.pair_slots(list(imgs)), pipeline.pair_slots(list(msk)), (So, So))
+    assert mc2.pattern == "fused" and mc2.B == 2 * B and mc2.n == n // 2
+    mc2.prime(); mc2.run(n // 2 - mc2.depth); mc2.drain()
+    for i in range(n):
+        assert torch.equal(mc2.outs[i // 2][(i % 2) * B:(i % 2 + 1) * B], pipeline.warp_from_masks(imgs[i], msk[i], (So, So))), i
+    with pytest.raises(ValueError):
+        pipeline.pair_slots([imgs[0], imgs[2]])                    # not adjacent
+    with pytest.raises(ValueError):
+        pipeline.pair_slots(list(imgs[:3]))                        # odd
+
+
 def test_randomised_differential_runs(dev):
     """A short run of the two fuzzers (tests/fuzz/fuzz_remap.py, tests/fuzz/fuzz_stages.py: random shapes, dtypes, layouts, modes,
     hostile values; every stage entry point against the oracle): no mismatch.  The long runs behind DESIGN section 4 are

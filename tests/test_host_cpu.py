@@ -436,3 +436,17 @@ def test_bench_lists_and_validates_legs():
                        timeout=120)
     assert r.returncode != 0 and "unknown leg" in (r.stderr + r.stdout)
 
+
+def test_pair_slots_views():
+    """pipeline.pair_slots (two batches of a stream as one): views, not copies; adjacency and parity are checked."""
+    from attwarp_amd import pipeline
+    r = torch.arange(4 * 3 * 2, dtype=torch.float32).reshape(4, 3, 2)
+    ps = pipeline.pair_slots(list(r))
+    assert len(ps) == 2 and tuple(ps[0].shape) == (6, 2) and torch.equal(ps[1], r[2:4].reshape(6, 2))
+    ps[0][4, 1] = -1.0
+    assert float(r[1, 1, 1]) == -1.0                               # a view of the ring's memory
+    with pytest.raises(ValueError):
+        pipeline.pair_slots([torch.zeros(3, 2), torch.zeros(3, 2)])
+    with pytest.raises(ValueError):
+        pipeline.pair_slots(list(r[:3]))
+
