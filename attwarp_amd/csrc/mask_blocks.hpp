@@ -186,6 +186,8 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
 #pragma unroll
   for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)r_beg * 8 + y];
   uint32_t* orow = reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + r_beg) * out_w) + min(q, nq - 1);
+  int round_half = 1 << (PIL_PRECISION_BITS - 1);
+  asm volatile("" : "+v"(round_half));                      // one register for the whole loop (not an inline constant: VOP3 takes none)
   for (int yy = r_beg; yy < r_end; ++yy) {
     const int ymin = ymin_c;
     int kv[8];
@@ -206,12 +208,18 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
       }
       base = ymin;
     }
-    int s0 = 1 << (PIL_PRECISION_BITS - 1), s1 = s0, s2 = s0, s3 = s0;
+    // one v_mad_i32_i24 per tap and pixel (left to itself the compiler pairs v_mul_i32_i24 with v_add3_u32: 1.5
+    // instructions per tap); the coefficient is wave uniform and sits in an SGPR.  The first tap takes Pillow's rounding
+    // constant from a loop-invariant register as its addend (as "sum = constant; sum += ..." every output row paid four
+    // v_mov_b32 to re-materialise it: a tenth of this loop's instructions)
+    int s0, s1, s2, s3;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s0) : "v"(win[0][0]), "s"(kv[0]), "v"(round_half));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s1) : "v"(win[0][1]), "s"(kv[0]), "v"(round_half));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s2) : "v"(win[0][2]), "s"(kv[0]), "v"(round_half));
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s3) : "v"(win[0][3]), "s"(kv[0]), "v"(round_half));
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
+    for (int y = 1; y < 8; ++y) {
       if (y == 7 && kv[7] == 0) break;                       // 24 -> 1024 has 7 taps: the padded 8th is skipped (uniform)
-      // one v_mad_i32_i24 per tap and pixel (left to itself the compiler pairs v_mul_i32_i24 with v_add3_u32:
-      // 1.5 instructions per tap); the coefficient is wave uniform and sits in an SGPR
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s0) : "v"(win[y][0]), "s"(kv[y]));
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s1) : "v"(win[y][1]), "s"(kv[y]));
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s2) : "v"(win[y][2]), "s"(kv[y]));
