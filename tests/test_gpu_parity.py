@@ -2647,6 +2647,23 @@ def test_mask_chain_stream_falls_back_to_branches(dev, case):
         pipeline.MaskChainStream(imgs, msk, (Ho, So), transform=tr, mode=mode, pattern="fused")
 
 
+@pytest.mark.parametrize("H,W,C,Ho,Wo,ks,coe", [(64, 96, 3, 80, 60, 3, 10.0), (96, 64, 1, 50, 100, 5, 4.0), (48, 80, 4, 64, 64, 7, 10.0),
+                                                 (128, 132, 2, 90, 34, 1, 25.0), (500, 500, 3, 336, 336, 3, 10.0)])
+def test_mask_chain_step_shapes_channels_filters(dev, H, W, C, Ho, Wo, ks, coe):
+    """The one-launch chain step on non-square images, 1 / 2 / 3 / 4 channels, other box-filter sizes and enhancement
+    strengths, down- and up-sampling outputs: every batch equals warp_from_masks with the same options."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(H + W + C)
+    n, B = 6, 2
+    imgs = [torch.randint(0, 256, (B, H, W, C), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) ** 2 for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, Wo), enhance_coe=coe, kernel_size=ks, pattern="fused")
+    mc.prime(); mc.run(n - mc.depth); mc.drain()
+    for j in range(n):
+        ref = pipeline.warp_from_masks(imgs[j], msk[j], (Ho, Wo), enhance_coe=coe, kernel_size=ks)
+        assert torch.equal(mc.outs[j], ref), j
+
+
 def test_mask_chain_two_batches_per_launch(dev):
     """pipeline.pair_slots: slots 2i, 2i+1 of rings allocated as one tensor, run as ONE batch of 2B through MaskChainStream
     (two batches of the stream per launch), give the bytes of the one-batch-per-launch stream and of warp_from_masks."""
