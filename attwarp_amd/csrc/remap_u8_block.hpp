@@ -167,8 +167,9 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
     const unsigned w1_ = KY, w0_ = 32u - KY;                                                           \
     const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
-      const uint32_t a02_ = AX[k] & 0x00ff00ffu, a13_ = (AX[k] >> 8) & 0x00ff00ffu;                      \
-      const uint32_t c02_ = CX[k] & 0x00ff00ffu, c13_ = (CX[k] >> 8) & 0x00ff00ffu;                      \
+      /* bytes (0, 2) and (1, 3) zero-extended to two u16: an and, and ONE v_perm_b32 (shift + and before) */ \
+      const uint32_t a02_ = AX[k] & 0x00ff00ffu, a13_ = __builtin_amdgcn_perm(0u, AX[k], 0x0c030c01u);   \
+      const uint32_t c02_ = CX[k] & 0x00ff00ffu, c13_ = __builtin_amdgcn_perm(0u, CX[k], 0x0c030c01u);   \
       const us2 v02_ = __builtin_bit_cast(us2, a02_) * w0p_ + __builtin_bit_cast(us2, c02_) * w1p_;      \
       const us2 v13_ = __builtin_bit_cast(us2, a13_) * w0p_ + __builtin_bit_cast(us2, c13_) * w1p_;      \
       uint2 st_;                                                                                       \
