@@ -1963,6 +1963,12 @@ def test_bench_gpus2_self_launch_on_one_gpu(dev):
     assert d["value"] > 0 and d["roofline"]["frac"] > 0
     # the 336x336 workloads time the HIP-graph path (no host call per kernel); it must equal the serial result
     assert d["bit_identical_to_serial"] is True and d["rccl_ranks_seen"] == [0, 1] and "also_eager" in d
+    # the curve apart from GPU-to-GPU spread: job rate / (N x mean rank rate) -- 1.0 when the ranks are equally fast, below it
+    # by exactly the spread (value divides by the slowest rank's time)
+    assert len(d["per_rank_roofline_frac"]) == 2 and d["dist_backend"] == "gloo"
+    rates = d["per_rank_images_per_s"]
+    assert 0.5 < d["scaling_efficiency_vs_rank_mean"] <= 1.0 + 1e-6
+    assert abs(d["scaling_efficiency_vs_rank_mean"] - d["value"] / (2 * sum(rates) / 2)) < 2e-3
 
 
 _RCCL_ONE_RANK = r"""
