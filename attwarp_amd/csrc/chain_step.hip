@@ -29,10 +29,12 @@ namespace attwarp {
 constexpr int CHAIN_NT = 256;
 constexpr int CHAIN_Q = 32;                 // octets per period of the P / L / R interleave
 constexpr int CHAIN_ORDER_DEFAULT = 2;      // see build_interleave
+constexpr int CHAIN_PRIO_DEFAULT = 0;
 constexpr int CHAIN_WAVES_DEFAULT = 8;      // waves per SIMD the register allocation leaves room for
 
 struct ChainStepArgs {
   int B;
+  int prio;                                 // 1: the F and V blocks (one lane's dependent chain each) raise their wave priority
   int nF8, nV8;                             // octets (8 blocks) of the F and V ranges
   int nPfirst8;                             // octets of P laid out as one range right behind them (0: P is interleaved)
   int nP, nL, nR;                           // blocks of P, L, R
@@ -51,28 +53,32 @@ struct ChainStepArgs {
   MapsFinalizeArgs fa;
   // R
   u8k::Params rp;
+#ifdef ATTWARP_TUNING
+  unsigned long long* trace;                // block timeline (common.hpp: trace_buffer), null = off
+#endif
 };
 
-template <int KI, int KD, int PD, int MINW>
-__global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const ChainStepArgs a, const PairwisePlan Pw,
-                                                                         const PairwisePlan Ph) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
+// one block of the step; returns the kind of work it did (0 F, 1 V, 2 P, 3 L, 4 R, -1 padding)
+template <int KI, int KD, int PD>
+__device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const PairwisePlan& Pw, const PairwisePlan& Ph, uint8_t* pool) {
   const int blk = blockIdx.x, l8 = blk & 7;
   int oct = blk >> 3;
   if (oct < a.nF8) {
-    if (blk < 2 * a.B) attention_maps_finalize_block(Pw, Ph, a.fa, blk >> 1, blk & 1, reinterpret_cast<double*>(pool));
-    return;
+    if (blk >= 2 * a.B) return -1;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    attention_maps_finalize_block(Pw, Ph, a.fa, blk >> 1, blk & 1, reinterpret_cast<double*>(pool));
+    return 0;
   }
   oct -= a.nF8;
   if (oct < a.nV8) {
     const int j = oct * 8 + l8;
-    if (j < a.B) {
-      float* x = reinterpret_cast<float*>(pool);
-      double* red = reinterpret_cast<double*>(pool + 32 * 32 * sizeof(float));
-      float* fred = reinterpret_cast<float*>(red + CHAIN_NT / WAVE);
-      mask_postproc_block(a.masks, a.g, a.ks, a.coe, a.rev_out, j, x, red, fred);
-    }
-    return;
+    if (j >= a.B) return -1;
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    float* x = reinterpret_cast<float*>(pool);
+    double* red = reinterpret_cast<double*>(pool + 32 * 32 * sizeof(float));
+    float* fred = reinterpret_cast<float*>(red + CHAIN_NT / WAVE);
+    mask_postproc_block(a.masks, a.g, a.ks, a.coe, a.rev_out, j, x, red, fred);
+    return 1;
   }
   oct -= a.nV8;
   int t, idx8;
@@ -91,19 +97,34 @@ __global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const C
   }
   const int j = idx8 * 8 + l8;
   if (t == 0) {
-    if (j < a.nP) {
-      const int b = j / Pw.nleaves, leaf = j - b * Pw.nleaves;
-      profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw, a.col_out,
-                                            a.ls_out, leaf, b, pool);
-    }
-  } else if (t == 1) {
-    if (j < a.nL) {
-      const int b = j / a.l_bx, bx = j - b * a.l_bx;
-      lanczos_strip_block<8>(a.la, bx, b, pool);
-    }
-  } else {
-    if (j < a.nR) u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
+    if (j >= a.nP) return -1;
+    const int b = j / Pw.nleaves, leaf = j - b * Pw.nleaves;
+    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw, a.col_out,
+                                          a.ls_out, leaf, b, pool);
+    return 2;
   }
+  if (t == 1) {
+    if (j >= a.nL) return -1;
+    const int b = j / a.l_bx, bx = j - b * a.l_bx;
+    lanczos_strip_block<8>(a.la, bx, b, pool);
+    return 3;
+  }
+  if (j >= a.nR) return -1;
+  u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
+  return 4;
+}
+
+template <int KI, int KD, int PD, int MINW>
+__global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const ChainStepArgs a, const PairwisePlan Pw,
+                                                                         const PairwisePlan Ph) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
+#ifdef ATTWARP_TUNING
+  const TraceStart t0 = trace_now();
+  const int kind = chain_step_block<KI, KD, PD>(a, Pw, Ph, pool);
+  trace_block(a.trace, t0, kind);
+#else
+  chain_step_block<KI, KD, PD>(a, Pw, Ph, pool);
+#endif
 }
 
 // proportional interleave of three block kinds inside a period of CHAIN_Q octets (largest-remainder rounding, then an
@@ -230,6 +251,7 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   if (!u8i_params(a.rp, images, out, ATTWARP_HWC, B, C, H, W, H_out, W_out, map_x, map_y))
     return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: this image shape / alignment does not run on the integer cv2 resample");
   a.B = B;
+  a.prio = tune(TUNE_STEP_PRIO) >= 0 ? tune(TUNE_STEP_PRIO) : CHAIN_PRIO_DEFAULT;
   a.masks = masks; a.g = g; a.ks = kernel_size; a.coe = enhance_coe; a.rev_out = rev_out;
   {   // L geometry: as attwarp_mask_upsample_lanczos
     const int nstrips = (W + MASK_NT - 1) / MASK_NT;
@@ -254,6 +276,10 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   a.nL = a.l_bx * B;
   a.nR = a.rp.nblocks;
   build_interleave(a, tune(TUNE_CHAIN_SEQ) >= 0 ? tune(TUNE_CHAIN_SEQ) : CHAIN_ORDER_DEFAULT);
+#ifdef ATTWARP_TUNING
+  a.trace = trace_buffer();
+  a.fa.trace = a.trace;
+#endif
   const long long octs = (long long)a.nF8 + a.nV8 + a.nPfirst8 + (long long)a.periods * CHAIN_Q + a.left8[0] + a.left8[1] + a.left8[2];
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");
   size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),

@@ -178,12 +178,58 @@ enum TuneKey {
   TUNE_U8_AHEAD,            // integer uint8 resample: output rows whose source rows are requested ahead (1, 2, 4)
   TUNE_CHAIN_SEQ,           // block order of the one-launch mask-chain step: 0 interleaved, 1 P / L / R ranges, 2 P first then L / R interleaved, 3 P + R then L, 4 P + L then R
   TUNE_CHAIN_WAVES,         // 6 / 8: waves per SIMD its register allocation leaves room for
+  TUNE_REMAP_PAIR,          // float32 staged resample, rows <= 4 KB: 0 = one row stream per block, 1 = two (default)
+  TUNE_STEP_PRIO,           // one-launch steps: 1 = the latency-chain blocks (maps / finalize / revise) run at raised wave priority
+  TUNE_TRACE_LO,            // block timeline of the one-launch steps (tools/gantt.py): bits 0..23 and 24..47 of the address of a
+  TUNE_TRACE_HI,            //   device buffer of TRACE_WORDS x uint64 per block (layout below)
   TUNE_COUNT
 };
 #ifdef ATTWARP_TUNING
 int tune(TuneKey k);        // current override or -1
 #else
 constexpr int tune(TuneKey) { return -1; }
+#endif
+
+#ifdef ATTWARP_TUNING
+// Block timeline of the kernels that carry it, tuning flavour only (the product kernels carry none of it).  One record
+// of TRACE_WORDS x uint64 per block (tools/gantt.py):
+//   0 start, 1 end (s_memrealtime, 100 MHz)   2 kind   3 HW_ID | XCC_ID << 32   4 start, 5 end (s_memtime, shader clock)
+//   6 what words 7.. hold: 1 = s_memtime stamps of the body's marks (zero = unused), 2 = cycle sums [stage, sync, gather, rows]
+constexpr int TRACE_WORDS = 16;
+inline unsigned long long* trace_buffer() {
+  const int lo = tune(TUNE_TRACE_LO), hi = tune(TUNE_TRACE_HI);
+  if (lo < 0 || hi < 0) return nullptr;
+  return reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 24) | (unsigned long long)lo);
+}
+#ifdef __HIPCC__
+struct TraceStart { unsigned long long real, cyc; };
+__device__ __forceinline__ TraceStart trace_now() { return TraceStart{__builtin_amdgcn_s_memrealtime(), __builtin_amdgcn_s_memtime()}; }
+// a body's mark i (0..8): thread 0 stamps the shader clock
+__device__ __forceinline__ void trace_mark(unsigned long long* tr, int i) {
+  if (tr && threadIdx.x == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned long long* r = tr + TRACE_WORDS * (size_t)blockIdx.x;
+    r[6] = 1;
+    r[7 + i] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+// after the block's work: every wave has passed the barrier, thread 0 writes the record
+__device__ __forceinline__ void trace_block(unsigned long long* tr, TraceStart t0, int kind) {
+  if (!tr) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long* r = tr + TRACE_WORDS * (size_t)blockIdx.x;
+    r[0] = t0.real;
+    r[1] = __builtin_amdgcn_s_memrealtime();
+    r[2] = (unsigned long long)(long long)kind;
+    r[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |             // HW_REG_HW_ID
+           ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);      // HW_REG_XCC_ID
+    r[4] = t0.cyc;
+    r[5] = __builtin_amdgcn_s_memtime();
+  }
+}
+#endif
 #endif
 
 }  // namespace attwarp

@@ -354,7 +354,15 @@ struct MapsFinalizeArgs {
   float* map_x;              // [B, new_w]
   float* map_y;              // [B, new_h]
   int depth_w;               // pw_depth of the row plan (the per-thread stack of the leaf-combine program)
+#ifdef ATTWARP_TUNING
+  unsigned long long* trace; // block timeline (common.hpp), null = off
+#endif
 };
+#ifdef ATTWARP_TUNING
+#define ATTWARP_F_MARK(i_) trace_mark(a.trace, i_);
+#else
+#define ATTWARP_F_MARK(i_)
+#endif
 // LDS of one workgroup: knots (max(h,w) + 2 doubles) | red | per-thread stacks | leaf sums | the two plans
 inline size_t maps_finalize_lds_bytes(int h, int w, const PairwisePlan& Pw, const PairwisePlan& Ph) {
   const int n = h > w ? h : w, nl = Pw.nleaves > Ph.nleaves ? Pw.nleaves : Ph.nleaves;
@@ -379,6 +387,7 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
   const PlanView Pw = plan_to_lds(Pw_arg, pv);           // numpy's pairwise plan of a row (w terms)
   const PlanView Ph = plan_to_lds(Ph_arg, pv + plan_view_lds_bytes(Pw_arg.nleaves));   // ... of a column profile (h terms)
   __syncthreads();
+  ATTWARP_F_MARK(0)
   const int n = axis ? h : w;            // profile length
   const int other = axis ? w : h;        // number of terms summed into each profile entry
   const int n_out = axis ? new_h : new_w;
@@ -407,12 +416,15 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
     all += v;
     if (axis == 1) xn[k + 1] = inv_bias(v, w); else acc_other += inv_bias(v, w);
   }
+  ATTWARP_F_MARK(1)
   acc_other = block_sum(acc_other, red);
   all = block_sum(all, red);
   __syncthreads();
+  ATTWARP_F_MARK(2)
   const double total_self = axis ? pw_sum_block(xn + 1, Ph, leafbuf) : pw_sum_block(xn + 1, Pw, leafbuf);   // np.sum(profile)
   double total = total_self;
   const bool fallback = (total_self < 1e-9) || (acc_other < 1e-9);
+  ATTWARP_F_MARK(3)
   if (fallback) {
     for (int k = threadIdx.x; k < n; k += blockDim.x) xn[k + 1] = 1.0;
     // total_att_x = w * (np.mean(att_map_biased) * h); total_att_y = h * (mean * w); then max(., EPS)
@@ -439,6 +451,7 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
     for (; k <= n; ++k) { c = c + xn[k]; xn[k] = c; }
   }
   __syncthreads();
+  ATTWARP_F_MARK(4)
   // (cum / total) * new ; knot 0 = 0 * new ; last knot = new
   for (int k = threadIdx.x + 1; k <= n; k += blockDim.x) xn[k] = (xn[k] / total) * (double)n_out;
   __syncthreads();
@@ -447,8 +460,12 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
     xn[n] = (double)n_out;
   }
   __syncthreads();
+  ATTWARP_F_MARK(5)
   const bool mono = block_is_sorted(xn, n + 1);
+  ATTWARP_F_MARK(6)
   np_interp_block(xn, n + 1, n_out, map, mono);
+  ATTWARP_F_MARK(7)
 }
+#undef ATTWARP_F_MARK
 
 }  // namespace attwarp

@@ -110,6 +110,8 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.skew = tune(TUNE_REMAP_SKEW) >= 0 ? tune(TUNE_REMAP_SKEW) : 0;
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
+  p.trace = trace_buffer();
+  p.pair = tune(TUNE_REMAP_PAIR) >= 0 ? tune(TUNE_REMAP_PAIR) : ROWS_PAIR_DEFAULT;
   p.nt_loads = tune(TUNE_REMAP_NT) > 0 ? tune(TUNE_REMAP_NT) : 0;      // bit 0: nontemporal loads of block-private rows, bit 1: nontemporal stores
 #endif
   *handled = true;
@@ -162,6 +164,10 @@ int step_fused_impl(const SlotPtrs* sl, int nslots, int layout, int B, int C, in
   StepExtra ex;
   memset(&ex, 0, sizeof(ex));
   ex.nslots = nslots;
+  ex.prio = tune(TUNE_STEP_PRIO) >= 0 ? tune(TUNE_STEP_PRIO) : 0;
+#ifdef ATTWARP_TUNING
+  ex.trace = trace_buffer();
+#endif
   if (s0.steps_in) {      // M: per-step maps of a later batch -> its inverse maps
     ATTWARP_REQUIRE(inv_x && inv_y, "warp_step_fused: null map-construction pointer");
     for (int k = 0; k < nslots; ++k) {

@@ -36,23 +36,25 @@
 // MI355X, 1024x1024x3 float32 B=256: 3 % faster on leases in the fast state, 1-2 % slower in the slow state, -15 % on a
 // batch that fits the Infinity Cache; nontemporal loads for ALL rows (the halo then misses): never a gain.  The
 // product library always issues plain loads.
-#ifdef ATTWARP_TUNING
+// (the register sets are clang vectors, not HIP's float4 struct: struct copies are memcpy's, and the row loop's control flow
+// left an array of them in scratch memory)
 typedef float rows_v4f __attribute__((ext_vector_type(4)));
+#ifdef ATTWARP_TUNING
 #define ATTWARP_ROW_STORE(ptr_, v_)                                                                                 \
   do { if (p.nt_loads & 2) __builtin_nontemporal_store((v_), (ptr_)); else *(ptr_) = (v_); } while (0)
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
   if ((p.nt_loads & 1) && srow_ != row_lo && srow_ != row_hi) {                                                           \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                                 \
       const rows_v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k]));             \
-      X[k] = make_float4(t_.x, t_.y, t_.z, t_.w);                                                                   \
+      X[k] = t_;                                                                                                    \
     }                                                                                                               \
   } else {                                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]);           \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]);           \
   }
 #else
 #define ATTWARP_ROW_STORE(ptr_, v_) (*(ptr_) = (v_))
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
-  { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const float4*>(rp_ + goff[k]); }
+  { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]); }
 #endif
 
 namespace attwarp {
@@ -118,6 +120,7 @@ __device__ __forceinline__ int plane_of(int e, int len) {     // e / len for e <
   return (e >= len) + (e >= 2 * len) + (e >= 3 * len);
 }
 
+constexpr int ROWS_PAIR_DEFAULT = 0;
 struct RowsParams {
   const float* src;
   float* dst;
@@ -140,8 +143,10 @@ struct RowsParams {
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int skew;          // block order 0: XCD x starts x * skew blocks into its contiguous range
   int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads
+  unsigned long long* trace;   // block timeline (common.hpp: trace_buffer): phase cycles of this block go to words 7..10
+  int pair;          // two row streams per block where the kernel has that form (rows_pair_form)
 #else
-  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0;
+  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0, pair = ROWS_PAIR_DEFAULT;
 #endif
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
@@ -149,6 +154,8 @@ struct RowsParams {
 
 constexpr int RMAX = 64;
 constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
+// which instantiations carry the two-streams-per-block row loop (remap_rows_block): rows of <= 4 KB
+constexpr bool rows_pair_form(int KI, bool TILED, bool SINGLE) { return KI == 1 && !TILED && !SINGLE; }
 
 // Per output row the kernel issues, per thread: KI x (3 lerps x 4) vertical blend + KI ds_write_b128 (CV2: 2 KI
 // ds_write_b128, no blend), one barrier, KO x (2 unpack + 2 LDS reads + lerp / 4-term sum + 1 global_store_dword).
@@ -174,6 +181,7 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE>
 __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int block_index, float* smem) {
   constexpr bool CV = MODE == ATTWARP_CV2;
+  constexpr bool PAIR = rows_pair_form(KI, TILED, SINGLE);
   float* s_my = smem;                                   // RMAX floats
   constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
   constexpr int BUF = CV ? 2 * ROWF : ROWF;             // floats per LDS buffer (CV2: top row, then bottom row)
@@ -283,8 +291,18 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   }
   }
 
+#ifdef ATTWARP_TUNING
+#define ATTWARP_R_MARK(i_) if (p.trace && tid == 0) { __builtin_amdgcn_sched_barrier(0); \
+    p.trace[TRACE_WORDS * (size_t)blockIdx.x + 11 + (i_)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define ATTWARP_R_MARK(i_)
+#endif
+  ATTWARP_R_MARK(0)      // column taps done
   // Row blocks of this workgroup: rb0, rb0 + wpi, ...  (wpi == nblk: exactly one).  With more than one, the column-tap
   // prologue above is paid once for all of them while the workgroups of an image still sweep it as one compact window.
+#ifdef ATTWARP_TUNING
+  unsigned long long ph_stage = 0, ph_sync = 0, ph_gather = 0, ph_rows = 0;
+#endif
   for (int rb = rb0; rb < p.nblk; rb += p.wpi) {
   const int y0 = rb * p.R;
   const int y1 = min(y0 + p.R, p.Ho);
@@ -292,6 +310,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   if (rb != rb0) __syncthreads();   // the previous block's last gather is done with s_my and the row buffers
   if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
   __syncthreads();
+  if (rb == rb0) { ATTWARP_R_MARK(1) }     // row maps in LDS
 
   if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
     for (int q = 0; q < nrows; ++q) {
@@ -318,8 +337,19 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
     continue;
   }
 
-  float4 X0[KI], X1[KI];
+  rows_v4f X0[KI], X1[KI];
   int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
+  // tuning flavour: shader-clock cycles of a row's three phases, summed over the block's rows (tools/gantt.py)
+  //   [load wait + staging | look-ahead issue + barrier | gather + arithmetic + store issue]
+#ifdef ATTWARP_TUNING
+#define ATTWARP_PHASE_T(v_) __builtin_amdgcn_sched_barrier(0); const unsigned long long v_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#define ATTWARP_PHASE_END(a_, b_, c_)                                                               \
+    { __builtin_amdgcn_sched_barrier(0); const unsigned long long e_ = __builtin_amdgcn_s_memtime(); \
+      ph_stage += (b_) - (a_); ph_sync += (c_) - (b_); ph_gather += e_ - (c_); }
+#else
+#define ATTWARP_PHASE_T(v_)
+#define ATTWARP_PHASE_END(a_, b_, c_)
+#endif
 #ifdef ATTWARP_TUNING
   // the two rows this block shares with its neighbours (valid for the monotone maps of the path; for arbitrary maps
   // they are just two rows that stay cacheable): only the "remap_nt" measurement option looks at them
@@ -335,13 +365,13 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   // EXACT: the vertical lerp of (XA, XC) into the row buffer; CV2: XA, then XC one row further
 #define ATTWARP_BLEND(rowbuf, XA, XC, fy)                                                           \
   do {                                                                                              \
-    float4* rowv_ = reinterpret_cast<float4*>(rowbuf);                                              \
+    rows_v4f* rowv_ = reinterpret_cast<rows_v4f*>(rowbuf);                                              \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                \
       if (CV) {                                                                                     \
         rowv_[tid + NT * k] = XA[k];                                                                \
         rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                                     \
       } else {                                                                                      \
-        float4 v_;                                                                                  \
+        rows_v4f v_;                                                                                \
         v_.x = lerp_rn(XA[k].x, XC[k].x, fy);                                                       \
         v_.y = lerp_rn(XA[k].y, XC[k].y, fy);                                                       \
         v_.z = lerp_rn(XA[k].z, XC[k].z, fy);                                                       \
@@ -350,14 +380,35 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       }                                                                                             \
     }                                                                                               \
   } while (0)
-  // make rows (i0, i1) resident; a set is only overwritten if it holds neither of them
-#define ATTWARP_ENSURE(i0_, i1_)                                                                    \
+  // make rows (i0, i1) resident in the 2-entry cache (S0_, S1_) with tags (g0_, g1_); a set is only overwritten if it
+  // holds neither of them
+  // The two arms of a choice issue the same load into different registers.  Left alone, LLVM merges them into ONE load
+  // in front of the branch and 8 KI v_cndmask_b32 behind it, which need the data at once: `s_waitcnt vmcnt(0)` right
+  // after the load, i.e. no look-ahead at all (rounds 1-3 shipped that: found with the block timeline of tools/gantt.py,
+  // a row's wait for its source row was the whole load latency).  Different empty asm statements at both ends of each
+  // arm keep the arms apart (neither hoisted nor sunk), the load writes its register set directly and is only waited
+  // for where the set is staged.
+#define ATTWARP_ARM(tag_, S_, g_, i_)                                                                \
+  { asm volatile("; row -> " tag_ " {"); ATTWARP_LOAD_ROW(S_, i_); g_ = (i_); asm volatile("; } row -> " tag_); }
+#define ATTWARP_ENSURE_S(S0_, S1_, g0_, g1_, i0_, i1_)                                               \
   do {                                                                                              \
-    if (t0 != (i0_) && t1 != (i0_)) {                                                               \
-      if (t0 == (i1_)) { ATTWARP_LOAD_ROW(X1, i0_); t1 = (i0_); } else { ATTWARP_LOAD_ROW(X0, i0_); t0 = (i0_); } \
+    if (g0_ != (i0_) && g1_ != (i0_)) {                                                             \
+      if (g0_ == (i1_)) ATTWARP_ARM("set 1", S1_, g1_, i0_) else ATTWARP_ARM("set 0", S0_, g0_, i0_) \
     }                                                                                               \
-    if (t0 != (i1_) && t1 != (i1_)) {                                                               \
-      if (t0 == (i0_)) { ATTWARP_LOAD_ROW(X1, i1_); t1 = (i1_); } else { ATTWARP_LOAD_ROW(X0, i1_); t0 = (i1_); } \
+    if (g0_ != (i1_) && g1_ != (i1_)) {                                                             \
+      if (g0_ == (i0_)) ATTWARP_ARM("set 1'", S1_, g1_, i1_) else ATTWARP_ARM("set 0'", S0_, g0_, i1_) \
+    }                                                                                               \
+  } while (0)
+#define ATTWARP_ENSURE(i0_, i1_) ATTWARP_ENSURE_S(X0, X1, t0, t1, i0_, i1_)
+  // stage the (top, bottom) rows of an output row from the cache (S0_, S1_)
+#define ATTWARP_STAGE_S(S0_, S1_, g0_, ty_, rowbuf)                                                  \
+  do {                                                                                              \
+    const bool top0 = (g0_ == ty_.i0);                                                              \
+    const bool bot0 = (ty_.i1 == ty_.i0) ? top0 : (g0_ == ty_.i1);                                  \
+    if (top0) {                                                                                     \
+      if (bot0) ATTWARP_BLEND(rowbuf, S0_, S0_, ty_.f); else ATTWARP_BLEND(rowbuf, S0_, S1_, ty_.f); \
+    } else {                                                                                        \
+      if (bot0) ATTWARP_BLEND(rowbuf, S1_, S0_, ty_.f); else ATTWARP_BLEND(rowbuf, S1_, S1_, ty_.f); \
     }                                                                                               \
   } while (0)
   // byte offset of k-slice k inside an output row (block uniform: scalar registers)
@@ -366,27 +417,11 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
     const int pl = (NT * k) / p.orow_len;
     return ((unsigned)(pl * p.oplane_stride) + (unsigned)(NT * k - pl * p.orow_len)) * 4u;
   };
-  // one output row: stage, prefetch for the next row, gather, store
-#define ATTWARP_DO_ROW(q_, rowbuf)                                                                  \
+  // the horizontal gather of output row yi_ from the staged rows, and its stores
+#define ATTWARP_GATHER(yi_, ty, rowbuf)                                                             \
   do {                                                                                              \
-    const int yi_ = ybeg + (q_) * ystep;                                                            \
-    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
-    ATTWARP_ENSURE(ty.i0, ty.i1); /* no-op unless the look-ahead missed */                          \
-    const bool top0 = (t0 == ty.i0);                                                                \
-    const bool bot0 = (ty.i1 == ty.i0) ? top0 : (t0 == ty.i1);                                      \
-    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
-    if (top0) {                                                                                     \
-      if (bot0) ATTWARP_BLEND(rowbuf, X0, X0, ty.f); else ATTWARP_BLEND(rowbuf, X0, X1, ty.f);      \
-    } else {                                                                                        \
-      if (bot0) ATTWARP_BLEND(rowbuf, X1, X0, ty.f); else ATTWARP_BLEND(rowbuf, X1, X1, ty.f);      \
-    }                                                                                               \
-    if ((q_) + 1 < nrows) { /* look-ahead: fetch what the next row needs */                         \
-      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
-      ATTWARP_ENSURE(tn.i0, tn.i1);                                                                 \
-    }                                                                                               \
-    __syncthreads();                                                                                \
     const char* rowb = reinterpret_cast<const char*>(rowbuf);                                       \
-    char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + yi_) * p.orow_len);               \
+    char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + (yi_)) * p.orow_len);             \
     const float fy_ = ty.f, oy_ = fsub(1.0f, ty.f);                                                 \
     /* gather in parts (EXACT: 2, CV2: 3 -- four values per output live there): the LDS reads of  \
        a part in flight, then their arithmetic + stores */                                          \
@@ -424,27 +459,189 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                               \
   } while (0)
+  // one output row: stage, prefetch for the next row, gather, store
+#define ATTWARP_DO_ROW(q_, rowbuf)                                                                  \
+  do {                                                                                              \
+    const int yi_ = ybeg + (q_) * ystep;                                                            \
+    ATTWARP_PHASE_T(pt0_)                                                                           \
+    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
+    ATTWARP_ENSURE(ty.i0, ty.i1); /* no-op unless the look-ahead missed */                          \
+    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
+    ATTWARP_STAGE_S(X0, X1, t0, ty, rowbuf);                                                        \
+    ATTWARP_PHASE_T(pt1_)                                                                           \
+    if ((q_) + 1 < nrows) { /* look-ahead: fetch what the next row needs */                         \
+      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
+      ATTWARP_ENSURE(tn.i0, tn.i1);                                                                 \
+    }                                                                                               \
+    __syncthreads();                                                                                \
+    ATTWARP_PHASE_T(pt2_)                                                                           \
+    ATTWARP_GATHER(yi_, ty, rowbuf);                                                                \
+    ATTWARP_PHASE_END(pt0_, pt1_, pt2_)                                                             \
+  } while (0)
 
+  if constexpr (PAIR) {
+  if (p.pair) {
+    // TWO row streams per block, one iteration = one output row of each: stream A sweeps the upper half of the block's
+    // rows bottom-up, stream B the lower half top-down, each through its own 2-entry row cache, so two source rows per
+    // block are in flight during the gathers (rows of <= 4 KB: one row per block and 8 blocks per CU are too few bytes
+    // in flight -- the timeline of tools/gantt.py puts 55 % of a row's time into waiting for its source row).  Both
+    // streams start at the middle of the block (the rows they share are requested together) and end at its edges, where
+    // the neighbouring blocks' streams end at about the same time.  One [top | bottom] buffer per stream, two barriers per
+    // iteration: the barrier rate per output row of the double-buffered loop below, with the same LDS.
+    rows_v4f Y0[KI], Y1[KI];
+    int u0 = -1, u1 = -1;
+#pragma unroll
+    for (int k = 0; k < KI; ++k) X0[k] = X1[k] = Y0[k] = Y1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
+    float* bufA = rows0;
+    float* bufB = rows0 + BUF;
+    const int nA = (nrows + 1) >> 1;
+    {
+      const Taps ta = rtaps<MODE>(s_my[nA - 1], p.H);
+      ATTWARP_ENSURE_S(X0, X1, t0, t1, ta.i0, ta.i1);
+      if (nA < nrows) {
+        const Taps tb = rtaps<MODE>(s_my[nA], p.H);
+        ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tb.i0, tb.i1);
+      }
+    }
+    if (rb == rb0) { ATTWARP_R_MARK(2) }   // first rows requested
+    for (int j = 0; j < nA; ++j) {
+      const int qa = nA - 1 - j, qb = nA + j;
+      const bool has_b = qb < nrows;                          // block uniform
+      ATTWARP_PHASE_T(pt0_)
+      const Taps ta = rtaps<MODE>(s_my[qa], p.H);
+      const Taps tb = rtaps<MODE>(s_my[has_b ? qb : qa], p.H);
+      ATTWARP_ENSURE_S(X0, X1, t0, t1, ta.i0, ta.i1);        // no-ops unless the look-ahead missed
+      if (has_b) ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tb.i0, tb.i1);
+      if (j > 0) __syncthreads();                             // the previous iteration's gathers are done with the buffers
+      ATTWARP_STAGE_S(X0, X1, t0, ta, bufA);
+      if (has_b) ATTWARP_STAGE_S(Y0, Y1, u0, tb, bufB);
+      ATTWARP_PHASE_T(pt1_)
+      if (qa > 0) {
+        const Taps tn = rtaps<MODE>(s_my[qa - 1], p.H);
+        ATTWARP_ENSURE_S(X0, X1, t0, t1, tn.i0, tn.i1);
+      }
+      if (qb + 1 < nrows) {
+        const Taps tn = rtaps<MODE>(s_my[qb + 1], p.H);
+        ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tn.i0, tn.i1);
+      }
+      __syncthreads();
+      ATTWARP_PHASE_T(pt2_)
+      ATTWARP_GATHER(qa, ta, bufA);
+      if (has_b) ATTWARP_GATHER(qb, tb, bufB);
+      ATTWARP_PHASE_END(pt0_, pt1_, pt2_)
+    }
+#ifdef ATTWARP_TUNING
+    ph_rows += (unsigned long long)nrows;
+#endif
+    continue;
+  }
+  }
   // Odd row blocks sweep bottom-up: block i ends, and block i+1 starts, at their shared halo rows at
   // about the same time, so the second read of those rows is an L2 hit instead of HBM traffic.
   const bool up = p.alt_dir && (rb & 1);
   const int ybeg = up ? nrows - 1 : 0, ystep = up ? -1 : 1;
+#ifdef ATTWARP_TUNING
+  if (p.nt_loads & 8) {
+    // rounds 1-3: the register set a look-ahead load goes to is chosen at run time -- which the compiler turns into ONE
+    // load in front of the choice and v_cndmask_b32 selects behind it, waiting for the data at once (kept for A/B runs)
 #pragma unroll
-  for (int k = 0; k < KI; ++k) X0[k] = X1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < KI; ++k) X0[k] = X1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
+    {
+      const Taps tf = rtaps<MODE>(s_my[ybeg], p.H);
+      ATTWARP_ENSURE(tf.i0, tf.i1);
+    }
+    int q = 0;
+    for (; q + 1 < nrows; q += 2) {
+      ATTWARP_DO_ROW(q, rows0);
+      ATTWARP_DO_ROW(q + 1, rows1);
+    }
+    if (q < nrows) ATTWARP_DO_ROW(q, rows0);
+    ph_rows += (unsigned long long)nrows;
+    continue;
+  }
+#endif
+  // The row loop.  The source rows of an output row live in the two register sets; which set holds the TOP row is not a
+  // run-time tag but the place in the code: the loop body exists twice (ATTWARP_SLOT(X0, X1): top in X0; ATTWARP_SLOT(X1,
+  // X0): top in X1) and control moves from one copy to the other whenever the rows advance by one and the sets swap their
+  // roles.  Every look-ahead load therefore has a destination known at compile time, its data is only waited for where
+  // the NEXT row is staged, and it is in flight during this row's barrier, gather and stores.  (Rounds 1-3 chose the set
+  // through tags at run time; the compiler made that one load and 8 KI v_cndmask_b32 selects, which need the data at
+  // once: `s_waitcnt vmcnt(0)` right behind every look-ahead load -- found with the block timeline of tools/gantt.py.
+  // 1024x1024x3 B=256 cv2: 1.15 -> 1.04 ms, 336x336x3 B=256: 0.159 -> 0.137 ms.)
+  //   next row needs the same rows          nothing to load, same copy
+  //   ... the next row down (or up)         ONE load into the set that became dead, the sets swap roles: other copy
+  //   ... anything else (maps may be arbitrary: steps of >= 2 rows when minifying)   both rows loaded, same copy
   {
     const Taps tf = rtaps<MODE>(s_my[ybeg], p.H);
-    ATTWARP_ENSURE(tf.i0, tf.i1);
+    ATTWARP_LOAD_ROW(X0, tf.i0);
+    if (tf.i1 != tf.i0) { ATTWARP_LOAD_ROW(X1, tf.i1); } else {
+#pragma unroll
+      for (int k = 0; k < KI; ++k) X1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
+    }
   }
-  // rows alternate between the two LDS buffers (one barrier per row is enough: a thread can only be
-  // one row ahead of the slowest reader, and then it writes the OTHER buffer)
+  // (the first rows are needed at once; consuming them here, in front of the loop, leaves the loop's own waits counted:
+  // `s_waitcnt vmcnt(KO + ...)` behind the previous row's stores instead of a `vmcnt(0)` that would drain them too)
+#pragma unroll
+  for (int k = 0; k < KI; ++k) asm volatile("" : : "v"(X0[k]), "v"(X1[k]));
   int q = 0;
-  for (; q + 1 < nrows; q += 2) {
-    ATTWARP_DO_ROW(q, rows0);
-    ATTWARP_DO_ROW(q + 1, rows1);
+  bool more = true;
+#define ATTWARP_SLOT(T_, B_)                                                                        \
+  for (;;) {                                                                                        \
+    const int yi_ = ybeg + q * ystep;                                                               \
+    ATTWARP_PHASE_T(pt0_)                                                                           \
+    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
+    float* rowbuf = (SINGLE || !(q & 1)) ? rows0 : rows1;   /* rows alternate between the two LDS buffers: one barrier per row */ \
+    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
+    if (ty.i1 == ty.i0) ATTWARP_BLEND(rowbuf, T_, T_, ty.f); else ATTWARP_BLEND(rowbuf, T_, B_, ty.f); \
+    ATTWARP_PHASE_T(pt1_)                                                                           \
+    /* what the next row needs, as scalar decisions; then at most ONE conditional load per set (a set with loads in \
+       several arms comes out of the compiler as a load into temporaries and copies that wait for it) */ \
+    bool step = false;                                                                              \
+    int rowT = -1, rowB = -1;                               /* source row to load into T_ / B_ (-1: none) */ \
+    if (q + 1 < nrows) {                                                                            \
+      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
+      const bool same = tn.i0 == ty.i0 && tn.i1 == ty.i1;                                           \
+      const bool down = !same && tn.i0 == ty.i1 && ty.i1 != ty.i0;           /* one row down: B_ becomes the top */ \
+      const bool upw = !same && !down && tn.i1 == ty.i0 && ty.i1 != ty.i0 && tn.i0 != tn.i1;   /* one row up */ \
+      step = down || upw;                                                                           \
+      if (down) { rowT = tn.i1 != tn.i0 ? tn.i1 : -1; }                                             \
+      else if (upw) { rowB = tn.i0; }                                                               \
+      else if (!same) { rowT = tn.i0; rowB = tn.i1 != tn.i0 ? tn.i1 : -1; }                         \
+    }                                                                                               \
+    if (rowT >= 0) ATTWARP_LOAD_ROW(T_, rowT);                                                      \
+    if (rowB >= 0) ATTWARP_LOAD_ROW(B_, rowB);                                                      \
+    __syncthreads();                                                                                \
+    ATTWARP_PHASE_T(pt2_)                                                                           \
+    ATTWARP_GATHER(yi_, ty, rowbuf);                                                                \
+    ATTWARP_PHASE_END(pt0_, pt1_, pt2_)                                                             \
+    if (++q >= nrows) { more = false; break; }                                                      \
+    if (step) break;                                                                                \
   }
-  if (q < nrows) ATTWARP_DO_ROW(q, rows0);
+  while (more) {
+    ATTWARP_SLOT(X0, X1)
+    if (!more) break;
+    ATTWARP_SLOT(X1, X0)
+  }
+#undef ATTWARP_SLOT
+#ifdef ATTWARP_TUNING
+  ph_rows += (unsigned long long)nrows;
+#endif
   }   // row blocks of this workgroup
+#ifdef ATTWARP_TUNING
+  if (p.trace && tid == 0) {
+    unsigned long long* r = p.trace + TRACE_WORDS * (size_t)blockIdx.x;
+    r[6] = 2; r[7] = ph_stage; r[8] = ph_sync; r[9] = ph_gather; r[10] = ph_rows;
+  }
+#endif
+  ATTWARP_R_MARK(3)      // last stores issued
+#undef ATTWARP_R_MARK
+#undef ATTWARP_PHASE_T
+#undef ATTWARP_PHASE_END
 #undef ATTWARP_DO_ROW
+#undef ATTWARP_GATHER
+#undef ATTWARP_STAGE_S
+#undef ATTWARP_ENSURE_S
+#undef ATTWARP_ARM
 #undef ATTWARP_ENSURE
 #undef ATTWARP_BLEND
 #undef ATTWARP_LOAD_ROW
@@ -453,7 +650,13 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>
 __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef ATTWARP_TUNING
+  const TraceStart t0 = trace_now();
+#endif
   remap_rows_block<NT, KI, KO, HWC, AFF, TILED, MODE, SINGLE>(p, blockIdx.x, smem);
+#ifdef ATTWARP_TUNING
+  trace_block(p.trace, t0, 2);
+#endif
 }
 
 // ---- the fused step: ONE launch = the resample of batch k + the map construction of batch k+1 + the attention
@@ -480,7 +683,11 @@ struct StepExtra {
   AttnStepArgsAny attn;    // nA reduce blocks per slot (0: none); its dtype is also the dtype of maps.steps
   int nM8, nA, nA8, nR8;   // blocks / 8 of the ranges: ceil(nslots * 2B / 8), ceil(nslots * nA / 8), ceil(nR / 8) PER SLOT
   int nslots;              // 1 or 2
+  int prio;                // 1: the map blocks (one lane's dependent chain each) raise their wave priority
   StepSlot2 s1;            // slot 1 (slot 0 = the pointers of RowsParams / maps / attn)
+#ifdef ATTWARP_TUNING
+  unsigned long long* trace;   // block timeline (common.hpp: trace_buffer), null = off
+#endif
 };
 
 // Waves per SIMD the register allocation must leave room for: the appended map / reduce blocks must not cost the
@@ -491,47 +698,58 @@ constexpr int step_min_waves(int KI, int KO, bool AFF) {
   return (KI == 1 && KO == 4) ? 6 : (KI <= 2 && KO <= 8) ? 4 : (KI == 3 && KO == 12 && AFF) ? 4 : 1;
 }
 
+// one block of the step; returns the kind of work it did (0 maps, 1 reduce, 2 resample, -1 padding)
 template <int NT, int KI, int KO, bool HWC, bool AFF, int MODE, bool SINGLE>
-__global__ __launch_bounds__(NT, step_min_waves(KI, KO, AFF)) void warp_step_kernel(const RowsParams p, const StepExtra ex) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ float s_tmp[64], s_pm[64];
+__device__ __forceinline__ int warp_step_block(const RowsParams& p, const StepExtra& ex, float* smem, float* s_tmp, float* s_pm) {
   const int blk = blockIdx.x;
   if (blk < ex.nM8 * 8) {
-    if (blk < ex.nslots * 2 * ex.maps.B) {
-      const bool s1 = blk >= 2 * ex.maps.B;                     // block uniform
-      const int jj = blk - (s1 ? 2 * ex.maps.B : 0);
-      StepsMapsArgs m = ex.maps;
-      if (s1) { m.steps = ex.s1.steps; m.map_x = ex.s1.map_x; m.map_y = ex.s1.map_y; }
-      double* sd = reinterpret_cast<double*>(smem);
-      if (m.step_dtype == ATTWARP_F32) axis_maps_from_steps_block<8, float>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
-      else if (m.step_dtype == ATTWARP_F16) axis_maps_from_steps_block<8, __half>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
-      else axis_maps_from_steps_block<8, __hip_bfloat16>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
-    }
-    return;
+    if (blk >= ex.nslots * 2 * ex.maps.B) return -1;
+    const bool s1 = blk >= 2 * ex.maps.B;                     // block uniform
+    const int jj = blk - (s1 ? 2 * ex.maps.B : 0);
+    StepsMapsArgs m = ex.maps;
+    if (s1) { m.steps = ex.s1.steps; m.map_x = ex.s1.map_x; m.map_y = ex.s1.map_y; }
+    if (ex.prio) __builtin_amdgcn_s_setprio(3);
+    double* sd = reinterpret_cast<double*>(smem);
+    if (m.step_dtype == ATTWARP_F32) axis_maps_from_steps_block<8, float>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
+    else if (m.step_dtype == ATTWARP_F16) axis_maps_from_steps_block<8, __half>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
+    else axis_maps_from_steps_block<8, __hip_bfloat16>(m, jj >> 1, jj & 1, sd, s_tmp, s_pm);
+    return 0;
   }
   const int j = blk - ex.nM8 * 8;
   if (j < ex.nA8 * 8) {
-    if (j < ex.nslots * ex.nA) {
-      const bool s1 = j >= ex.nA;
-      const int jj = j - (s1 ? ex.nA : 0);
-      AttnStepArgsAny at = ex.attn;
-      if (s1) { at.attn = ex.s1.attn; at.starts = ex.s1.starts; at.out = ex.s1.out; }
-      if (at.dtype == ATTWARP_F32) attn_reduce_v4_block<float, 3, 2>(at.as<float>(), jj, smem);
-      else if (at.dtype == ATTWARP_F16) attn_reduce_v4_block<__half, 3, 2>(at.as<__half>(), jj, smem);
-      else attn_reduce_v4_block<__hip_bfloat16, 3, 2>(at.as<__hip_bfloat16>(), jj, smem);
-    }
-    return;
+    if (j >= ex.nslots * ex.nA) return -1;
+    const bool s1 = j >= ex.nA;
+    const int jj = j - (s1 ? ex.nA : 0);
+    AttnStepArgsAny at = ex.attn;
+    if (s1) { at.attn = ex.s1.attn; at.starts = ex.s1.starts; at.out = ex.s1.out; }
+    if (at.dtype == ATTWARP_F32) attn_reduce_v4_block<float, 3, 2>(at.as<float>(), jj, smem);
+    else if (at.dtype == ATTWARP_F16) attn_reduce_v4_block<__half, 3, 2>(at.as<__half>(), jj, smem);
+    else attn_reduce_v4_block<__hip_bfloat16, 3, 2>(at.as<__hip_bfloat16>(), jj, smem);
+    return 1;
   }
   // every slot's resample range is padded to a multiple of 8 blocks (and a multiple of 8 blocks precedes): block % 8 still
   // names the XCD
   int rb = j - ex.nA8 * 8;
   const bool s1 = rb >= ex.nR8 * 8;
   rb -= s1 ? ex.nR8 * 8 : 0;
-  if (rb < p.nblocks) {
-    RowsParams q = p;
-    if (s1) { q.src = ex.s1.src; q.dst = ex.s1.dst; q.mx = ex.s1.mx; q.my = ex.s1.my; }
-    remap_rows_block<NT, KI, KO, HWC, AFF, false, MODE, SINGLE>(q, rb, smem);
-  }
+  if (rb >= p.nblocks) return -1;
+  RowsParams q = p;
+  if (s1) { q.src = ex.s1.src; q.dst = ex.s1.dst; q.mx = ex.s1.mx; q.my = ex.s1.my; }
+  remap_rows_block<NT, KI, KO, HWC, AFF, false, MODE, SINGLE>(q, rb, smem);
+  return 2;
+}
+
+template <int NT, int KI, int KO, bool HWC, bool AFF, int MODE, bool SINGLE>
+__global__ __launch_bounds__(NT, step_min_waves(KI, KO, AFF)) void warp_step_kernel(const RowsParams p, const StepExtra ex) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float s_tmp[64], s_pm[64];
+#ifdef ATTWARP_TUNING
+  const TraceStart t0 = trace_now();
+  const int kind = warp_step_block<NT, KI, KO, HWC, AFF, MODE, SINGLE>(p, ex, smem, s_tmp, s_pm);
+  trace_block(ex.trace, t0, kind);
+#else
+  warp_step_block<NT, KI, KO, HWC, AFF, MODE, SINGLE>(p, ex, smem, s_tmp, s_pm);
+#endif
 }
 
 template <int MODE, bool SINGLE>
