@@ -100,6 +100,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.nblk = (Ho + R - 1) / R;
   if (const int v = tune(TUNE_REMAP_CPW); v >= 1) cpw = v;
   while (cpw > 1 && (long long)((p.nblk + cpw - 1) / cpw) * B * p.ntiles < 4096) cpw >>= 1;   // keep the chip filled
+  if (cpw * R > RMAX) cpw = RMAX / R;        // a workgroup's rows are one list in LDS (remap_rows_block)
   p.wpi = (p.nblk + cpw - 1) / cpw;
   const long long nb = (long long)p.wpi * B * p.ntiles;
   if (nb > 2147483647LL) return ATTWARP_OK;
@@ -111,7 +112,6 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
   p.trace = trace_buffer();
-  p.pair = tune(TUNE_REMAP_PAIR) >= 0 ? tune(TUNE_REMAP_PAIR) : ROWS_PAIR_DEFAULT;
   p.nt_loads = tune(TUNE_REMAP_NT) > 0 ? tune(TUNE_REMAP_NT) : 0;      // bit 0: nontemporal loads of block-private rows, bit 1: nontemporal stores
 #endif
   *handled = true;

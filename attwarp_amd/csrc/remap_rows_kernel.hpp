@@ -31,11 +31,10 @@
 #include "attn_f32v.hpp"
 #include <algorithm>
 
-// Source-row loads.  Tuning flavour only (test hook "remap_nt"): rows a block shares with a neighbour (its first and last
-// needed row: the neighbour's halo) are read with plain loads, rows only this block reads NONTEMPORAL -- measured on
-// MI355X, 1024x1024x3 float32 B=256: 3 % faster on leases in the fast state, 1-2 % slower in the slow state, -15 % on a
-// batch that fits the Infinity Cache; nontemporal loads for ALL rows (the halo then misses): never a gain.  The
-// product library always issues plain loads.
+// Source-row loads and output stores.  Tuning flavour only (test hook "remap_nt"): bit 0 = NONTEMPORAL loads of the source
+// rows, bit 1 = nontemporal stores.  Measured on MI355X, 1024x1024x3 float32 B=256 (rounds 2-3, docs/experiments.md): never
+// a gain worth a lease-dependent loss; -15 % on a batch that fits the Infinity Cache.  The product library always issues
+// plain loads and stores.
 // (the register sets are clang vectors, not HIP's float4 struct: struct copies are memcpy's, and the row loop's control flow
 // left an array of them in scratch memory)
 typedef float rows_v4f __attribute__((ext_vector_type(4)));
@@ -43,18 +42,15 @@ typedef float rows_v4f __attribute__((ext_vector_type(4)));
 #define ATTWARP_ROW_STORE(ptr_, v_)                                                                                 \
   do { if (p.nt_loads & 2) __builtin_nontemporal_store((v_), (ptr_)); else *(ptr_) = (v_); } while (0)
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
-  if ((p.nt_loads & 1) && srow_ != row_lo && srow_ != row_hi) {                                                           \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                                 \
-      const rows_v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k]));             \
-      X[k] = t_;                                                                                                    \
-    }                                                                                                               \
+  if (p.nt_loads & 1) {                                                                                             \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k])); \
   } else {                                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]);           \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]);         \
   }
 #else
 #define ATTWARP_ROW_STORE(ptr_, v_) (*(ptr_) = (v_))
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
-  { (void)srow_; _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]); }
+  { _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]); }
 #endif
 
 namespace attwarp {
@@ -120,7 +116,6 @@ __device__ __forceinline__ int plane_of(int e, int len) {     // e / len for e <
   return (e >= len) + (e >= 2 * len) + (e >= 3 * len);
 }
 
-constexpr int ROWS_PAIR_DEFAULT = 0;
 struct RowsParams {
   const float* src;
   float* dst;
@@ -142,11 +137,10 @@ struct RowsParams {
   int alt_dir;       // 1: odd row blocks sweep bottom-up so both neighbours meet at the shared halo rows
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int skew;          // block order 0: XCD x starts x * skew blocks into its contiguous range
-  int nt_loads;      // 1: rows that only THIS block reads are fetched with nontemporal loads
+  int nt_loads;      // bit 0: nontemporal loads of the source rows, bit 1: nontemporal stores
   unsigned long long* trace;   // block timeline (common.hpp: trace_buffer): phase cycles of this block go to words 7..10
-  int pair;          // two row streams per block where the kernel has that form (rows_pair_form)
 #else
-  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0, pair = ROWS_PAIR_DEFAULT;
+  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0;
 #endif
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
@@ -154,8 +148,6 @@ struct RowsParams {
 
 constexpr int RMAX = 64;
 constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
-// which instantiations carry the two-streams-per-block row loop (remap_rows_block): rows of <= 4 KB
-constexpr bool rows_pair_form(int KI, bool TILED, bool SINGLE) { return KI == 1 && !TILED && !SINGLE; }
 
 // Per output row the kernel issues, per thread: KI x (3 lerps x 4) vertical blend + KI ds_write_b128 (CV2: 2 KI
 // ds_write_b128, no blend), one barrier, KO x (2 unpack + 2 LDS reads + lerp / 4-term sum + 1 global_store_dword).
@@ -181,7 +173,6 @@ constexpr bool rows_pair_form(int KI, bool TILED, bool SINGLE) { return KI == 1 
 template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE>
 __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int block_index, float* smem) {
   constexpr bool CV = MODE == ATTWARP_CV2;
-  constexpr bool PAIR = rows_pair_form(KI, TILED, SINGLE);
   float* s_my = smem;                                   // RMAX floats
   constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
   constexpr int BUF = CV ? 2 * ROWF : ROWF;             // floats per LDS buffer (CV2: top row, then bottom row)
@@ -226,146 +217,100 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 
   const int bm = b / p.map_div;
 
-  // ---- column taps, once per block, kept in registers.  Lanes past the end of the row duplicate
-  //      the last element (same value to the same address): the row loop has no per-lane branches.
+  // ---- what lives in registers for the whole workgroup
   unsigned pk[KO];     // LDS BYTE offset of tap 0 | tap 1 << 16   (staged rows are <= 16 KB)
   float fxr[KO];
   unsigned ooff[AFF ? 1 : KO];   // BYTE offset of the element inside an output row (incl. plane)
   unsigned goff[KI];   // BYTE offset inside a source row (incl. plane) of the float4s this thread owns
   bool direct = false; // TILED: the tile's source span does not fit the LDS row -> global taps
   unsigned f0s[TILED ? KO : 1], f1s[TILED ? KO : 1];   // TILED: absolute float indices of the two taps
+  __shared__ int s_yy[RMAX];                            // output row of entry i of the workgroup's row list
+
+  // ---- column taps, once per workgroup.  Lanes past the end of the row duplicate the last element (same value to
+  //      the same address): the row loop has no per-lane branches.
+  //      (macro: for rows that fit the LDS row it runs AFTER the first source rows have been requested, below)
+#define ATTWARP_COLUMN_TAPS()                                                                         \
+  if (TILED) {                                                                                        \
+    __shared__ int s_lo[NT / WAVE], s_hi[NT / WAVE];                                                  \
+    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);                                   \
+    int lo = 0x7fffffff, hi = 0;                                                                      \
+    _Pragma("unroll") for (int k = 0; k < KO; ++k) {                                                  \
+      const int e = min(e0 + tid + NT * k, e1 - 1);                                                   \
+      const int x = (int)div_small((unsigned)e, p.CS);                                                \
+      const int c = e - x * p.CS;                                                                     \
+      const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);                               \
+      f0s[k] = tx.i0 * p.CS + c;                                                                      \
+      f1s[k] = tx.i1 * p.CS + c;                                                                      \
+      fxr[k] = tx.f;                                                                                  \
+      ooff[AFF ? 0 : k] = (unsigned)e * 4u;                                                           \
+      lo = min(lo, (int)min(f0s[k], f1s[k]));                                                         \
+      hi = max(hi, (int)max(f0s[k], f1s[k]));                                                         \
+    }                                                                                                 \
+    _Pragma("unroll") for (int o = WAVE / 2; o > 0; o >>= 1) {                                        \
+      lo = min(lo, __shfl_xor(lo, o, WAVE));                                                          \
+      hi = max(hi, __shfl_xor(hi, o, WAVE));                                                          \
+    }                                                                                                 \
+    if ((tid & (WAVE - 1)) == 0) { s_lo[tid / WAVE] = lo; s_hi[tid / WAVE] = hi; }                    \
+    __syncthreads();                                                                                  \
+    _Pragma("unroll") for (int w = 0; w < NT / WAVE; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); } \
+    const int abase = lo & ~3;                          /* 4-float aligned start of the staged span */ \
+    const int nf4 = (hi - abase + 4) >> 2;              /* float4s covering [abase, hi] */            \
+    direct = nf4 > KI * NT;                                                                           \
+    _Pragma("unroll") for (int k = 0; k < KO; ++k) pk[k] = ((f0s[k] - abase) * 4u) | (((f1s[k] - abase) * 4u) << 16); \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) goff[k] = (unsigned)(abase + 4 * min(tid + NT * k, nf4 - 1)) * 4u; \
+  } else {                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < KO; ++k) {                                                  \
+      const int e = min(tid + NT * k, p.OVL - 1);                                                     \
+      const int pl = HWC ? 0 : plane_of(e, p.orow_len);                                               \
+      const int r = e - pl * p.orow_len;                                                              \
+      const int x = (int)div_small((unsigned)r, p.CS);                                                \
+      const int c = r - x * p.CS;                                                                     \
+      const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);                               \
+      const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;                                          \
+      const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + c;                                          \
+      pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);                                                          \
+      fxr[k] = tx.f;                                                                                  \
+      if (!AFF) ooff[AFF ? 0 : k] = ((unsigned)(pl * p.oplane_stride) + (unsigned)r) * 4u;            \
+    }                                                                                                 \
+  }
   if (TILED) {
-    __shared__ int s_lo[NT / WAVE], s_hi[NT / WAVE];
-    const int e0 = tile * (KO * NT), e1 = min(e0 + KO * NT, p.OVL);
-    int lo = 0x7fffffff, hi = 0;
-#pragma unroll
-    for (int k = 0; k < KO; ++k) {
-      const int e = min(e0 + tid + NT * k, e1 - 1);
-      const int x = (int)div_small((unsigned)e, p.CS);
-      const int c = e - x * p.CS;
-      const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
-      f0s[k] = tx.i0 * p.CS + c;
-      f1s[k] = tx.i1 * p.CS + c;
-      fxr[k] = tx.f;
-      ooff[k] = (unsigned)e * 4u;
-      lo = min(lo, (int)min(f0s[k], f1s[k]));
-      hi = max(hi, (int)max(f0s[k], f1s[k]));
-    }
-#pragma unroll
-    for (int o = WAVE / 2; o > 0; o >>= 1) {
-      lo = min(lo, __shfl_xor(lo, o, WAVE));
-      hi = max(hi, __shfl_xor(hi, o, WAVE));
-    }
-    if ((tid & (WAVE - 1)) == 0) { s_lo[tid / WAVE] = lo; s_hi[tid / WAVE] = hi; }
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < NT / WAVE; ++w) { lo = min(lo, s_lo[w]); hi = max(hi, s_hi[w]); }
-    const int abase = lo & ~3;                          // 4-float aligned start of the staged span
-    const int nf4 = (hi - abase + 4) >> 2;              // float4s covering [abase, hi]
-    direct = nf4 > KI * NT;
-#pragma unroll
-    for (int k = 0; k < KO; ++k) pk[k] = ((f0s[k] - abase) * 4u) | (((f1s[k] - abase) * 4u) << 16);
-#pragma unroll
-    for (int k = 0; k < KI; ++k) goff[k] = (unsigned)(abase + 4 * min(tid + NT * k, nf4 - 1)) * 4u;
+    ATTWARP_COLUMN_TAPS()
   } else {
+    // ---- which float4 of a source row this thread owns (clamped: padding lanes re-read the last one)
 #pragma unroll
-  for (int k = 0; k < KO; ++k) {
-    const int e = min(tid + NT * k, p.OVL - 1);
-    const int pl = HWC ? 0 : plane_of(e, p.orow_len);
-    const int r = e - pl * p.orow_len;
-    const int x = (int)div_small((unsigned)r, p.CS);
-    const int c = r - x * p.CS;
-    const Taps tx = rtaps<MODE>(p.mx[(long long)bm * p.Wo + x], p.W);
-    const unsigned i0 = pl * p.row_len + tx.i0 * p.CS + c;
-    const unsigned i1 = pl * p.row_len + tx.i1 * p.CS + c;
-    pk[k] = (i0 * 4u) | ((i1 * 4u) << 16);
-    fxr[k] = tx.f;
-    if (!AFF) ooff[k] = ((unsigned)(pl * p.oplane_stride) + (unsigned)r) * 4u;
-  }
-  // ---- which float4 of a source row this thread owns (clamped: padding lanes re-read the last one)
-#pragma unroll
-  for (int k = 0; k < KI; ++k) {
-    const int f = min(tid + NT * k, p.VLV - 1) * 4;
-    const int pl = HWC ? 0 : plane_of(f, p.row_len);
-    goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
-  }
+    for (int k = 0; k < KI; ++k) {
+      const int f = min(tid + NT * k, p.VLV - 1) * 4;
+      const int pl = HWC ? 0 : plane_of(f, p.row_len);
+      goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
+    }
   }
 
 #ifdef ATTWARP_TUNING
 #define ATTWARP_R_MARK(i_) if (p.trace && tid == 0) { __builtin_amdgcn_sched_barrier(0); \
     p.trace[TRACE_WORDS * (size_t)blockIdx.x + 11 + (i_)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
-#else
-#define ATTWARP_R_MARK(i_)
-#endif
-  ATTWARP_R_MARK(0)      // column taps done
-  // Row blocks of this workgroup: rb0, rb0 + wpi, ...  (wpi == nblk: exactly one).  With more than one, the column-tap
-  // prologue above is paid once for all of them while the workgroups of an image still sweep it as one compact window.
-#ifdef ATTWARP_TUNING
-  unsigned long long ph_stage = 0, ph_sync = 0, ph_gather = 0, ph_rows = 0;
-#endif
-  for (int rb = rb0; rb < p.nblk; rb += p.wpi) {
-  const int y0 = rb * p.R;
-  const int y1 = min(y0 + p.R, p.Ho);
-  const int nrows = y1 - y0;
-  if (rb != rb0) __syncthreads();   // the previous block's last gather is done with s_my and the row buffers
-  if (tid < nrows) s_my[tid] = p.my[(long long)bm * p.Ho + y0 + tid];
-  __syncthreads();
-  if (rb == rb0) { ATTWARP_R_MARK(1) }     // row maps in LDS
-
-  if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
-    for (int q = 0; q < nrows; ++q) {
-      const Taps ty = rtaps<MODE>(s_my[q], p.H);
-      const float* ra = src_b + (long long)ty.i0 * p.row_len;
-      const float* rc = src_b + (long long)ty.i1 * p.row_len;
-      char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + q) * p.orow_len);
-      const float oy = fsub(1.0f, ty.f);
-#pragma unroll
-      for (int k = 0; k < KO; ++k) {
-        float o_;
-        if (CV) {
-          const float ox = fsub(1.0f, fxr[k]);
-          o_ = cv2_sum(ra[f0s[k]], ra[f1s[k]], rc[f0s[k]], rc[f1s[k]], fmul(oy, ox), fmul(oy, fxr[k]),
-                       fmul(ty.f, ox), fmul(ty.f, fxr[k]));
-        } else {
-          const float v0 = lerp_rn(ra[f0s[k]], rc[f0s[k]], ty.f);      // vertical first, as the staged path
-          const float v1 = lerp_rn(ra[f1s[k]], rc[f1s[k]], ty.f);
-          o_ = lerp_rn(v0, v1, fxr[k]);
-        }
-        *reinterpret_cast<float*>(orow + ooff[k]) = o_;
-      }
-    }
-    continue;
-  }
-
-  rows_v4f X0[KI], X1[KI];
-  int t0 = -1, t1 = -1;      // which source row each register set holds (block uniform)
-  // tuning flavour: shader-clock cycles of a row's three phases, summed over the block's rows (tools/gantt.py)
+  // shader-clock cycles of a row's three phases, summed over the workgroup's rows (tools/gantt.py)
   //   [load wait + staging | look-ahead issue + barrier | gather + arithmetic + store issue]
-#ifdef ATTWARP_TUNING
+  unsigned long long ph_stage = 0, ph_sync = 0, ph_gather = 0, ph_rows = 0;
 #define ATTWARP_PHASE_T(v_) __builtin_amdgcn_sched_barrier(0); const unsigned long long v_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #define ATTWARP_PHASE_END(a_, b_, c_)                                                               \
     { __builtin_amdgcn_sched_barrier(0); const unsigned long long e_ = __builtin_amdgcn_s_memtime(); \
       ph_stage += (b_) - (a_); ph_sync += (c_) - (b_); ph_gather += e_ - (c_); }
 #else
+#define ATTWARP_R_MARK(i_)
 #define ATTWARP_PHASE_T(v_)
 #define ATTWARP_PHASE_END(a_, b_, c_)
 #endif
-#ifdef ATTWARP_TUNING
-  // the two rows this block shares with its neighbours (valid for the monotone maps of the path; for arbitrary maps
-  // they are just two rows that stay cacheable): only the "remap_nt" measurement option looks at them
-  const int row_lo = rtaps<MODE>(s_my[0], p.H).i0, row_hi = rtaps<MODE>(s_my[nrows - 1], p.H).i1;
-#endif
+
   // (macros, not lambdas: the register sets must stay scalar-replaced, never addressed through a pointer)
 #define ATTWARP_LOAD_ROW(X, srow)                                                                   \
   do {                                                                                              \
-    const int srow_ = (srow);                                                                       \
-    const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)srow_ * p.row_len);          \
+    const char* rp_ = reinterpret_cast<const char*>(src_b + (long long)(srow) * p.row_len);         \
     ATTWARP_ROW_LOAD(X, rp_)                                                                        \
   } while (0)
   // EXACT: the vertical lerp of (XA, XC) into the row buffer; CV2: XA, then XC one row further
 #define ATTWARP_BLEND(rowbuf, XA, XC, fy)                                                           \
   do {                                                                                              \
-    rows_v4f* rowv_ = reinterpret_cast<rows_v4f*>(rowbuf);                                              \
+    rows_v4f* rowv_ = reinterpret_cast<rows_v4f*>(rowbuf);                                          \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                \
       if (CV) {                                                                                     \
         rowv_[tid + NT * k] = XA[k];                                                                \
@@ -380,48 +325,17 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       }                                                                                             \
     }                                                                                               \
   } while (0)
-  // make rows (i0, i1) resident in the 2-entry cache (S0_, S1_) with tags (g0_, g1_); a set is only overwritten if it
-  // holds neither of them
-  // The two arms of a choice issue the same load into different registers.  Left alone, LLVM merges them into ONE load
-  // in front of the branch and 8 KI v_cndmask_b32 behind it, which need the data at once: `s_waitcnt vmcnt(0)` right
-  // after the load, i.e. no look-ahead at all (rounds 1-3 shipped that: found with the block timeline of tools/gantt.py,
-  // a row's wait for its source row was the whole load latency).  Different empty asm statements at both ends of each
-  // arm keep the arms apart (neither hoisted nor sunk), the load writes its register set directly and is only waited
-  // for where the set is staged.
-#define ATTWARP_ARM(tag_, S_, g_, i_)                                                                \
-  { asm volatile("; row -> " tag_ " {"); ATTWARP_LOAD_ROW(S_, i_); g_ = (i_); asm volatile("; } row -> " tag_); }
-#define ATTWARP_ENSURE_S(S0_, S1_, g0_, g1_, i0_, i1_)                                               \
-  do {                                                                                              \
-    if (g0_ != (i0_) && g1_ != (i0_)) {                                                             \
-      if (g0_ == (i1_)) ATTWARP_ARM("set 1", S1_, g1_, i0_) else ATTWARP_ARM("set 0", S0_, g0_, i0_) \
-    }                                                                                               \
-    if (g0_ != (i1_) && g1_ != (i1_)) {                                                             \
-      if (g0_ == (i0_)) ATTWARP_ARM("set 1'", S1_, g1_, i1_) else ATTWARP_ARM("set 0'", S0_, g0_, i1_) \
-    }                                                                                               \
-  } while (0)
-#define ATTWARP_ENSURE(i0_, i1_) ATTWARP_ENSURE_S(X0, X1, t0, t1, i0_, i1_)
-  // stage the (top, bottom) rows of an output row from the cache (S0_, S1_)
-#define ATTWARP_STAGE_S(S0_, S1_, g0_, ty_, rowbuf)                                                  \
-  do {                                                                                              \
-    const bool top0 = (g0_ == ty_.i0);                                                              \
-    const bool bot0 = (ty_.i1 == ty_.i0) ? top0 : (g0_ == ty_.i1);                                  \
-    if (top0) {                                                                                     \
-      if (bot0) ATTWARP_BLEND(rowbuf, S0_, S0_, ty_.f); else ATTWARP_BLEND(rowbuf, S0_, S1_, ty_.f); \
-    } else {                                                                                        \
-      if (bot0) ATTWARP_BLEND(rowbuf, S1_, S0_, ty_.f); else ATTWARP_BLEND(rowbuf, S1_, S1_, ty_.f); \
-    }                                                                                               \
-  } while (0)
   // byte offset of k-slice k inside an output row (block uniform: scalar registers)
   auto kbase = [&](int k) -> unsigned {
     if (HWC) return (unsigned)(NT * 4 * k);
     const int pl = (NT * k) / p.orow_len;
     return ((unsigned)(pl * p.oplane_stride) + (unsigned)(NT * k - pl * p.orow_len)) * 4u;
   };
-  // the horizontal gather of output row yi_ from the staged rows, and its stores
-#define ATTWARP_GATHER(yi_, ty, rowbuf)                                                             \
+  // the horizontal gather of output row yabs_ from the staged rows, and its stores
+#define ATTWARP_GATHER(yabs_, ty, rowbuf)                                                           \
   do {                                                                                              \
     const char* rowb = reinterpret_cast<const char*>(rowbuf);                                       \
-    char* orow = reinterpret_cast<char*>(dst_b + (long long)(y0 + (yi_)) * p.orow_len);             \
+    char* orow = reinterpret_cast<char*>(dst_b + (long long)(yabs_) * p.orow_len);                  \
     const float fy_ = ty.f, oy_ = fsub(1.0f, ty.f);                                                 \
     /* gather in parts (EXACT: 2, CV2: 3 -- four values per output live there): the LDS reads of  \
        a part in flight, then their arithmetic + stores */                                          \
@@ -445,7 +359,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       _Pragma("unroll") for (int kk = 0; kk < KH; ++kk) {                                           \
         const int k = half * KH + kk;                                                               \
         if (k < KO) {                                                                               \
-          const unsigned off = AFF ? (unsigned)(tid * 4) + kbase(k) : ooff[k];                      \
+          const unsigned off = AFF ? (unsigned)(tid * 4) + kbase(k) : ooff[AFF ? 0 : k];            \
           float o_;                                                                                 \
           if (CV) {                                                                                 \
             const float fx_ = fxr[k], ox_ = fsub(1.0f, fx_);                                        \
@@ -459,174 +373,131 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }                                                                                               \
   } while (0)
-  // one output row: stage, prefetch for the next row, gather, store
-#define ATTWARP_DO_ROW(q_, rowbuf)                                                                  \
-  do {                                                                                              \
-    const int yi_ = ybeg + (q_) * ystep;                                                            \
-    ATTWARP_PHASE_T(pt0_)                                                                           \
-    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
-    ATTWARP_ENSURE(ty.i0, ty.i1); /* no-op unless the look-ahead missed */                          \
-    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
-    ATTWARP_STAGE_S(X0, X1, t0, ty, rowbuf);                                                        \
-    ATTWARP_PHASE_T(pt1_)                                                                           \
-    if ((q_) + 1 < nrows) { /* look-ahead: fetch what the next row needs */                         \
-      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
-      ATTWARP_ENSURE(tn.i0, tn.i1);                                                                 \
-    }                                                                                               \
-    __syncthreads();                                                                                \
-    ATTWARP_PHASE_T(pt2_)                                                                           \
-    ATTWARP_GATHER(yi_, ty, rowbuf);                                                                \
-    ATTWARP_PHASE_END(pt0_, pt1_, pt2_)                                                             \
-  } while (0)
 
-  if constexpr (PAIR) {
-  if (p.pair) {
-    // TWO row streams per block, one iteration = one output row of each: stream A sweeps the upper half of the block's
-    // rows bottom-up, stream B the lower half top-down, each through its own 2-entry row cache, so two source rows per
-    // block are in flight during the gathers (rows of <= 4 KB: one row per block and 8 blocks per CU are too few bytes
-    // in flight -- the timeline of tools/gantt.py puts 55 % of a row's time into waiting for its source row).  Both
-    // streams start at the middle of the block (the rows they share are requested together) and end at its edges, where
-    // the neighbouring blocks' streams end at about the same time.  One [top | bottom] buffer per stream, two barriers per
-    // iteration: the barrier rate per output row of the double-buffered loop below, with the same LDS.
-    rows_v4f Y0[KI], Y1[KI];
-    int u0 = -1, u1 = -1;
+  // ---- the workgroup's output rows.  It owns the row blocks rb0, rb0 + wpi, ... of its image (wpi == nblk: exactly
+  // one; the workgroups of an image still sweep it as one compact window).  Their rows form ONE list the row loop walks
+  // from end to end -- the jump from one row block to the next is just a step of more than one source row, requested
+  // during the previous row's gather like any other -- so the column taps, the loads of the row maps and the exposed
+  // wait for the first two source rows are paid once per workgroup, not once per row block.  Odd row blocks are listed
+  // bottom-up: block i ends, and block i+1 starts, at their shared halo rows at about the same time, so the second read
+  // of those rows is an L2 hit instead of HBM traffic.  (Column-tiled rows keep one list per row block: their taps
+  // differ per tile, not per row block, and a tile may take the direct path.)
+  const int nlist_blocks = TILED ? 1 : (p.nblk - rb0 + p.wpi - 1) / p.wpi;      // row blocks per list
+  int rbl = rb0;
+  do {
+    const int rb_last = rbl + (nlist_blocks - 1) * p.wpi;
+    const int ntot = (nlist_blocks - 1) * p.R + min(p.R, p.Ho - rb_last * p.R);   // only an image's last block is short
+    if (TILED && rbl != rb0) __syncthreads();   // the previous list's last gather is done with the list and the row buffers
+    for (int i = tid; i < ntot; i += NT) {
+      const int rbi = i / p.R, j = i - rbi * p.R, rb = rbl + rbi * p.wpi;
+      const int y0 = rb * p.R, nr = min(p.R, p.Ho - y0);
+      const int y = y0 + ((p.alt_dir && (rb & 1)) ? nr - 1 - j : j);
+      s_yy[i] = y;
+      s_my[i] = p.my[(long long)bm * p.Ho + y];
+    }
+    __syncthreads();
+    ATTWARP_R_MARK(0)      // row maps in LDS
+
+    if (TILED && direct) {     // block uniform: this tile's source span does not fit the staged row
+      for (int q = 0; q < ntot; ++q) {
+        const Taps ty = rtaps<MODE>(s_my[q], p.H);
+        const float* ra = src_b + (long long)ty.i0 * p.row_len;
+        const float* rc = src_b + (long long)ty.i1 * p.row_len;
+        char* orow = reinterpret_cast<char*>(dst_b + (long long)s_yy[q] * p.orow_len);
+        const float oy = fsub(1.0f, ty.f);
 #pragma unroll
-    for (int k = 0; k < KI; ++k) X0[k] = X1[k] = Y0[k] = Y1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
-    float* bufA = rows0;
-    float* bufB = rows0 + BUF;
-    const int nA = (nrows + 1) >> 1;
+        for (int k = 0; k < KO; ++k) {
+          float o_;
+          if (CV) {
+            const float ox = fsub(1.0f, fxr[k]);
+            o_ = cv2_sum(ra[f0s[TILED ? k : 0]], ra[f1s[TILED ? k : 0]], rc[f0s[TILED ? k : 0]], rc[f1s[TILED ? k : 0]],
+                         fmul(oy, ox), fmul(oy, fxr[k]), fmul(ty.f, ox), fmul(ty.f, fxr[k]));
+          } else {
+            const float v0 = lerp_rn(ra[f0s[TILED ? k : 0]], rc[f0s[TILED ? k : 0]], ty.f);      // vertical first, as the staged path
+            const float v1 = lerp_rn(ra[f1s[TILED ? k : 0]], rc[f1s[TILED ? k : 0]], ty.f);
+            o_ = lerp_rn(v0, v1, fxr[k]);
+          }
+          *reinterpret_cast<float*>(orow + ooff[AFF ? 0 : k]) = o_;
+        }
+      }
+      continue;
+    }
+
+    // ---- the row loop.  The source rows of an output row live in two register sets; which set holds the TOP row is
+    // not a run-time tag but the place in the code: the loop body exists twice (ATTWARP_SLOT(X0, X1): top in X0;
+    // ATTWARP_SLOT(X1, X0): top in X1) and control moves from one copy to the other whenever the rows advance by one and
+    // the sets swap their roles.  Every look-ahead load therefore has a destination known at compile time, its data is
+    // only waited for where the NEXT row is staged (a counted `s_waitcnt vmcnt` behind this row's stores), and it is in
+    // flight during this row's barrier, gather and stores.  Rounds 1-3 chose the set through tags at run time; the compiler
+    // made that ONE load in front of the choice and 8 KI v_cndmask_b32 selects behind it, which need the data at once --
+    // `s_waitcnt vmcnt(0)` right behind every look-ahead load, no look-ahead at all (found with the block timeline of
+    // tools/gantt.py: a row's wait for its source row was the whole load latency).
+    //   next row needs the same rows          nothing to load, same copy
+    //   ... the next row down (or up)         ONE load into the set that became dead, the sets swap roles: other copy
+    //   ... anything else (maps may be arbitrary; steps of >= 2 rows when minifying; the next row block of the list)
+    //                                         both rows loaded, same copy
+    rows_v4f X0[KI], X1[KI];
     {
-      const Taps ta = rtaps<MODE>(s_my[nA - 1], p.H);
-      ATTWARP_ENSURE_S(X0, X1, t0, t1, ta.i0, ta.i1);
-      if (nA < nrows) {
-        const Taps tb = rtaps<MODE>(s_my[nA], p.H);
-        ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tb.i0, tb.i1);
-      }
-    }
-    if (rb == rb0) { ATTWARP_R_MARK(2) }   // first rows requested
-    for (int j = 0; j < nA; ++j) {
-      const int qa = nA - 1 - j, qb = nA + j;
-      const bool has_b = qb < nrows;                          // block uniform
-      ATTWARP_PHASE_T(pt0_)
-      const Taps ta = rtaps<MODE>(s_my[qa], p.H);
-      const Taps tb = rtaps<MODE>(s_my[has_b ? qb : qa], p.H);
-      ATTWARP_ENSURE_S(X0, X1, t0, t1, ta.i0, ta.i1);        // no-ops unless the look-ahead missed
-      if (has_b) ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tb.i0, tb.i1);
-      if (j > 0) __syncthreads();                             // the previous iteration's gathers are done with the buffers
-      ATTWARP_STAGE_S(X0, X1, t0, ta, bufA);
-      if (has_b) ATTWARP_STAGE_S(Y0, Y1, u0, tb, bufB);
-      ATTWARP_PHASE_T(pt1_)
-      if (qa > 0) {
-        const Taps tn = rtaps<MODE>(s_my[qa - 1], p.H);
-        ATTWARP_ENSURE_S(X0, X1, t0, t1, tn.i0, tn.i1);
-      }
-      if (qb + 1 < nrows) {
-        const Taps tn = rtaps<MODE>(s_my[qb + 1], p.H);
-        ATTWARP_ENSURE_S(Y0, Y1, u0, u1, tn.i0, tn.i1);
-      }
-      __syncthreads();
-      ATTWARP_PHASE_T(pt2_)
-      ATTWARP_GATHER(qa, ta, bufA);
-      if (has_b) ATTWARP_GATHER(qb, tb, bufB);
-      ATTWARP_PHASE_END(pt0_, pt1_, pt2_)
-    }
-#ifdef ATTWARP_TUNING
-    ph_rows += (unsigned long long)nrows;
-#endif
-    continue;
-  }
-  }
-  // Odd row blocks sweep bottom-up: block i ends, and block i+1 starts, at their shared halo rows at
-  // about the same time, so the second read of those rows is an L2 hit instead of HBM traffic.
-  const bool up = p.alt_dir && (rb & 1);
-  const int ybeg = up ? nrows - 1 : 0, ystep = up ? -1 : 1;
-#ifdef ATTWARP_TUNING
-  if (p.nt_loads & 8) {
-    // rounds 1-3: the register set a look-ahead load goes to is chosen at run time -- which the compiler turns into ONE
-    // load in front of the choice and v_cndmask_b32 selects behind it, waiting for the data at once (kept for A/B runs)
+      const Taps tf = rtaps<MODE>(s_my[0], p.H);
+      ATTWARP_LOAD_ROW(X0, tf.i0);
+      if (tf.i1 != tf.i0) { ATTWARP_LOAD_ROW(X1, tf.i1); } else {
 #pragma unroll
-    for (int k = 0; k < KI; ++k) X0[k] = X1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
-    {
-      const Taps tf = rtaps<MODE>(s_my[ybeg], p.H);
-      ATTWARP_ENSURE(tf.i0, tf.i1);
+        for (int k = 0; k < KI; ++k) X1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
+      }
     }
+    ATTWARP_R_MARK(1)      // first rows requested
+    if (!TILED) {
+      ATTWARP_COLUMN_TAPS()  // (their map loads fly beside the first source rows)
+    }
+    ATTWARP_R_MARK(2)      // column taps done
+    // (the first rows are needed at once; consuming them here, in front of the loop, leaves the loop's own waits counted:
+    // `s_waitcnt vmcnt(KO + ...)` behind the previous row's stores instead of a `vmcnt(0)` that would drain them too)
+#pragma unroll
+    for (int k = 0; k < KI; ++k) asm volatile("" : : "v"(X0[k]), "v"(X1[k]));
     int q = 0;
-    for (; q + 1 < nrows; q += 2) {
-      ATTWARP_DO_ROW(q, rows0);
-      ATTWARP_DO_ROW(q + 1, rows1);
-    }
-    if (q < nrows) ATTWARP_DO_ROW(q, rows0);
-    ph_rows += (unsigned long long)nrows;
-    continue;
-  }
-#endif
-  // The row loop.  The source rows of an output row live in the two register sets; which set holds the TOP row is not a
-  // run-time tag but the place in the code: the loop body exists twice (ATTWARP_SLOT(X0, X1): top in X0; ATTWARP_SLOT(X1,
-  // X0): top in X1) and control moves from one copy to the other whenever the rows advance by one and the sets swap their
-  // roles.  Every look-ahead load therefore has a destination known at compile time, its data is only waited for where
-  // the NEXT row is staged, and it is in flight during this row's barrier, gather and stores.  (Rounds 1-3 chose the set
-  // through tags at run time; the compiler made that one load and 8 KI v_cndmask_b32 selects, which need the data at
-  // once: `s_waitcnt vmcnt(0)` right behind every look-ahead load -- found with the block timeline of tools/gantt.py.
-  // 1024x1024x3 B=256 cv2: 1.15 -> 1.04 ms, 336x336x3 B=256: 0.159 -> 0.137 ms.)
-  //   next row needs the same rows          nothing to load, same copy
-  //   ... the next row down (or up)         ONE load into the set that became dead, the sets swap roles: other copy
-  //   ... anything else (maps may be arbitrary: steps of >= 2 rows when minifying)   both rows loaded, same copy
-  {
-    const Taps tf = rtaps<MODE>(s_my[ybeg], p.H);
-    ATTWARP_LOAD_ROW(X0, tf.i0);
-    if (tf.i1 != tf.i0) { ATTWARP_LOAD_ROW(X1, tf.i1); } else {
-#pragma unroll
-      for (int k = 0; k < KI; ++k) X1[k] = rows_v4f{0.f, 0.f, 0.f, 0.f};
-    }
-  }
-  // (the first rows are needed at once; consuming them here, in front of the loop, leaves the loop's own waits counted:
-  // `s_waitcnt vmcnt(KO + ...)` behind the previous row's stores instead of a `vmcnt(0)` that would drain them too)
-#pragma unroll
-  for (int k = 0; k < KI; ++k) asm volatile("" : : "v"(X0[k]), "v"(X1[k]));
-  int q = 0;
-  bool more = true;
+    bool more = true;
 #define ATTWARP_SLOT(T_, B_)                                                                        \
-  for (;;) {                                                                                        \
-    const int yi_ = ybeg + q * ystep;                                                               \
-    ATTWARP_PHASE_T(pt0_)                                                                           \
-    const Taps ty = rtaps<MODE>(s_my[yi_], p.H);                                                    \
-    float* rowbuf = (SINGLE || !(q & 1)) ? rows0 : rows1;   /* rows alternate between the two LDS buffers: one barrier per row */ \
-    if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */            \
-    if (ty.i1 == ty.i0) ATTWARP_BLEND(rowbuf, T_, T_, ty.f); else ATTWARP_BLEND(rowbuf, T_, B_, ty.f); \
-    ATTWARP_PHASE_T(pt1_)                                                                           \
-    /* what the next row needs, as scalar decisions; then at most ONE conditional load per set (a set with loads in \
-       several arms comes out of the compiler as a load into temporaries and copies that wait for it) */ \
-    bool step = false;                                                                              \
-    int rowT = -1, rowB = -1;                               /* source row to load into T_ / B_ (-1: none) */ \
-    if (q + 1 < nrows) {                                                                            \
-      const Taps tn = rtaps<MODE>(s_my[yi_ + ystep], p.H);                                          \
-      const bool same = tn.i0 == ty.i0 && tn.i1 == ty.i1;                                           \
-      const bool down = !same && tn.i0 == ty.i1 && ty.i1 != ty.i0;           /* one row down: B_ becomes the top */ \
-      const bool upw = !same && !down && tn.i1 == ty.i0 && ty.i1 != ty.i0 && tn.i0 != tn.i1;   /* one row up */ \
-      step = down || upw;                                                                           \
-      if (down) { rowT = tn.i1 != tn.i0 ? tn.i1 : -1; }                                             \
-      else if (upw) { rowB = tn.i0; }                                                               \
-      else if (!same) { rowT = tn.i0; rowB = tn.i1 != tn.i0 ? tn.i1 : -1; }                         \
-    }                                                                                               \
-    if (rowT >= 0) ATTWARP_LOAD_ROW(T_, rowT);                                                      \
-    if (rowB >= 0) ATTWARP_LOAD_ROW(B_, rowB);                                                      \
-    __syncthreads();                                                                                \
-    ATTWARP_PHASE_T(pt2_)                                                                           \
-    ATTWARP_GATHER(yi_, ty, rowbuf);                                                                \
-    ATTWARP_PHASE_END(pt0_, pt1_, pt2_)                                                             \
-    if (++q >= nrows) { more = false; break; }                                                      \
-    if (step) break;                                                                                \
-  }
-  while (more) {
-    ATTWARP_SLOT(X0, X1)
-    if (!more) break;
-    ATTWARP_SLOT(X1, X0)
-  }
+    for (;;) {                                                                                      \
+      ATTWARP_PHASE_T(pt0_)                                                                         \
+      const Taps ty = rtaps<MODE>(s_my[q], p.H);                                                    \
+      const int yabs = s_yy[q];                                                                     \
+      float* rowbuf = (SINGLE || !(q & 1)) ? rows0 : rows1;   /* rows alternate between the two LDS buffers: one barrier per row */ \
+      if (SINGLE) __syncthreads(); /* the previous row's gather is done with the buffer */          \
+      if (ty.i1 == ty.i0) ATTWARP_BLEND(rowbuf, T_, T_, ty.f); else ATTWARP_BLEND(rowbuf, T_, B_, ty.f); \
+      ATTWARP_PHASE_T(pt1_)                                                                         \
+      /* what the next row needs, as scalar decisions; then at most ONE conditional load per set (a set with loads in \
+         several arms comes out of the compiler as a load into temporaries and copies that wait for it) */ \
+      bool step = false;                                                                            \
+      int rowT = -1, rowB = -1;                             /* source row to load into T_ / B_ (-1: none) */ \
+      if (q + 1 < ntot) {                                                                           \
+        const Taps tn = rtaps<MODE>(s_my[q + 1], p.H);                                              \
+        const bool same = tn.i0 == ty.i0 && tn.i1 == ty.i1;                                         \
+        const bool down = !same && tn.i0 == ty.i1 && ty.i1 != ty.i0;          /* one row down: B_ becomes the top */ \
+        const bool upw = !same && !down && tn.i1 == ty.i0 && ty.i1 != ty.i0 && tn.i0 != tn.i1;   /* one row up */ \
+        step = down || upw;                                                                         \
+        if (down) { rowT = tn.i1 != tn.i0 ? tn.i1 : -1; }                                           \
+        else if (upw) { rowB = tn.i0; }                                                             \
+        else if (!same) { rowT = tn.i0; rowB = tn.i1 != tn.i0 ? tn.i1 : -1; }                       \
+      }                                                                                             \
+      if (rowT >= 0) ATTWARP_LOAD_ROW(T_, rowT);                                                    \
+      if (rowB >= 0) ATTWARP_LOAD_ROW(B_, rowB);                                                    \
+      __syncthreads();                                                                              \
+      ATTWARP_PHASE_T(pt2_)                                                                         \
+      ATTWARP_GATHER(yabs, ty, rowbuf);                                                             \
+      ATTWARP_PHASE_END(pt0_, pt1_, pt2_)                                                           \
+      if (++q >= ntot) { more = false; break; }                                                     \
+      if (step) break;                                                                              \
+    }
+    while (more) {
+      ATTWARP_SLOT(X0, X1)
+      if (!more) break;
+      ATTWARP_SLOT(X1, X0)
+    }
 #undef ATTWARP_SLOT
 #ifdef ATTWARP_TUNING
-  ph_rows += (unsigned long long)nrows;
+    ph_rows += (unsigned long long)ntot;
 #endif
-  }   // row blocks of this workgroup
+  } while (TILED && (rbl += p.wpi) < p.nblk);   // row lists of this workgroup
 #ifdef ATTWARP_TUNING
   if (p.trace && tid == 0) {
     unsigned long long* r = p.trace + TRACE_WORDS * (size_t)blockIdx.x;
@@ -637,14 +508,10 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 #undef ATTWARP_R_MARK
 #undef ATTWARP_PHASE_T
 #undef ATTWARP_PHASE_END
-#undef ATTWARP_DO_ROW
 #undef ATTWARP_GATHER
-#undef ATTWARP_STAGE_S
-#undef ATTWARP_ENSURE_S
-#undef ATTWARP_ARM
-#undef ATTWARP_ENSURE
 #undef ATTWARP_BLEND
 #undef ATTWARP_LOAD_ROW
+#undef ATTWARP_COLUMN_TAPS
 }
 
 template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>

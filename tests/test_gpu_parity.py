@@ -1189,8 +1189,8 @@ def test_remap_rows_block_boundaries(dev, R, mode):
         got8 = N(cu.remap_separable(T(img8, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
     assert np.array_equal(got, ref)
     assert np.array_equal(got8, ref8)
-    # nontemporal loads of block-private rows (what large streaming batches select) change no bit
-    with _lib.debug_override(remap_rows=R, remap_nt=1):
+    # nontemporal loads and stores (measurement options of the tuning flavour) change no bit
+    with _lib.debug_override(remap_rows=R, remap_nt=3):
         got_nt = N(cu.remap_separable(T(img, dev), T(mx, dev), T(my, dev), mode=mode, channels_last=True))
         chw_nt = N(cu.remap_separable(T(img.transpose(0, 3, 1, 2), dev), T(mx, dev), T(my, dev), mode=mode))
     assert np.array_equal(got_nt, ref) and np.array_equal(chw_nt.transpose(0, 2, 3, 1), ref)

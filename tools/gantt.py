@@ -9,6 +9,8 @@ import os, sys, time, contextlib
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from attwarp_amd import pipeline, _lib
+if os.environ.get("AB_TUNING_LIB"):          # another build of the tuning flavour (same record layout)
+    _lib.TUNING_LIB_PATH = os.path.abspath(os.environ["AB_TUNING_LIB"])
 dev = torch.device("cuda:0")
 pos = [a for a in sys.argv[1:] if "=" not in a]
 kw = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
