@@ -77,7 +77,9 @@ for name in ("bench_336", "bench_336x256", "bench_main_batched", "bench_config5"
     if os.path.exists(os.path.join(SRC, f"{name}.json")):
         open(os.path.join(DST, f"{tag}_{name}.json"), "w").write([l for l in open(os.path.join(SRC, f"{name}.json")) if l.startswith("{")][-1])
 for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench", "chain_stream",
-             "pair_step", "chain_step_kernel_stats"):
+             "pair_step", "chain_step_kernel_stats", "remap_lines", "timeline_chain_32_336_500", "timeline_chain_64_336_500",
+             "timeline_chain_256_1024_500", "timeline_step_64_336", "timeline_step_256_336", "timeline_remap_256_1024",
+             "timeline_remap_256_336"):
     if os.path.exists(os.path.join(SRC, f"{name}.txt")):
         shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)

@@ -31,6 +31,10 @@ python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.
 python3 $ROOT/tools/remap_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_bench.txt
 python3 $ROOT/tools/chain_stream_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_stream.txt
 python3 $ROOT/tools/pair_step_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/pair_step.txt
+for c in "chain 32 336 500" "chain 64 336 500" "chain 256 1024 500" "step 64 336" "step 256 336" "remap 256 1024" "remap 256 336"; do
+  python3 $ROOT/tools/gantt.py $c bin=8 2>&1 | grep -v amdgpu.ids > "$OUT/timeline_$(echo $c | tr ' ' _).txt"
+done
+python3 $ROOT/tools/remap_lines.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_lines.txt
 python3 $ROOT/bench.py --workload main_batched > $OUT/bench_main_batched.json 2> $OUT/bench_main_batched.err
 python3 $ROOT/bench.py --workload config5 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
 python3 $ROOT/bench.py --gpus 1 --force-dist --no-cpu-baseline --legs none > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
