@@ -84,9 +84,12 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
     // instead of groups of 4 with 2 -- the halo rows that cross XCDs drop from 1/4 to 1/8 of the seams (fabric reads
     // 1.090 -> 1.051 x algorithmic, total traffic 1.045 -> 1.025 x), +0.7-1 % on both kinds of lease, peaked maps +3 %;
     // larger groups (12, 16, 24) and more rows per block (5, 6) lose; exact mode is fastest as it was (groups of 3; 8 loses 7 %)
+    // (round 4, with the row loop whose look-ahead overlaps and one row list per workgroup: which of 1 / 2 / 3 row blocks per
+    //  workgroup is fastest flips with the lease state -- uniform maps, two leases: 1.08 / 1.16 / 1.19 ms and 1.17 / 1.11 / 1.12;
+    //  two has the best worst case, docs/experiments.md)
     R = 3;
     group = mode == ATTWARP_CV2 ? 8 : 3;
-    cpw = mode == ATTWARP_CV2 ? 3 : 1;
+    cpw = mode == ATTWARP_CV2 ? 2 : 1;
   } else if (!tiled && row_bytes >= 5 * 1024 && mode == ATTWARP_CV2) {
     cpw = 4;
   } else if (!tiled && split) {

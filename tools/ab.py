@@ -1,5 +1,5 @@
 """Dev tool: same-box A/B of builds of libattwarp_hip.so (alternating subprocesses, one build per process).
-usage: python tools/ab.py <target> libA.so libB.so [...]     targets: attn | remap | step
+usage: python tools/ab.py <target> libA.so libB.so [...]     targets: attn | remap | headline | step
 (variants inside ONE build are compared with attwarp_debug_set through the tools that take key=value / tune= arguments)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,6 +40,12 @@ if "--child" in sys.argv:
         rb.bench(256, 336, "hwc", "peaked", "cv2", 50, tag=tag)
         rb.bench(256, 1024, "chw", "peaked", "cv2", tag=tag)
         rb.bench(256, 1024, "hwc", "uniform", "cv2", tag=tag)
+    elif target == "headline":
+        import remap_bench as rb
+        for rep in range(3):
+            rb.bench(256, 1024, "hwc", "uniform", "cv2", tag=tag)
+            rb.bench(256, 1024, "hwc", "uniform", "exact", tag=tag)
+            rb.bench(256, 1024, "hwc", "peaked", "cv2", tag=tag)
     elif target == "step":
         import bench
         from attwarp_amd import dist as D
