@@ -93,7 +93,10 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   } else if (!tiled && row_bytes >= 5 * 1024 && mode == ATTWARP_CV2) {
     cpw = 4;
   } else if (!tiled && split) {
-    group = 2;        // planes of a planar image as one-channel images (4 KB rows at 1024): 1.170 -> 1.150 ms on a slow lease
+    // planes of a planar image as one-channel images (4 KB rows at 1024).  Round 3: groups of 2 (1.170 -> 1.150 ms on a slow
+    // lease with the old row loop).  Round 4, the loop whose look-ahead overlaps: the contiguous order on five leases
+    // 1.075-1.161 ms against 1.18-1.21 for groups of 2 (R4 g8: 1.12-1.16): docs/experiments.md
+    group = 0;
   } else if (!tiled && row_bytes < 5 * 1024 && (long long)B * ((Ho + R - 1) / R) >= 8192) {
     group = 2;        // large batches of small images (336x336x3, B=256): 0.1434 -> 0.1414 ms alone, 0.215 -> 0.209 ms
   }                   // inside the fused step (tools/ab_fused336.py); B=64 is fastest with the contiguous order
