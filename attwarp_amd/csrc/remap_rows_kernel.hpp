@@ -154,11 +154,13 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // Everything that does not depend on the row (taps, store offsets) lives in registers, packed to keep the
 // allocation low enough for >= 3-4 resident workgroups per CU: bytes in flight per CU, not ALU, bound this kernel.
 //
-// Source rows live in TWO register sets X0/X1 used as a 2-entry cache with tags: an output row uses
-// (top, bottom) = whichever sets hold rows (i0, i1).  Right after a row's staging has consumed the
-// registers, the rows the NEXT output row needs are looked up and any missing one is loaded into the
-// set that became dead -- the load then flies during this row's barrier, LDS gather and stores.  The
-// cache logic is correct for arbitrary (also non-monotone) maps; monotone maps simply never miss.
+// Source rows live in TWO register sets X0/X1 used as a 2-entry row cache.  Right after a row's staging has
+// consumed the registers, the rows the NEXT output row needs are worked out (block-uniform scalar code) and
+// any missing one is loaded into the set that became dead -- the load then flies during this row's barrier, LDS
+// gather and stores.  Which set holds the top row is encoded in the position in the code (the row loop exists
+// twice, see the row loop below), not in run-time tags: a tag-selected destination compiles to a load plus
+// selects that wait for the data at once.  Correct for arbitrary (also non-monotone) maps: whatever the next row
+// needs and the sets do not hold is loaded (both rows, if need be).
 // AFF: output offsets are tid*4 + a block-uniform term per k (OVL == KO*256 exactly; for planar images also
 // Wo % 256 == 0 so that a k-slice never straddles two planes): no per-element offset table in VGPRs.
 // (forcing >= 4 waves per SIMD on the planar variants, which allocate 130-138 VGPRs, was measured: the
@@ -168,8 +170,8 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // reduction; it is staged relative to its 4-float-aligned start, so everything after the prologue is the same
 // code.  A tile whose span exceeds KI*NT*4 floats (a map that minifies more than ~1.3x inside the tile) falls back
 // to direct global taps for that tile only.
-// SINGLE (CV2, rows wider than 8 KB): one [top | bottom] buffer and two barriers per row instead of two
-// buffers and one barrier (half the LDS, more resident workgroups).
+// SINGLE (CV2, rows wider than 12 KB, and the one-launch step's 8-12 KB rows): one [top | bottom] buffer and two
+// barriers per row instead of two buffers and one barrier (half the LDS; two buffers of 16 KB rows would not fit 64 KB).
 template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE>
 __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int block_index, float* smem) {
   constexpr bool CV = MODE == ATTWARP_CV2;
