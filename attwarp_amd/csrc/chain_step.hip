@@ -37,12 +37,14 @@ struct ChainStepArgs {
   int prio;                                 // 1: the F and V blocks (one lane's dependent chain each) raise their wave priority
   int nF8, nV8;                             // octets (8 blocks) of the F and V ranges
   int nPfirst8;                             // octets of P laid out as one range right behind them (0: P is interleaved)
+  int nPmid8;                               // octets of P laid out as one range between the two interleaved sections
   int nP, nL, nR;                           // blocks of P, L, R
   // interleave: `periods` periods of CHAIN_Q octets, each holding q[t] octets of type t (0 = P, 1 = L, 2 = R) at the
   // positions type[] says (rank[] = how many octets of the same type precede inside the period); then the leftovers of
   // P, of L and of R one after the other
-  int periods, q[3], left8[3];
-  unsigned char type[CHAIN_Q], rank[CHAIN_Q];
+  // two such sections one after the other (the second starts where the first stopped in every kind); sec[1] may be empty
+  struct Section { int periods, q[3], base8[3]; unsigned char type[CHAIN_Q], rank[CHAIN_Q]; } sec[2];
+  int left8[3], leftbase8[3];
   // V: masks [B,g,g] -> rev_out
   const float* masks; int g, ks; float coe; float* rev_out;
   // L: la.mf (the rev of batch k+3) -> la.out (mota)
@@ -82,18 +84,24 @@ __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const Pa
   }
   oct -= a.nV8;
   int t, idx8;
-  const int inter = a.periods * CHAIN_Q;
+  const int interA = a.sec[0].periods * CHAIN_Q, interB = a.sec[1].periods * CHAIN_Q;
   if (oct < a.nPfirst8) {
     t = 0; idx8 = oct;
-  } else if ((oct -= a.nPfirst8) < inter) {
+  } else if ((oct -= a.nPfirst8) < interA) {
     const int per = oct / CHAIN_Q, pos = oct - per * CHAIN_Q;
-    t = a.type[pos];
-    idx8 = per * a.q[t] + a.rank[pos];
+    t = a.sec[0].type[pos];
+    idx8 = a.sec[0].base8[t] + per * a.sec[0].q[t] + a.sec[0].rank[pos];
+  } else if ((oct -= interA) < a.nPmid8) {
+    t = 0; idx8 = a.sec[1].base8[0] + oct;          // (sec[1].base8[0] = where section A stopped in P)
+  } else if ((oct -= a.nPmid8) < interB) {
+    const int per = oct / CHAIN_Q, pos = oct - per * CHAIN_Q;
+    t = a.sec[1].type[pos];
+    idx8 = a.sec[1].base8[t] + per * a.sec[1].q[t] + a.sec[1].rank[pos] + (t == 0 ? a.nPmid8 : 0);
   } else {
-    int r = oct - inter;
-    if (r < a.left8[0]) { t = 0; idx8 = a.periods * a.q[0] + r; }
-    else if ((r -= a.left8[0]) < a.left8[1]) { t = 1; idx8 = a.periods * a.q[1] + r; }
-    else { t = 2; idx8 = a.periods * a.q[2] + (r - a.left8[1]); }
+    int r = oct - interB;
+    if (r < a.left8[0]) { t = 0; idx8 = a.leftbase8[0] + r; }
+    else if ((r -= a.left8[0]) < a.left8[1]) { t = 1; idx8 = a.leftbase8[1] + r; }
+    else { t = 2; idx8 = a.leftbase8[2] + (r - a.left8[1]); }
   }
   const int j = idx8 * 8 + l8;
   if (t == 0) {
@@ -128,67 +136,86 @@ __global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const C
 }
 
 // proportional interleave of three block kinds inside a period of CHAIN_Q octets (largest-remainder rounding, then an
-// even spread: position i goes to the kind that is furthest behind its share)
-// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved;
-// 3 / 4: see below (measured, not the default)
-static void build_interleave(ChainStepArgs& a, int order) {
-  const bool sequential = order == 1;
-  int n8[3] = {(a.nP + 7) / 8, (a.nL + 7) / 8, (a.nR + 7) / 8};
-  a.nPfirst8 = 0;
-  if (order == 2) { a.nPfirst8 = n8[0]; n8[0] = 0; }
-  // 3 = P and R interleaved, then all of L; 4 = P and L interleaved, then all of R (the excluded kind is laid out behind
-  // the interleaved part as one range)
-  const int excl = order == 3 ? 1 : order == 4 ? 2 : -1;
-  const int n8_excl = excl >= 0 ? n8[excl] : 0;
-  if (excl >= 0) n8[excl] = 0;
+// even spread: position i goes to the kind that is furthest behind its share); fills one section with as many whole
+// periods as n8[] allows and returns what it consumed
+static void fill_section(ChainStepArgs::Section& S, const int n8[3], const int base8[3], int used8[3]) {
+  memset(&S, 0, sizeof(S));
+  for (int t = 0; t < 3; ++t) { S.base8[t] = base8[t]; used8[t] = 0; }
   const long long tot = (long long)n8[0] + n8[1] + n8[2];
-  int q[3] = {0, 0, 0};
-  a.periods = 0;
-  if (!sequential && tot > 0) {
-    int used = 0;
-    double frac[3];
-    for (int t = 0; t < 3; ++t) {
-      const double share = (double)CHAIN_Q * n8[t] / (double)tot;
-      q[t] = (int)share;
-      if (n8[t] > 0 && q[t] == 0) q[t] = 1;
-      frac[t] = share - (int)share;
-      used += q[t];
-    }
-    while (used < CHAIN_Q) {
-      int best = 0;
-      for (int t = 1; t < 3; ++t) if (frac[t] > frac[best]) best = t;
-      ++q[best]; frac[best] = -1.0; ++used;
-    }
-    while (used > CHAIN_Q) {
-      int big = 0;
-      for (int t = 1; t < 3; ++t) if (q[t] > q[big]) big = t;
-      --q[big]; --used;
-    }
-    int periods = 0x7fffffff;
-    for (int t = 0; t < 3; ++t) if (q[t] > 0) periods = std::min(periods, n8[t] / q[t]);
-    a.periods = periods == 0x7fffffff ? 0 : periods;
-    int placed[3] = {0, 0, 0};
-    for (int i = 0; i < CHAIN_Q; ++i) {
-      int best = -1;
-      double lag = -1e30;
-      for (int t = 0; t < 3; ++t) {
-        if (placed[t] >= q[t]) continue;
-        const double l = (double)(i + 1) * q[t] / CHAIN_Q - placed[t];
-        if (l > lag) { lag = l; best = t; }
-      }
-      a.type[i] = (unsigned char)best;
-      a.rank[i] = (unsigned char)placed[best];
-      ++placed[best];
-    }
-  } else {
-    memset(a.type, 0, sizeof(a.type));
-    memset(a.rank, 0, sizeof(a.rank));
-  }
+  if (tot <= 0) return;
+  int q[3] = {0, 0, 0}, used = 0;
+  double frac[3];
   for (int t = 0; t < 3; ++t) {
-    a.q[t] = q[t];
-    a.left8[t] = n8[t] - a.periods * q[t];
+    const double share = (double)CHAIN_Q * n8[t] / (double)tot;
+    q[t] = (int)share;
+    if (n8[t] > 0 && q[t] == 0) q[t] = 1;
+    frac[t] = share - (int)share;
+    used += q[t];
   }
-  if (excl >= 0) a.left8[excl] = n8_excl;
+  while (used < CHAIN_Q) {
+    int best = 0;
+    for (int t = 1; t < 3; ++t) if (frac[t] > frac[best]) best = t;
+    ++q[best]; frac[best] = -1.0; ++used;
+  }
+  while (used > CHAIN_Q) {
+    int big = 0;
+    for (int t = 1; t < 3; ++t) if (q[t] > q[big]) big = t;
+    --q[big]; --used;
+  }
+  int periods = 0x7fffffff;
+  for (int t = 0; t < 3; ++t) if (q[t] > 0) periods = std::min(periods, n8[t] / q[t]);
+  S.periods = periods == 0x7fffffff ? 0 : periods;
+  int placed[3] = {0, 0, 0};
+  for (int i = 0; i < CHAIN_Q; ++i) {
+    int best = -1;
+    double lag = -1e30;
+    for (int t = 0; t < 3; ++t) {
+      if (placed[t] >= q[t]) continue;
+      const double l = (double)(i + 1) * q[t] / CHAIN_Q - placed[t];
+      if (l > lag) { lag = l; best = t; }
+    }
+    S.type[i] = (unsigned char)best;
+    S.rank[i] = (unsigned char)placed[best];
+    ++placed[best];
+  }
+  for (int t = 0; t < 3; ++t) { S.q[t] = q[t]; used8[t] = S.periods * q[t]; }
+}
+// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved;
+// 3 = P and R interleaved, then all of L; 4 = P and L interleaved, then all of R (measured, not the default);
+// 10..99 = P spread over the first `order` per cent of L and R (interleaved with them), then the rest of L and R
+// interleaved: the long marginals blocks all start early enough not to be the launch's tail, and the resample's memory
+// traffic runs beside their arithmetic from the start
+static void build_interleave(ChainStepArgs& a, int order) {
+  int n8[3] = {(a.nP + 7) / 8, (a.nL + 7) / 8, (a.nR + 7) / 8};
+  const int zero3[3] = {0, 0, 0};
+  int usedA[3] = {0, 0, 0}, usedB[3] = {0, 0, 0};
+  a.nPfirst8 = a.nPmid8 = 0;
+  memset(a.sec, 0, sizeof(a.sec));
+  int baseB[3] = {0, 0, 0};
+  if (order >= 10 && order <= 99) {
+    const int nA[3] = {n8[0], (int)((long long)n8[1] * order / 100), (int)((long long)n8[2] * order / 100)};
+    fill_section(a.sec[0], nA, zero3, usedA);
+    a.nPmid8 = n8[0] - usedA[0];                               // what the whole periods left of P: one range behind section A
+    for (int t = 0; t < 3; ++t) baseB[t] = usedA[t];
+    const int nB[3] = {0, n8[1] - usedA[1], n8[2] - usedA[2]};
+    fill_section(a.sec[1], nB, baseB, usedB);
+    for (int t = 0; t < 3; ++t) { a.leftbase8[t] = usedA[t] + usedB[t] + (t == 0 ? a.nPmid8 : 0); a.left8[t] = n8[t] - a.leftbase8[t]; }
+    return;
+  }
+  if (order == 1) {                                            // three ranges
+    for (int t = 0; t < 3; ++t) { a.leftbase8[t] = 0; a.left8[t] = n8[t]; }
+    return;
+  }
+  int nA[3] = {n8[0], n8[1], n8[2]};
+  int base[3] = {0, 0, 0};
+  if (order == 2) { a.nPfirst8 = n8[0]; nA[0] = 0; base[0] = n8[0]; }
+  const int excl = order == 3 ? 1 : order == 4 ? 2 : -1;      // that kind follows the interleaved part as one range
+  if (excl >= 0) nA[excl] = 0;
+  fill_section(a.sec[0], nA, base, usedA);
+  for (int t = 0; t < 3; ++t) {
+    a.leftbase8[t] = base[t] + usedA[t];
+    a.left8[t] = (t == 0 && order == 2) ? 0 : n8[t] - usedA[t];
+  }
 }
 
 template <int KI, int KD>
@@ -280,7 +307,8 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   a.trace = trace_buffer();
   a.fa.trace = a.trace;
 #endif
-  const long long octs = (long long)a.nF8 + a.nV8 + a.nPfirst8 + (long long)a.periods * CHAIN_Q + a.left8[0] + a.left8[1] + a.left8[2];
+  const long long octs = (long long)a.nF8 + a.nV8 + a.nPfirst8 + (long long)a.sec[0].periods * CHAIN_Q + a.nPmid8 +
+                         (long long)a.sec[1].periods * CHAIN_Q + a.left8[0] + a.left8[1] + a.left8[2];
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");
   size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
                         std::max(maps_finalize_lds_bytes(H, W, Pw, Ph), std::max(lanczos_strip_lds_bytes(g, g), mask_postproc_lds_bytes())));

@@ -176,7 +176,7 @@ enum TuneKey {
   TUNE_REMAP_SKEW,          // XCD x starts x * skew blocks into its contiguous range of row blocks
   TUNE_ATTN_HU,             // heads in flight per wave of the four-tokens-per-lane attention reduce (1, 2, 4, 8)
   TUNE_U8_AHEAD,            // integer uint8 resample: output rows whose source rows are requested ahead (1, 2, 4)
-  TUNE_CHAIN_SEQ,           // block order of the one-launch mask-chain step: 0 interleaved, 1 P / L / R ranges, 2 P first then L / R interleaved, 3 P + R then L, 4 P + L then R
+  TUNE_CHAIN_SEQ,           // block order of the one-launch mask-chain step: 0 interleaved, 1 P / L / R ranges, 2 P first then L / R interleaved, 3 P + R then L, 4 P + L then R, 10..99 P spread over that per cent of L / R
   TUNE_CHAIN_WAVES,         // 6 / 8: waves per SIMD its register allocation leaves room for
   TUNE_REMAP_CV2_DOUBLE,    // cv2 rows of 8-12 KB: 0 = one [top | bottom] LDS buffer and two barriers per row instead of two buffers and one (48 KB)
   TUNE_STEP_PRIO,           // one-launch steps: 1 = the latency-chain blocks (maps / finalize / revise) run at raised wave priority
