@@ -793,6 +793,38 @@ def test_maps_non_monotone_cdf_replays_numpy_search(dev):
     assert np.array_equal(N(mx), ref_x, equal_nan=True) and np.array_equal(N(my), ref_y, equal_nan=True)
 
 
+def test_cdf_tail_dip_takes_the_tie_break_ramp(dev):
+    """cdf_from_density overwrites the last element with 1.0 after a float32 cumsum that can reach 1 + 2^-23
+    (MN/checkpoint_utils.py:39-40): a -1 ulp step at the tail, which sends warp_from_cdf_torch into its tie-break ramp
+    (:181-184).  The pinned hypothesis example of tests/test_oracle_properties.py through attwarp_cdf_from_density ->
+    attwarp_axis_map_from_cdf, and 24-bin PDFs whose up-sampled density has the same dip through the fused
+    attwarp_axis_maps_from_pdf: bit-exact against the oracle."""
+    from attwarp_amd import checkpoint_utils as cu, pipeline
+    from test_oracle_properties import tail_dip_cdf
+    p, F = tail_dip_cdf()
+    assert F[2, -2] > 1.0
+    Fg = cu.cdf_from_density(T(p, dev))
+    assert np.array_equal(N(Fg), F)
+    for out in ((135, 135), (157, 157), (500, 336), (64, 700)):
+        rx, ry = O.maps_from_cdf(F, F, out)
+        mx, my = cu.axis_maps_from_cdf(Fg, Fg, out)
+        assert np.array_equal(N(mx), rx) and np.array_equal(N(my), ry), out
+    hit = 0
+    for seed, L in ((3, 500), (4, 500), (6, 500), (18, 1024), (29, 1024), (58, 1024)):
+        rng = np.random.default_rng(seed)
+        z = rng.standard_normal((8, 24)) * rng.uniform(0.5, 5)
+        px = (np.exp(z) / np.exp(z).sum(1, keepdims=True)).astype(np.float32)
+        Fx = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(px, L), 0))
+        hit += int((Fx[:, -2] > 1.0).sum())
+        py = px[::-1].copy()
+        Fy = O.cdf_from_density(np.maximum(O.upsample_pdf_right_inverse(py, L), 0))
+        for out in (None, (500, 500)):
+            rx, ry = O.maps_from_cdf(Fx, Fy, out)
+            mx, my = pipeline.axis_maps_from_pdf(T(px, dev), T(py, dev), (L, L), out)
+            assert np.array_equal(N(mx), rx) and np.array_equal(N(my), ry), (seed, L, out)
+    assert hit >= 6                                          # the cases really carry the dip
+
+
 def test_fused_axis_maps_from_pdf(dev):
     from attwarp_amd import pipeline
     rng = np.random.default_rng(32)

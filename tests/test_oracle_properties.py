@@ -2,11 +2,12 @@
 ones the HIP kernels rely on (monotone maps, CDF shape, right-inverse consistency).  CPU only."""
 import numpy as np
 import pytest
-from hypothesis import given, settings, strategies as st
+from hypothesis import example, given, settings, strategies as st
 
 from oracle import warp_oracle as O
 
-SET = dict(max_examples=40, deadline=None)
+# derandomize: the same examples on every run and every clone (no dependence on a local .hypothesis database)
+SET = dict(max_examples=40, deadline=None, derandomize=True, database=None)
 
 
 @settings(**SET)
@@ -25,18 +26,43 @@ def test_right_inverse_pools_back_to_input(L, seed, peak):
 
 @settings(**SET)
 @given(L=st.integers(2, 600), seed=st.integers(0, 2**31 - 1), zero_frac=st.floats(0.0, 0.9))
+@example(L=157, seed=117271, zero_frac=0.8984375)     # the cumsum reaches 1.0000001 in front of the forced last element
 def test_cdf_shape_and_map_monotone(L, seed, zero_frac):
+    """What ``cdf_from_density`` guarantees (MN/checkpoint_utils.py:36-40): a running sum of non-negative terms, so
+    non-decreasing -- EXCEPT at the last element, which is overwritten with 1.0 after a float32 cumsum that may have
+    reached 1 + 2^-23: a -1 ulp step at the tail.  That dip is what sends ``warp_from_cdf_torch`` into its tie-break ramp
+    (:181-184); the GPU parity case built from the pinned example is ``test_cdf_tail_dip_takes_the_tie_break_ramp``."""
     rng = np.random.default_rng(seed)
     p = rng.random((3, L)).astype(np.float32)
     p[rng.random((3, L)) < zero_frac] = 0.0
     F = O.cdf_from_density(p)
     assert F.dtype == np.float32 and (F[:, -1] == 1.0).all()
-    assert (np.diff(F, axis=1) >= 0).all() and (F >= 0).all() and (F <= 1.0 + 1e-6).all()
+    assert (np.diff(F[:, :-1], axis=1) >= 0).all() and (F >= 0).all()
+    assert (F[:, :-1] <= np.float32(1.0) + np.float32(2.0 ** -23)).all()
+    assert (np.diff(F, axis=1)[:, -1] >= -np.float32(2.0 ** -23)).all()
     n_out = int(rng.integers(1, 700))
     m = np.stack([O.axis_map_from_cdf(F[b], n_out) for b in range(3)])
     assert (np.diff(m, axis=1) >= 0).all()                      # non-decreasing: what remap_rows_kernel exploits
     assert (m >= 0).all() and (m <= L).all()
     assert np.all(m[:, 0] >= 0)
+
+
+def tail_dip_cdf():
+    """The CDFs of the pinned example above: row 2 holds 1.0000001 in front of the forced 1.0."""
+    L, seed, zero_frac = 157, 117271, 0.8984375
+    rng = np.random.default_rng(seed)
+    p = rng.random((3, L)).astype(np.float32)
+    p[rng.random((3, L)) < zero_frac] = 0.0
+    return p, O.cdf_from_density(p)
+
+
+def test_tail_dip_example_is_a_tail_dip():
+    p, F = tail_dip_cdf()
+    assert F[2, -2] > 1.0 and F[2, -1] == 1.0          # the input of the GPU case really has the dip
+    for n_out in (135, 157, 500):
+        xn = np.concatenate([[0.0], F[2].astype(np.float64)]) * n_out
+        xn[-1] = n_out
+        assert (np.diff(xn) <= 0).any()                # -> the ramp branch of checkpoint_utils.py:181-184
 
 
 @settings(**SET)
