@@ -79,12 +79,41 @@ SIGNATURES = {
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                          c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "attwarp_pil_coeffs_8bpc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
+    "attwarp_ragged_table_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "attwarp_ragged_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t]),
+    "attwarp_mask_chain_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "attwarp_axis_maps_from_steps_t": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_resize_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "attwarp_remap_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_void_p, c_void_p, c_int, c_void_p]),
 }
+
+PIL_LANCZOS, PIL_BICUBIC = 0, 1
+
+
+class RaggedImage(ctypes.Structure):
+    """attwarp_ragged_image (include/attwarp.h): one image of a ragged batch, device pointers in a host array."""
+    _fields_ = [("image", c_void_p), ("bounds_x", c_void_p), ("kk_x", c_void_p), ("bounds_y", c_void_p), ("kk_y", c_void_p),
+                ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("ksize_x", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class RaggedHeader(ctypes.Structure):
+    """attwarp_ragged_header: the first bytes of a table written by attwarp_ragged_plan."""
+    _fields_ = [("magic", ctypes.c_uint32), ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("g", ctypes.c_int32),
+                ("H_out", ctypes.c_int32), ("W_out", ctypes.c_int32),
+                ("nL", ctypes.c_int32), ("nP", ctypes.c_int32), ("nR", ctypes.c_int32), ("nplans", ctypes.c_int32),
+                ("rows_per_block", ctypes.c_int32), ("blocks_per_image", ctypes.c_int32), ("kd", ctypes.c_int32),
+                ("max_hw", ctypes.c_int32),
+                ("table_bytes", ctypes.c_uint64), ("mota_bytes", ctypes.c_uint64), ("sums_bytes", ctypes.c_uint64),
+                ("lds_bytes", ctypes.c_uint64), ("off_images", ctypes.c_uint64), ("off_plans", ctypes.c_uint64),
+                ("off_lmap", ctypes.c_uint64), ("off_pmap", ctypes.c_uint64)]
+
 
 _lib = None            # the library every call goes to: the product, or the tuning flavour inside debug_override()
 _product = None

@@ -46,60 +46,27 @@ def right_inverse_inv(n_out: int, n_in: int, eps: float, device: torch.device) -
     return t
 
 
-_PRECISION_BITS = 32 - 8 - 2
+_FILTER_IDS = {"lanczos": 0, "bicubic": 1}          # ATTWARP_PIL_LANCZOS / ATTWARP_PIL_BICUBIC
 
 
-def _sinc(x: float) -> float:
-    if x == 0.0:
-        return 1.0
-    x *= math.pi
-    return math.sin(x) / x
-
-
-def _lanczos3(x: float) -> float:
-    return _sinc(x) * _sinc(x / 3.0) if -3.0 <= x < 3.0 else 0.0
-
-
-def _bicubic(x: float) -> float:
-    a = -0.5
-    x = abs(x)
-    if x < 1.0:
-        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
-    if x < 2.0:
-        return (((x - 5) * x + 8) * x - 4) * a
-    return 0.0
-
-
-_FILTERS = {"lanczos": (_lanczos3, 3.0), "bicubic": (_bicubic, 2.0)}
-
-
-@functools.lru_cache(maxsize=64)
+@functools.lru_cache(maxsize=8192)
 def _lanczos_tables_host(n_in: int, n_out: int, filt: str = "lanczos"):
-    fn, support0 = _FILTERS[filt]
-    if n_in == n_out:       # Pillow skips the pass; an identity table makes clip8((v << 22 + 2^21) >> 22) == v
-        bounds = np.stack([np.arange(n_out, dtype=np.int32), np.ones(n_out, dtype=np.int32)], axis=1)
-        return bounds, np.full((n_out, 1), 1 << _PRECISION_BITS, dtype=np.int32), 1
-    scale = n_in / n_out
-    fscale = max(scale, 1.0)
-    support = support0 * fscale
-    ksize = int(math.ceil(support)) * 2 + 1
+    """Pillow's 8-bit coefficient tables (precompute_coeffs + normalize_coeffs_8bpc, libImaging/Resample.c) from the
+    library's HOST helper attwarp_pil_coeffs_8bpc (double arithmetic with libm's sin, as Pillow's C code; a batch of
+    differently sized images needs two tables per distinct size -- a Python loop cost 6-9 ms per table).
+    -> (bounds int32 [n_out,2], kk int32 [n_out,ksize], ksize)."""
+    from . import _lib
+    if n_in == n_out:
+        cols = 1
+    else:
+        support = (3.0 if filt == "lanczos" else 2.0) * max(n_in / n_out, 1.0)
+        cols = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((n_out, 2), dtype=np.int32)
-    kk = np.zeros((n_out, ksize), dtype=np.int32)
-    inv_fscale = 1.0 / fscale
-    for o in range(n_out):
-        center = (o + 0.5) * scale
-        lo = max(int(center - support + 0.5), 0)
-        hi = min(int(center + support + 0.5), n_in)
-        cnt = hi - lo
-        w = [fn((i + lo - center + 0.5) * inv_fscale) for i in range(cnt)]
-        tot = 0.0
-        for v in w:
-            tot += v
-        if tot != 0.0:
-            w = [v / tot for v in w]
-        for i, v in enumerate(w):
-            kk[o, i] = int((-0.5 if v < 0 else 0.5) + v * (1 << _PRECISION_BITS))
-        bounds[o] = (lo, cnt)
+    kk = np.zeros((n_out, cols), dtype=np.int32)
+    lib = _lib.load()
+    ksize = lib.attwarp_pil_coeffs_8bpc(n_in, n_out, _FILTER_IDS[filt], bounds.ctypes.data, kk.ctypes.data, cols)
+    if ksize < 0:
+        raise _lib.AttWarpError(f"attwarp_pil_coeffs_8bpc failed ({ksize}): {lib.attwarp_last_error().decode('utf-8', 'replace')}")
     return bounds, kk, ksize
 
 

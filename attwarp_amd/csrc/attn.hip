@@ -331,10 +331,11 @@ __global__ __launch_bounds__(NT) void lanczos_fused_kernel(const float* __restri
 
 // Up-sampling form of the fused kernel (<= 8 taps on both axes): body lanczos_strip_block (mask_blocks.hpp).
 // grid = (nstrips * nchunks, B).  LDS: src[h*w] | tile[h][256].   kk_y rows hold exactly 8 coefficients (zero padded).
-template <int KS>
+template <int KS, bool UA>
 __global__ __launch_bounds__(NT) void lanczos_strip_kernel(const LanczosStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lz[];
-  lanczos_strip_block<KS>(a, blockIdx.x, blockIdx.y, lz);
+  const int b = blockIdx.y;
+  lanczos_strip_block<KS, UA>(a, blockIdx.x, (size_t)b * a.h * a.w, a.out + (size_t)b * a.out_h * a.out_w, lz);
 }
 
 // copy / quantise pass used when an axis keeps its size (Pillow skips that pass)
@@ -525,8 +526,10 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     return check_launch("quantise_copy_kernel");
   }
   // up-sampling of a small source with <= 8 taps per axis (the 24 x 24 token grid): column-strip kernel
-  if (need_h && need_v && tune(TUNE_LANCZOS_VARIANT) <= 0 && (long long)h * w <= 4096 && out_w % 4 == 0 && ksize_x <= 8 &&
-      ksize_y == 8 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0 && (size_t)((h * w + 3) & ~3) + (size_t)h * NT <= 48 * 1024) {
+  if (need_h && need_v && tune(TUNE_LANCZOS_VARIANT) <= 0 && (long long)h * w <= 4096 && ksize_x <= 8 &&
+      ksize_y == 8 && (size_t)((h * w + 3) & ~3) + (size_t)h * NT <= 48 * 1024) {
+    // rows that do not start on dword boundaries (out_w % 4 != 0, e.g. the mask of a 683-pixel-wide image): the UA form
+    const bool ua = out_w % 4 != 0 || (reinterpret_cast<uintptr_t>(out) & 3u) != 0;
     const int nstrips = (out_w + NT - 1) / NT;
     // enough workgroups to fill the chip (~4096: measured 1024x1024 B=256, rows per chunk 512 / 256 / 128 / 64:
     // 108 / 105 / 111 / 127 us), at least 16 rows per wave
@@ -539,7 +542,8 @@ extern "C" int attwarp_mask_upsample_lanczos(const float* mask_f32, const uint8_
     nchunks = (out_h + rows_per_chunk - 1) / rows_per_chunk;
     const size_t lds = (size_t)((h * w + 3) & ~3) + (size_t)h * NT;
     LanczosStripArgs la{mask_f32, mask_u8, h, w, out_h, out_w, bounds_x, kk_x, ksize_x, bounds_y, kk_y, (int)nchunks, rows_per_chunk, out};
-    hipLaunchKernelGGL((lanczos_strip_kernel<8>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, la);
+    if (ua) hipLaunchKernelGGL((lanczos_strip_kernel<8, true>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, la);
+    else hipLaunchKernelGGL((lanczos_strip_kernel<8, false>), dim3((unsigned)(nstrips * nchunks), B), dim3(NT), lds, st, la);
     return check_launch("lanczos_strip_kernel");
   }
   // small source and both passes needed, any tap count: one fused launch (row-block form)

@@ -17,6 +17,7 @@
 // the XCD for the resample's XCD-aware order.  Every body is the stand-alone kernel's body (same arithmetic, bit for
 // bit); LDS is one pool sized for the largest of them.
 #include "common.hpp"
+#include "chain_order.hpp"
 #include "mask_blocks.hpp"
 #include "profiles_blocks.hpp"
 #include "remap_u8_block.hpp"
@@ -27,24 +28,13 @@
 namespace attwarp {
 
 constexpr int CHAIN_NT = 256;
-constexpr int CHAIN_Q = 32;                 // octets per period of the P / L / R interleave
-constexpr int CHAIN_ORDER_DEFAULT = 2;      // see build_interleave
 constexpr int CHAIN_PRIO_DEFAULT = 0;
 constexpr int CHAIN_WAVES_DEFAULT = 8;      // waves per SIMD the register allocation leaves room for
 
 struct ChainStepArgs {
   int B;
   int prio;                                 // 1: the F and V blocks (one lane's dependent chain each) raise their wave priority
-  int nF8, nV8;                             // octets (8 blocks) of the F and V ranges
-  int nPfirst8;                             // octets of P laid out as one range right behind them (0: P is interleaved)
-  int nPmid8;                               // octets of P laid out as one range between the two interleaved sections
-  int nP, nL, nR;                           // blocks of P, L, R
-  // interleave: `periods` periods of CHAIN_Q octets, each holding q[t] octets of type t (0 = P, 1 = L, 2 = R) at the
-  // positions type[] says (rank[] = how many octets of the same type precede inside the period); then the leftovers of
-  // P, of L and of R one after the other
-  // two such sections one after the other (the second starts where the first stopped in every kind); sec[1] may be empty
-  struct Section { int periods, q[3], base8[3]; unsigned char type[CHAIN_Q], rank[CHAIN_Q]; } sec[2];
-  int left8[3], leftbase8[3];
+  ChainOrder ord;                           // which block does what (chain_order.hpp)
   // V: masks [B,g,g] -> rev_out
   const float* masks; int g, ks; float coe; float* rev_out;
   // L: la.mf (the rev of batch k+3) -> la.out (mota)
@@ -60,66 +50,32 @@ struct ChainStepArgs {
 #endif
 };
 
-// one block of the step; returns the kind of work it did (0 F, 1 V, 2 P, 3 L, 4 R, -1 padding)
+// one block of the step; returns the kind of work it did (CHAIN_F .. CHAIN_R, CHAIN_PAD)
 template <int KI, int KD, int PD>
 __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const PairwisePlan& Pw, const PairwisePlan& Ph, uint8_t* pool) {
-  const int blk = blockIdx.x, l8 = blk & 7;
-  int oct = blk >> 3;
-  if (oct < a.nF8) {
-    if (blk >= 2 * a.B) return -1;
+  int j;
+  const int kind = chain_order_decode(a.ord, blockIdx.x, j);
+  if (kind == CHAIN_F) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    attention_maps_finalize_block(Pw, Ph, a.fa, blk >> 1, blk & 1, reinterpret_cast<double*>(pool));
-    return 0;
-  }
-  oct -= a.nF8;
-  if (oct < a.nV8) {
-    const int j = oct * 8 + l8;
-    if (j >= a.B) return -1;
+    attention_maps_finalize_block(Pw, Ph, maps_finalize_image(a.fa, j >> 1, Pw.nleaves), j & 1, reinterpret_cast<double*>(pool));
+  } else if (kind == CHAIN_V) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     float* x = reinterpret_cast<float*>(pool);
     double* red = reinterpret_cast<double*>(pool + 32 * 32 * sizeof(float));
     float* fred = reinterpret_cast<float*>(red + CHAIN_NT / WAVE);
     mask_postproc_block(a.masks, a.g, a.ks, a.coe, a.rev_out, j, x, red, fred);
-    return 1;
-  }
-  oct -= a.nV8;
-  int t, idx8;
-  const int interA = a.sec[0].periods * CHAIN_Q, interB = a.sec[1].periods * CHAIN_Q;
-  if (oct < a.nPfirst8) {
-    t = 0; idx8 = oct;
-  } else if ((oct -= a.nPfirst8) < interA) {
-    const int per = oct / CHAIN_Q, pos = oct - per * CHAIN_Q;
-    t = a.sec[0].type[pos];
-    idx8 = a.sec[0].base8[t] + per * a.sec[0].q[t] + a.sec[0].rank[pos];
-  } else if ((oct -= interA) < a.nPmid8) {
-    t = 0; idx8 = a.sec[1].base8[0] + oct;          // (sec[1].base8[0] = where section A stopped in P)
-  } else if ((oct -= a.nPmid8) < interB) {
-    const int per = oct / CHAIN_Q, pos = oct - per * CHAIN_Q;
-    t = a.sec[1].type[pos];
-    idx8 = a.sec[1].base8[t] + per * a.sec[1].q[t] + a.sec[1].rank[pos] + (t == 0 ? a.nPmid8 : 0);
-  } else {
-    int r = oct - interB;
-    if (r < a.left8[0]) { t = 0; idx8 = a.leftbase8[0] + r; }
-    else if ((r -= a.left8[0]) < a.left8[1]) { t = 1; idx8 = a.leftbase8[1] + r; }
-    else { t = 2; idx8 = a.leftbase8[2] + (r - a.left8[1]); }
-  }
-  const int j = idx8 * 8 + l8;
-  if (t == 0) {
-    if (j >= a.nP) return -1;
+  } else if (kind == CHAIN_P) {
     const int b = j / Pw.nleaves, leaf = j - b * Pw.nleaves;
-    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw, a.col_out,
-                                          a.ls_out, leaf, b, pool);
-    return 2;
-  }
-  if (t == 1) {
-    if (j >= a.nL) return -1;
+    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in + (size_t)b * a.fa.h * a.fa.w, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0},
+                                          Pw.off[leaf], Pw.len[leaf], Pw.nleaves, leaf, a.col_out + (size_t)b * a.fa.w,
+                                          a.ls_out + (size_t)b * a.fa.h * Pw.nleaves, pool);
+  } else if (kind == CHAIN_L) {
     const int b = j / a.l_bx, bx = j - b * a.l_bx;
-    lanczos_strip_block<8>(a.la, bx, b, pool);
-    return 3;
+    lanczos_strip_block<8>(a.la, bx, (size_t)b * a.la.h * a.la.w, a.la.out + (size_t)b * a.la.out_h * a.la.out_w, pool);
+  } else if (kind == CHAIN_R) {
+    u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
   }
-  if (j >= a.nR) return -1;
-  u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
-  return 4;
+  return kind;
 }
 
 template <int KI, int KD, int PD, int MINW>
@@ -133,89 +89,6 @@ __global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const C
 #else
   chain_step_block<KI, KD, PD>(a, Pw, Ph, pool);
 #endif
-}
-
-// proportional interleave of three block kinds inside a period of CHAIN_Q octets (largest-remainder rounding, then an
-// even spread: position i goes to the kind that is furthest behind its share); fills one section with as many whole
-// periods as n8[] allows and returns what it consumed
-static void fill_section(ChainStepArgs::Section& S, const int n8[3], const int base8[3], int used8[3]) {
-  memset(&S, 0, sizeof(S));
-  for (int t = 0; t < 3; ++t) { S.base8[t] = base8[t]; used8[t] = 0; }
-  const long long tot = (long long)n8[0] + n8[1] + n8[2];
-  if (tot <= 0) return;
-  int q[3] = {0, 0, 0}, used = 0;
-  double frac[3];
-  for (int t = 0; t < 3; ++t) {
-    const double share = (double)CHAIN_Q * n8[t] / (double)tot;
-    q[t] = (int)share;
-    if (n8[t] > 0 && q[t] == 0) q[t] = 1;
-    frac[t] = share - (int)share;
-    used += q[t];
-  }
-  while (used < CHAIN_Q) {
-    int best = 0;
-    for (int t = 1; t < 3; ++t) if (frac[t] > frac[best]) best = t;
-    ++q[best]; frac[best] = -1.0; ++used;
-  }
-  while (used > CHAIN_Q) {
-    int big = 0;
-    for (int t = 1; t < 3; ++t) if (q[t] > q[big]) big = t;
-    --q[big]; --used;
-  }
-  int periods = 0x7fffffff;
-  for (int t = 0; t < 3; ++t) if (q[t] > 0) periods = std::min(periods, n8[t] / q[t]);
-  S.periods = periods == 0x7fffffff ? 0 : periods;
-  int placed[3] = {0, 0, 0};
-  for (int i = 0; i < CHAIN_Q; ++i) {
-    int best = -1;
-    double lag = -1e30;
-    for (int t = 0; t < 3; ++t) {
-      if (placed[t] >= q[t]) continue;
-      const double l = (double)(i + 1) * q[t] / CHAIN_Q - placed[t];
-      if (l > lag) { lag = l; best = t; }
-    }
-    S.type[i] = (unsigned char)best;
-    S.rank[i] = (unsigned char)placed[best];
-    ++placed[best];
-  }
-  for (int t = 0; t < 3; ++t) { S.q[t] = q[t]; used8[t] = S.periods * q[t]; }
-}
-// order: 0 = P, L and R interleaved; 1 = P, L, R one after the other; 2 = all of P first, then L and R interleaved;
-// 3 = P and R interleaved, then all of L; 4 = P and L interleaved, then all of R (measured, not the default);
-// 10..99 = P spread over the first `order` per cent of L and R (interleaved with them), then the rest of L and R
-// interleaved: the long marginals blocks all start early enough not to be the launch's tail, and the resample's memory
-// traffic runs beside their arithmetic from the start
-static void build_interleave(ChainStepArgs& a, int order) {
-  int n8[3] = {(a.nP + 7) / 8, (a.nL + 7) / 8, (a.nR + 7) / 8};
-  const int zero3[3] = {0, 0, 0};
-  int usedA[3] = {0, 0, 0}, usedB[3] = {0, 0, 0};
-  a.nPfirst8 = a.nPmid8 = 0;
-  memset(a.sec, 0, sizeof(a.sec));
-  int baseB[3] = {0, 0, 0};
-  if (order >= 10 && order <= 99) {
-    const int nA[3] = {n8[0], (int)((long long)n8[1] * order / 100), (int)((long long)n8[2] * order / 100)};
-    fill_section(a.sec[0], nA, zero3, usedA);
-    a.nPmid8 = n8[0] - usedA[0];                               // what the whole periods left of P: one range behind section A
-    for (int t = 0; t < 3; ++t) baseB[t] = usedA[t];
-    const int nB[3] = {0, n8[1] - usedA[1], n8[2] - usedA[2]};
-    fill_section(a.sec[1], nB, baseB, usedB);
-    for (int t = 0; t < 3; ++t) { a.leftbase8[t] = usedA[t] + usedB[t] + (t == 0 ? a.nPmid8 : 0); a.left8[t] = n8[t] - a.leftbase8[t]; }
-    return;
-  }
-  if (order == 1) {                                            // three ranges
-    for (int t = 0; t < 3; ++t) { a.leftbase8[t] = 0; a.left8[t] = n8[t]; }
-    return;
-  }
-  int nA[3] = {n8[0], n8[1], n8[2]};
-  int base[3] = {0, 0, 0};
-  if (order == 2) { a.nPfirst8 = n8[0]; nA[0] = 0; base[0] = n8[0]; }
-  const int excl = order == 3 ? 1 : order == 4 ? 2 : -1;      // that kind follows the interleaved part as one range
-  if (excl >= 0) nA[excl] = 0;
-  fill_section(a.sec[0], nA, base, usedA);
-  for (int t = 0; t < 3; ++t) {
-    a.leftbase8[t] = base[t] + usedA[t];
-    a.left8[t] = (t == 0 && order == 2) ? 0 : n8[t] - usedA[t];
-  }
 }
 
 template <int KI, int KD>
@@ -275,7 +148,7 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   ChainStepArgs a;
   memset(&a, 0, sizeof(a));
   // R: the integer cv2 kernel's conditions
-  if (!u8i_params(a.rp, images, out, ATTWARP_HWC, B, C, H, W, H_out, W_out, map_x, map_y))
+  if (!u8i_params(a.rp, images, out, ATTWARP_HWC, B, C, H, W, H_out, W_out, map_x, map_y) || a.rp.unaligned)
     return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: this image shape / alignment does not run on the integer cv2 resample");
   a.B = B;
   a.prio = tune(TUNE_STEP_PRIO) >= 0 ? tune(TUNE_STEP_PRIO) : CHAIN_PRIO_DEFAULT;
@@ -297,18 +170,18 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   const double* col_in = static_cast<const double*>(sums_in);
   a.fa = MapsFinalizeArgs{col_in, col_in + (size_t)B * W, H, W, W_out, H_out, ATTWARP_T_IDENTITY, 1.0, 1.0, 0, map_x_next, map_y_next,
                           pw_depth(Pw)};
-  a.nF8 = (2 * B + 7) / 8;
-  a.nV8 = (B + 7) / 8;
-  a.nP = Pw.nleaves * B;
-  a.nL = a.l_bx * B;
-  a.nR = a.rp.nblocks;
-  build_interleave(a, tune(TUNE_CHAIN_SEQ) >= 0 ? tune(TUNE_CHAIN_SEQ) : CHAIN_ORDER_DEFAULT);
+  a.ord.nF = 2 * B; a.ord.nV = B;
+  a.ord.nF8 = (2 * B + 7) / 8;
+  a.ord.nV8 = (B + 7) / 8;
+  a.ord.nP = Pw.nleaves * B;
+  a.ord.nL = a.l_bx * B;
+  a.ord.nR = a.rp.nblocks;
+  build_interleave(a.ord, tune(TUNE_CHAIN_SEQ) >= 0 ? tune(TUNE_CHAIN_SEQ) : CHAIN_ORDER_DEFAULT);
 #ifdef ATTWARP_TUNING
   a.trace = trace_buffer();
   a.fa.trace = a.trace;
 #endif
-  const long long octs = (long long)a.nF8 + a.nV8 + a.nPfirst8 + (long long)a.sec[0].periods * CHAIN_Q + a.nPmid8 +
-                         (long long)a.sec[1].periods * CHAIN_Q + a.left8[0] + a.left8[1] + a.left8[2];
+  const long long octs = chain_order_octets(a.ord);
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");
   size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
                         std::max(maps_finalize_lds_bytes(H, W, Pw, Ph), std::max(lanczos_strip_lds_bytes(g, g), mask_postproc_lds_bytes())));

@@ -137,6 +137,10 @@ template <typename T> __device__ __forceinline__ T div_t(T a, T b) {   // a / b 
   return from_f32<T>(to_f32<T>(a) / to_f32<T>(b));
 }
 
+// A dword at ANY byte address: gfx950 runs with unaligned access mode on (one global / buffer dword instruction either
+// way); the type only stops the compiler from assuming 4-byte alignment of rows like 683 x 3 bytes.
+typedef uint32_t u32_una __attribute__((aligned(1)));
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // A launch gets at most 64 KB of dynamic LDS unless the kernel has been granted more (a CU of gfx950 has 160 KB).  The
@@ -159,7 +163,7 @@ inline int grant_dynamic_lds(K kernel, size_t bytes, const char* what) {
 // relaxed atomics that tune() reads, -1 = automatic.  In the product library tune() is the constant -1, the symbol
 // does not exist and every `tune(...)` branch folds away.  No environment variable is ever read by either.
 enum TuneKey {
-  TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only; 2: uint8 cv2 on the float-pipeline rows kernel (not the integer form)
+  TUNE_REMAP_VARIANT = 0,   // 1: generic gather kernel only; 2: uint8 cv2 on the float-pipeline rows kernel (not the integer form); 3: staged kernels only (a request that would take the gather kernel is refused)
   TUNE_REMAP_ROWS,          // output rows per workgroup (1..64)
   TUNE_REMAP_CHW_SPLIT,     // 0 / 1: planar images plane by plane
   TUNE_REMAP_TILED,         // 0: rows wider than the LDS row take the generic kernel

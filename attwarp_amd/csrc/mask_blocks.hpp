@@ -122,9 +122,12 @@ struct LanczosStripArgs {
   uint8_t* out;
 };
 inline size_t lanczos_strip_lds_bytes(int h, int w) { return (size_t)((h * w + 3) & ~3) + (size_t)h * MASK_NT; }
-// bx = strip * nchunks + chunk, b = image; lz: lanczos_strip_lds_bytes(h, w) bytes of LDS
-template <int KS>
-__device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, int bx, int b, uint8_t* lz) {
+// bx = strip * nchunks + chunk; mask_off: element offset of this image's h x w mask in a.mf / a.mu; out_img: this image's
+// [out_h,out_w] bytes (a.out is not read here); lz: lanczos_strip_lds_bytes(h, w) bytes of LDS.
+// UA ("unaligned"): out_w % 4 != 0 or an image that starts anywhere -- the dword stores stay dwords relative to the row
+// start (unaligned access mode), the row's last 1..3 bytes are stored byte by byte by the lane that owns them.
+template <int KS, bool UA = false>
+__device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, int bx, size_t mask_off, uint8_t* out_img, uint8_t* lz) {
   constexpr int NT = MASK_NT;
   const float* __restrict__ mf = a.mf; const uint8_t* __restrict__ mu = a.mu;
   const int h = a.h, w = a.w, out_h = a.out_h, out_w = a.out_w, ksize_x = a.ksize_x, nchunks = a.nchunks,
@@ -134,7 +137,6 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
   // pointers inside an argument struct they may alias `out`: vector loads, 19 more VGPRs)
   typedef const __attribute__((address_space(4))) int32_t* ctab;
   const ctab bounds_x = (ctab)a.bounds_x, kk_x = (ctab)a.kk_x, bounds_y = (ctab)a.bounds_y, kk_y = (ctab)a.kk_y;
-  uint8_t* __restrict__ out = a.out;
   constexpr int SW = NT;                               // strip width in pixels
   const int srcp = (h * w + 3) & ~3;
   uint8_t* src = lz;
@@ -144,7 +146,7 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
   const int yy0 = chunk * rows_per_chunk, yy1 = min(yy0 + rows_per_chunk, out_h);
   const int ys = bounds_y[2 * yy0];                                          // first / one-past-last source row
   const int ye = bounds_y[2 * (yy1 - 1)] + bounds_y[2 * (yy1 - 1) + 1];
-  const size_t ib = (size_t)b * h * w;
+  const size_t ib = mask_off;
   for (int i = ys * w + tid; i < ye * w; i += NT) src[i] = mf ? to_pil_u8(mf[ib + i]) : mu[ib + i];
   __syncthreads();
   {   // horizontal pass: one column per thread
@@ -185,7 +187,9 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
   int kc[8], ymin_c = bounds_y[2 * r_beg];
 #pragma unroll
   for (int y = 0; y < 8; ++y) kc[y] = kk_y[(size_t)r_beg * 8 + y];
-  uint32_t* orow = reinterpret_cast<uint32_t*>(out + ((size_t)b * out_h + r_beg) * out_w) + min(q, nq - 1);
+  // (UA: a narrow last strip may have no whole dword at all: nq == 0)
+  uint8_t* __restrict__ orow = out_img + (size_t)r_beg * out_w + 4 * (UA ? min(q, nq) : min(q, nq - 1));
+  const int tail_bytes = (UA && q == nq) ? (out_w & 3) : 0;
   int round_half = 1 << (PIL_PRECISION_BITS - 1);
   asm volatile("" : "+v"(round_half));                      // one register for the whole loop (not an inline constant: VOP3 takes none)
   for (int yy = r_beg; yy < r_end; ++yy) {
@@ -227,8 +231,12 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
     }
     // (written once by this kernel: nontemporal -- 24 -> 1024 B=256 109.9 -> 106.2 us, 24 -> 336 40.6 -> 36.6, and the
     // marginals kernel that reads the mask next is not slower for it)
-    if (q < nq) __builtin_nontemporal_store(pil_clip8x4(s0, s1, s2, s3), orow);
-    orow += nq;
+    if (q < nq) __builtin_nontemporal_store(pil_clip8x4(s0, s1, s2, s3), reinterpret_cast<u32_una*>(orow));
+    else if (UA && tail_bytes) {
+      const uint32_t v = pil_clip8x4(s0, s1, s2, s3);
+      for (int j = 0; j < tail_bytes; ++j) orow[j] = (uint8_t)(v >> (8 * j));
+    }
+    orow += out_w;
   }
 }
 

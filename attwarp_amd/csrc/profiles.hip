@@ -112,22 +112,27 @@ __global__ __launch_bounds__(NT) void profiles_kernel(const T* __restrict__ A, i
 }
 
 // ---- uint8 attention (the main_batched chain): body profiles_u8_block (profiles_blocks.hpp).  grid = (leaf, image) ----
-template <int TR>
+template <int TR, bool UA>
 __global__ __launch_bounds__(NT) void profiles_u8_kernel(const uint8_t* __restrict__ A, int H, int W,
                                                          XfAttention<TR> xf, const PairwisePlan P,
                                                          double* __restrict__ col, double* __restrict__ ls) {
   __shared__ __attribute__((aligned(16))) uint8_t lds[profiles_u8_lds_bytes<TR>()];
-  profiles_u8_block<TR>(A, H, W, xf, P, col, ls, blockIdx.x, blockIdx.y, lds);
+  const int leaf = blockIdx.x, b = blockIdx.y;
+  profiles_u8_block<TR, UA>(A + (size_t)b * H * W, H, W, xf, P.off[leaf], P.len[leaf], P.nleaves, leaf, col + (size_t)b * W,
+                            ls + (size_t)b * H * P.nleaves, lds);
 }
 template <int TR>
 static int launch_profiles_u8(const void* A, int B, int H, int W, XfAttention<TR> xf, const PairwisePlan& P,
                               double* col, double* ls, hipStream_t st, bool* handled) {
   *handled = false;
-  if (tune(TUNE_PROFILES_VARIANT) == 1 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 3u) != 0) return ATTWARP_OK;
+  if (tune(TUNE_PROFILES_VARIANT) == 1) return ATTWARP_OK;
   for (int j = 0; j < P.nleaves; ++j)
-    if (P.len[j] < 8 || P.len[j] % 4 != 0) return ATTWARP_OK;
+    if (P.len[j] < 8) return ATTWARP_OK;
   *handled = true;
-  hipLaunchKernelGGL((profiles_u8_kernel<TR>), dim3(P.nleaves, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, col, ls);
+  // rows that do not start on dword boundaries (W % 4 != 0, or a view that starts anywhere): the UA form of the block
+  const bool ua = W % 4 != 0 || (reinterpret_cast<uintptr_t>(A) & 3u) != 0;
+  if (ua) hipLaunchKernelGGL((profiles_u8_kernel<TR, true>), dim3(P.nleaves, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, col, ls);
+  else hipLaunchKernelGGL((profiles_u8_kernel<TR, false>), dim3(P.nleaves, B), dim3(NT), 0, st, (const uint8_t*)A, H, W, xf, P, col, ls);
   return check_launch("profiles_u8_kernel");
 }
 
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(NT) void adaptive_pool_kernel(const float* __restri
 __global__ __launch_bounds__(NT) void attention_maps_finalize_kernel(const PairwisePlan Pw, const PairwisePlan Ph,
                                                                      const MapsFinalizeArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem_d[];
-  attention_maps_finalize_block(Pw, Ph, a, blockIdx.x, blockIdx.y, smem_d);
+  attention_maps_finalize_block(Pw, Ph, maps_finalize_image(a, blockIdx.x, Pw.nleaves), blockIdx.y, smem_d);
 }
 
 template <typename T, typename XF>

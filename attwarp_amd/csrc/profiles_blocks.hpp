@@ -132,8 +132,10 @@ struct PlanView {
   int nleaves, nprog;
 };
 constexpr size_t plan_view_lds_bytes(int nleaves) { return (size_t)nleaves * 8 + (size_t)((2 * nleaves + 7) & ~7); }
-// carve a view out of `mem` (plan_view_lds_bytes(P.nleaves) bytes, 4-byte aligned) and fill it; all threads, then barrier
-__device__ __forceinline__ PlanView plan_to_lds(const PairwisePlan& P, void* mem) {
+// carve a view out of `mem` (plan_view_lds_bytes(P.nleaves) bytes, 4-byte aligned) and fill it; all threads, then barrier.
+// SrcPlan: a PairwisePlan in the kernel arguments, or a plan of the same member names in global memory (the ragged chain)
+template <typename SrcPlan>
+__device__ __forceinline__ PlanView plan_to_lds(const SrcPlan& P, void* mem) {
   PlanView v;
   v.nleaves = P.nleaves; v.nprog = P.nprog;
   v.off = reinterpret_cast<int*>(mem);
@@ -226,7 +228,10 @@ __device__ __forceinline__ double pw_sum_block(const double* a, const Plan& P, d
 //     table of XfAttention<TR>(byte) built once per workgroup with the SAME device functions as the generic kernel
 //     (bit-identical results, no per-element sqrt / exp / log).
 // The row stride of the byte tile is 128 + 8 bytes = 34 dwords: the 64 dword reads of a row-sum wave (32 rows x 2
-// halves) hit 64 different banks.  Requires W % 4 == 0, a 4-byte aligned base, every leaf >= 8 long and a multiple of 4.
+// halves) hit 64 different banks.  Requires every leaf >= 8 long.  W % 4 != 0 and any base address (UA, "unaligned":
+// the up-sampled mask of a 683-pixel-wide image): leaf offsets are multiples of 8 in every plan, so only the row STARTS
+// move -- the dword loads stay dwords relative to the row start (unaligned access mode) -- and only the plan's last leaf
+// can end in a partial dword, which is loaded END-aligned (the four bytes that end with the row) and shifted down.
 constexpr int U8_RB = 64;              // rows per band
 constexpr int U8_STR = 128 + 8;        // tile row stride in bytes
 
@@ -235,18 +240,19 @@ template <int TR>
 constexpr size_t profiles_u8_lds_bytes() {
   return 2 * (size_t)U8_RB * U8_STR + ((TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE) ? 0 : 256 * sizeof(double));
 }
-template <int TR>
-__device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ A, int H, int W, const XfAttention<TR>& xf,
-                                                  const PairwisePlan& P, double* __restrict__ col,
-                                                  double* __restrict__ ls, int leaf, int b, uint8_t* lds) {
+// img: ONE image's [H,W] bytes; (coff, len) = leaf `leaf` of the row plan of W (nleaves leaves); col: that image's [W]
+// column sums, ls: its [H,nleaves] per-leaf row sums
+template <int TR, bool UA = false>
+__device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ img, int H, int W, const XfAttention<TR>& xf,
+                                                  int coff, int len, int nleaves, int leaf, double* __restrict__ col,
+                                                  double* __restrict__ ls, uint8_t* lds) {
   constexpr bool ARITH = (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE);
   uint8_t (*tile)[U8_RB * U8_STR] = reinterpret_cast<uint8_t (*)[U8_RB * U8_STR]>(lds);
   double* lut = reinterpret_cast<double*>(lds + 2 * U8_RB * U8_STR);
   const int tid = threadIdx.x;
-  const int coff = P.off[leaf], len = P.len[leaf], nleaves = P.nleaves;
   const int m = len >> 3;                                          // steps of the stride-8 accumulators
   if (!ARITH) lut[tid] = xf((double)tid);
-  const uint8_t* base = A + (size_t)b * H * W + coff;
+  const uint8_t* base = img + coff;
   // element transform of a byte held as float (exact)
   auto tf = [&](float f) -> double {
     if (TR == ATTWARP_T_SQUARE) return (double)fmul(f, f) + 1e-9;   // <= 65025: exact in float32
@@ -254,13 +260,18 @@ __device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ A,
   };
   // global -> registers: thread owns dword (tid & 31) of rows (tid >> 5) + 8 * pass
   const int gd = tid & 31, gr = tid >> 5;
-  const int nd = len >> 2;                                         // dwords per leaf row (len % 4 == 0)
+  const int nd = UA ? (len + 3) >> 2 : len >> 2;                   // dwords per leaf row (!UA: len % 4 == 0)
+  // UA: the leaf's last dword holds len % 4 bytes: loaded from the four bytes that END with the leaf, shifted down
+  const bool tail = UA && 4 * gd + 4 > len && gd < nd;
+  const int goff = tail ? len - 4 : 4 * gd;
+  const unsigned tshr = tail ? 8u * (unsigned)(4 * gd + 4 - len) : 0u;
   constexpr int NPASS = U8_RB / 8;
   uint32_t raw[NPASS];
 #define ATTWARP_U8P_FETCH(row0_)                                                                 \
   _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps) {                                          \
     const int r_ = (row0_) + gr + 8 * ps;                                                        \
-    raw[ps] = (r_ < H && gd < nd) ? reinterpret_cast<const uint32_t*>(base + (size_t)r_ * W)[gd] : 0u; \
+    raw[ps] = (r_ < H && gd < nd) ? *reinterpret_cast<const u32_una*>(base + (size_t)r_ * W + goff) : 0u; \
+    if (UA) raw[ps] >>= tshr;                                                                    \
   }
 #define ATTWARP_U8P_STAGE(buf_)                                                                  \
   _Pragma("unroll") for (int ps = 0; ps < NPASS; ++ps)                                            \
@@ -306,7 +317,7 @@ __device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ A,
       if (hh == 0 && r < nb) {
         const uint8_t* tp = tb + r * U8_STR;
         for (int i = 8 * m; i < len; ++i) u += ARITH ? tf((float)tp[i]) : lut[tp[i]];
-        ls[((size_t)b * H + row0 + r) * nleaves + leaf] = u;
+        ls[((size_t)row0 + r) * nleaves + leaf] = u;
       }
     } else if (tid - 2 * U8_RB < len) {
       // ---- columns (waves 2-3): ascending rows ----
@@ -327,7 +338,7 @@ __device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ A,
   }
 #undef ATTWARP_U8P_FETCH
 #undef ATTWARP_U8P_STAGE
-  if (tid >= 2 * U8_RB && tid - 2 * U8_RB < len) col[(size_t)b * W + coff + tid - 2 * U8_RB] = cacc;
+  if (tid >= 2 * U8_RB && tid - 2 * U8_RB < len) col[coff + tid - 2 * U8_RB] = cacc;
 }
 
 // ---- A13 finalize: profile -> (inverse) -> total / fallback -> cumsum -> knots -> np.interp ----
@@ -346,8 +357,8 @@ __device__ __forceinline__ double inverse_transform(double x, int transform, dou
 }
 
 struct MapsFinalizeArgs {
-  const double* col;         // [B, w] column sums
-  const double* ls;          // [B, h, nleaves(w)] per-leaf row sums
+  const double* col;         // [B, w] column sums           (kernel arguments: the batch; inside the block: one image,
+  const double* ls;          // [B, h, nleaves(w)] per-leaf row sums                     see maps_finalize_image)
   int h, w, new_w, new_h, transform;
   double exp_scale, exp_divisor;
   int apply_inverse;
@@ -369,8 +380,10 @@ inline size_t maps_finalize_lds_bytes(int h, int w, const PairwisePlan& Pw, cons
   return (size_t)(n + 2) * 8 + (PROF_NT / WAVE) * 8 + (size_t)pw_depth(Pw) * PROF_NT * 8 + (size_t)nl * 8 +
          plan_view_lds_bytes(Pw.nleaves) + plan_view_lds_bytes(Ph.nleaves);
 }
-__device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan& Pw_arg, const PairwisePlan& Ph_arg,
-                                                              const MapsFinalizeArgs& a, int b, int axis, double* lds) {
+// a.col / a.ls / a.map_x / a.map_y: ONE image's column sums [w], per-leaf row sums [h,nleaves(w)] and map rows
+template <typename SrcPlan>
+__device__ __forceinline__ void attention_maps_finalize_block(const SrcPlan& Pw_arg, const SrcPlan& Ph_arg,
+                                                              const MapsFinalizeArgs& a, int axis, double* lds) {
   constexpr int NT = PROF_NT;
   const double* __restrict__ col = a.col; const double* __restrict__ ls = a.ls;
   const int h = a.h, w = a.w, new_w = a.new_w, new_h = a.new_h, transform = a.transform, apply_inverse = a.apply_inverse;
@@ -392,12 +405,12 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
   const int other = axis ? w : h;        // number of terms summed into each profile entry
   const int n_out = axis ? new_h : new_w;
   const int nl = Pw.nleaves;
-  float* map = (axis ? map_y : map_x) + (size_t)b * n_out;
+  float* map = axis ? map_y : map_x;
   double* xn = smem_d;                   // n+1 knots; xn[1..n] first holds the profile
 
   // row r of the y profile = numpy's pairwise tree over that row's leaf sums
   auto row_sum = [&](int r) -> double {
-    const double* l = ls + ((size_t)b * h + r) * nl;
+    const double* l = ls + (size_t)r * nl;
     return pw_combine(Pw, [&](int j) { return l[j]; }, pstack + threadIdx.x, NT);
   };
   auto inv_bias = [&](double v, int terms) -> double {
@@ -408,7 +421,7 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
   // they only feed the `< 1e-9` fallback test and the fallback's np.mean)
   double acc_other = 0.0, all = 0.0;
   for (int k = threadIdx.x; k < w; k += blockDim.x) {
-    const double v = col[(size_t)b * w + k];
+    const double v = col[k];
     if (axis == 0) xn[k + 1] = inv_bias(v, h); else acc_other += inv_bias(v, h);
   }
   for (int k = threadIdx.x; k < h; k += blockDim.x) {
@@ -467,5 +480,13 @@ __device__ __forceinline__ void attention_maps_finalize_block(const PairwisePlan
   ATTWARP_F_MARK(7)
 }
 #undef ATTWARP_F_MARK
+// the arguments of image b of a dense batch
+__device__ __forceinline__ MapsFinalizeArgs maps_finalize_image(MapsFinalizeArgs a, int b, int nleaves_w) {
+  a.col += (size_t)b * a.w;
+  a.ls += (size_t)b * a.h * nleaves_w;
+  a.map_x += (size_t)b * a.new_w;
+  a.map_y += (size_t)b * a.new_h;
+  return a;
+}
 
 }  // namespace attwarp

@@ -276,6 +276,9 @@ extern "C" int attwarp_remap_bilinear(const void* src, void* dst, int dtype, int
     if (handled) return rc;
   }
 
+  // (tuning flavour, remap_variant = 3: the tests' proof of WHICH kernel served a shape -- refuse instead of falling back)
+  if (tune(TUNE_REMAP_VARIANT) == 3) return fail(ATTWARP_E_UNSUPPORTED, "remap_bilinear: this request takes the generic gather kernel");
+
 #define ATTWARP_DISPATCH(T)                                                                                  \
   if (mode == ATTWARP_EXACT && layout == ATTWARP_HWC)                                                        \
     return launch_gather<T, ATTWARP_EXACT, ATTWARP_HWC>(src, dst, B, C, H, W, H_out, W_out, map_x, map_y, st); \

@@ -74,14 +74,16 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // contiguous range of row blocks per XCD (group = 0) the eight XCDs stream eight regions ~B/8 images apart, which is
   // the fastest order on some leases (1.09 ms at 1024x1024x3 B=256) and the slowest on others (1.175 ms); with the XCDs
   // interleaved in groups of g row blocks (g - 1 of g halo seams still meet in one L2) all of them work in ONE compact
-  // window and the time is the same on both kinds of lease.  Rows of >= 10 KB therefore run R = 3 with groups of 4
-  // (cv2: 1.12-1.13 ms on three slow leases, 1.11 on a fast one; exact: groups of 3, 1.106 ms); the choice is made for
-  // the worst case (profiles/round3_order_sweeps.md).  cpw = row blocks per workgroup, strided by the workgroups of
-  // the image: the column-tap prologue is paid once per cpw blocks (peaked maps 0.97 -> 0.93 ms, 768x768x3 0.84 -> 0.76).
+  // window and the time is the same on both kinds of lease.  Rows of >= 10 KB therefore run R = 3 in groups (shipped:
+  // cv2 groups of 8 with two row blocks per workgroup, exact groups of 3 with one -- the history of that choice is below
+  // and in docs/experiments.md); the choice is made for the worst case (profiles/round3_order_sweeps.md).  cpw = row
+  // blocks per workgroup, strided by the workgroups of the image: the column-tap prologue is paid once per cpw blocks
+  // (peaked maps 0.97 -> 0.93 ms, 768x768x3 0.84 -> 0.76).  (LDS: cv2 rows of 8-12 KB use two [top | bottom] buffers
+  // and one barrier per row, the fused step and wider rows one buffer and two: remap_rows_kernel.hpp, SINGLE.)
   int group = 0, cpw = 1;
   if (!tiled && row_bytes >= 10 * 1024) {
-    // round 4 (profiles/round4_remap_pmc.txt, round4_order_sweep_*.txt): cv2 groups of 8 with 3 row blocks per workgroup
-    // instead of groups of 4 with 2 -- the halo rows that cross XCDs drop from 1/4 to 1/8 of the seams (fabric reads
+    // round 4 (profiles/round4_remap_pmc.txt, round4_order_sweep_*.txt): cv2 groups of 8 (first with 3 row blocks per
+    // workgroup, shipped with 2: see below) instead of groups of 4 -- the halo rows that cross XCDs drop from 1/4 to 1/8 of the seams (fabric reads
     // 1.090 -> 1.051 x algorithmic, total traffic 1.045 -> 1.025 x), +0.7-1 % on both kinds of lease, peaked maps +3 %;
     // larger groups (12, 16, 24) and more rows per block (5, 6) lose; exact mode is fastest as it was (groups of 3; 8 loses 7 %)
     // (round 4, with the row loop whose look-ahead overlaps and one row list per workgroup: which of 1 / 2 / 3 row blocks per
@@ -164,8 +166,13 @@ int step_fused_impl(const SlotPtrs* sl, int nslots, int layout, int B, int C, in
     // 16-byte vector loads of the resample: the geometry is planned on slot 0, slot 1 must satisfy the same alignment
     ATTWARP_REQUIRE(((reinterpret_cast<uintptr_t>(sl[1].src) ^ reinterpret_cast<uintptr_t>(s0.src)) & 15u) == 0,
                     "warp_step_fused: both slots' images must have the same 16-byte alignment");
-    ATTWARP_REQUIRE(sl[1].dst != s0.dst && sl[1].map_x_next != s0.map_x_next && sl[1].steps_out != s0.steps_out,
-                    "warp_step_fused: the two slots must write different buffers");
+    // (an absent piece has null pointers in BOTH slots: only the pieces that are present are compared)
+    ATTWARP_REQUIRE(sl[1].dst != s0.dst, "warp_step_fused: the two slots must write different buffers");
+    if (s0.steps_in)
+      ATTWARP_REQUIRE(sl[1].map_x_next != s0.map_x_next && sl[1].map_y_next != s0.map_y_next,
+                      "warp_step_fused: the two slots must write different map buffers");
+    if (s0.rows)
+      ATTWARP_REQUIRE(sl[1].steps_out != s0.steps_out, "warp_step_fused: the two slots must write different step-map buffers");
   }
   StepExtra ex;
   memset(&ex, 0, sizeof(ex));

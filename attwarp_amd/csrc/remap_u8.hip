@@ -308,20 +308,21 @@ static int launch_ko(const Params& p, hipStream_t st) {
 }
 
 // ---- CV2 mode, integer form (rows of <= 4096 bytes): body remap_rows_u8i_block (remap_u8_block.hpp) ----
-template <int KI, int KD, bool HWC, int PD>
+template <int KI, int KD, bool HWC, int PD, bool UA>
 __global__ __launch_bounds__(NT) void remap_rows_u8i_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  remap_rows_u8i_block<KI, KD, HWC, PD>(p, blockIdx.x, smem);
+  remap_rows_u8i_block<KI, KD, HWC, PD, UA>(p, blockIdx.x, smem);
 }
 
 template <int KI, int PD>
 static int launch_u8i_ki(const Params& p, hipStream_t st) {
   const size_t lds = (size_t)RMAX * sizeof(float) + 2 * (size_t)U8I_VLP * sizeof(uint16_t);
-  const int kd = ((p.OVL >> 2) + NT - 1) / NT;
+  const int kd = ((((p.OVL + 3) >> 2)) + NT - 1) / NT;
   const dim3 g(p.nblocks), t(NT);
 #define ATTWARP_U8I_LAUNCH(KD)                                                                              \
-  if (p.NP == 1) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true, PD>), g, t, lds, st, p);            \
-  else hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, false, PD>), g, t, lds, st, p)
+  if (p.unaligned) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true, PD, true>), g, t, lds, st, p);    \
+  else if (p.NP == 1) hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, true, PD, false>), g, t, lds, st, p); \
+  else hipLaunchKernelGGL((remap_rows_u8i_kernel<KI, KD, false, PD, false>), g, t, lds, st, p)
   if (kd <= 1) { ATTWARP_U8I_LAUNCH(1); } else if (kd == 2) { ATTWARP_U8I_LAUNCH(2); }
   else if (kd == 3) { ATTWARP_U8I_LAUNCH(3); } else { ATTWARP_U8I_LAUNCH(4); }
 #undef ATTWARP_U8I_LAUNCH
@@ -341,7 +342,7 @@ static int launch_u8i_depth(const Params& p, hipStream_t st) {
   return launch_u8i_ki<KI, (KI <= 2 ? 4 : 2)>(p, st);
 }
 static int launch_u8i(const Params& p, hipStream_t st) {
-  const int ki = ((p.VL >> 2) + NT - 1) / NT;
+  const int ki = (((p.VL + 3) >> 2) + NT - 1) / NT;
   switch (ki) {
     case 1: return launch_u8i_depth<1>(p, st);
     case 2: return launch_u8i_depth<2>(p, st);
@@ -378,20 +379,25 @@ static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout
   if (layout == ATTWARP_HWC) { p.NP = 1; p.CS = C; } else { p.NP = C; p.CS = 1; }
   p.row_len = W * p.CS;
   p.orow_len = Wo * p.CS;
-  const long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
-  // dword loads / stores: every plane row must start on a 4-byte boundary, both sides
-  if (p.row_len % 4 != 0 || p.orow_len % 4 != 0) return false;
-  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0) return false;
-  if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
-                            : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0)
-    return false;
+  long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
+  // dword loads / stores: every plane row starts on a 4-byte boundary on both sides -- or the request is "unaligned"
+  // (e.g. 683 pixels x 3 bytes per row): served by the UA form of the integer cv2 kernel when its other conditions hold
+  // (cv2 mode, rows of 4 .. 4096 bytes; planar images plane by plane), by the generic gather kernel otherwise (exact
+  // mode, column-tiled rows)
+  bool ua = p.row_len % 4 != 0 || p.orow_len % 4 != 0 ||
+            ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0 ||
+            (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
+                                   : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0);
+  if (ua && (mode != ATTWARP_CV2 || tune(TUNE_REMAP_VARIANT) == 2)) return false;
   p.map_div = 1;
   p.ntiles = 1;
   p.grp = tune(TUNE_REMAP_NOSWZ) >= 0 ? tune(TUNE_REMAP_NOSWZ) : 0;
   // up to 4096 bytes per staged row (16-bit LDS offsets); wider rows run in column tiles, planar ones plane by plane
-  const bool tiled = VL > 4096 || OVL > 4096;
-  if (tiled) {
-    if (tune(TUNE_REMAP_TILED) == 0) return false;
+  bool tiled = VL > 4096 || OVL > 4096;
+  if (ua && layout != ATTWARP_HWC && p.row_len <= 4096 && p.orow_len <= 4096) tiled = false;   // plane by plane below
+  if (ua && (tiled || p.row_len < 4)) return false;
+  if (tiled || (ua && layout != ATTWARP_HWC)) {
+    if (tiled && tune(TUNE_REMAP_TILED) == 0) return false;
     if ((long long)p.row_len > 2147483647LL / 8 || (long long)p.orow_len > 2147483647LL / 8 ||
         (long long)B * C > 2147483647LL)
       return false;
@@ -402,8 +408,10 @@ static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout
       p.NP = 1;
       p.CS = 1;
       layout = ATTWARP_HWC;
+      VL = p.row_len; OVL = p.orow_len;
     }
   }
+  p.unaligned = ua ? 1 : 0;
   p.VL = (int)(tiled ? p.row_len : VL);
   p.OVL = (int)(tiled ? p.orow_len : OVL);
   p.plane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)H * W;
@@ -438,6 +446,7 @@ static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout
     while (cpw > 1 && (long long)((p.nblk + cpw - 1) / cpw) * B < 4096) cpw >>= 1;       // keep the chip filled
     p.wpi = (p.nblk + cpw - 1) / cpw;
   }
+  if (ua && !integer_form) return false;
   const long long nb = (long long)p.wpi * B * p.ntiles;
   if (nb > 2147483647LL) return false;
   p.nblocks = (int)nb;

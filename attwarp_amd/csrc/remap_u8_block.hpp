@@ -24,6 +24,7 @@ struct Params {
   int grp;   // integer cv2 kernel, block order: 0 = contiguous range per XCD, 1 = plain, g >= 2 = XCDs interleaved in groups of g
   int ntiles;              // TILED: column tiles per row (each KO*NT output bytes), else 1
   int map_div;             // maps belong to image b / map_div (planes of a planar image dispatched as images)
+  int unaligned;           // integer cv2 kernel: rows / images that are not dword aligned (the UA instantiation)
 };
 
 // ---- CV2 mode, integer form (rows of <= 4096 bytes) ----------------------------------------------------------------
@@ -50,42 +51,45 @@ constexpr int U8I_STORE_NT = 2;
 constexpr int U8I_VLP = 4096 + 16;      // u16 elements per LDS row buffer: rows of <= 4096 bytes + one pixel of slack
 
 constexpr size_t u8i_lds_bytes() { return (size_t)RMAX * sizeof(float) + 2 * (size_t)U8I_VLP * sizeof(uint16_t); }
-// bid_in: the workgroup's index in launch order (block % 8 names the XCD it runs on); smem: u8i_lds_bytes() of LDS
-template <int KI, int KD, bool HWC, int PD>
-__device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in, float* smem) {
+// One workgroup's share of ONE image: row blocks rb0, rb0 + p.wpi, ... of the image whose pixels start at src_b (img_bytes
+// long) and whose output starts at dst_b; mx_b / my_b: that image's maps.  p carries the geometry (H, W, Ho, Wo, CS,
+// row_len, VL, ..., R, nblk, wpi); p.src / p.dst / p.mx / p.my / p.img_stride are not read here, so the ragged chain
+// (chain_ragged.hip) can fill a Params per image from its descriptor table.  smem: u8i_lds_bytes() of LDS.
+// UA ("unaligned", interleaved images only): rows whose byte length is not a multiple of 4 and images that start anywhere
+// -- e.g. 683 x 3 bytes per row, the portrait TextVQA case.  The loads and stores stay dwords relative to the ROW start
+// (gfx950 runs with unaligned access mode on: a wave's 256 contiguous bytes at a byte offset touch one more cache line);
+// only the LAST dword of a row differs: it is loaded END-aligned (the four bytes that end with the row: nothing behind
+// the image is ever read) and shifted down in registers, and the last output dword of a row is stored byte by byte.
+template <int KI, int KD, bool HWC, int PD, bool UA>
+__device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8_t* src_b, int img_bytes, uint8_t* dst_b,
+                                                    int oimg_bytes, const float* mx_b, const float* my_b, int rb0, float* smem) {
+  static_assert(!UA || HWC, "unaligned rows: interleaved images only (planar ones are dispatched plane by plane)");
   float* s_my = smem;                                               // RMAX
   // two row buffers a COMPILE-TIME distance apart: tap offsets then fold into the 16-bit offset field of the LDS
   // instructions (with a run-time stride every one of the 8 reads per output dword cost a v_add_u32 for its address)
   uint16_t* vrow0 = reinterpret_cast<uint16_t*>(smem + RMAX);
   uint16_t* vrow1 = vrow0 + U8I_VLP;
   const int tid = threadIdx.x;
-  int bid = bid_in;
-  {     // block order, as in remap_rows_kernel.hpp
-    const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-    if (p.grp == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
-    else if (p.grp >= 2) {
-      const int g = p.grp, per = 8 * g, grp = idx / g, within = idx - grp * g, cand = grp * per + xcd * g + within;
-      bid = cand < (n / per) * per ? cand : bid;
-    }
-  }
-  const int b = bid / p.wpi, rb0 = bid - b * p.wpi;
   // per-image buffer descriptors (block uniform; images are < 2 GiB: plane_stride * NP is checked by the host)
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(p.src + (long long)b * p.img_stride), 0, (int)p.img_stride, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(p.dst + (long long)b * p.oimg_stride, 0,
-                                                                        (int)p.oimg_stride, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_b), 0, img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(dst_b, 0, oimg_bytes, 0x00020000);
 
   // source dwords this thread owns (clamped: padding lanes repeat the last dword)
   unsigned goff[KI];                // byte offset inside the image (row 0): unsigned, so the loads take the SGPR-base form
   int voff[KI];                     // u16 index in the LDS row
+  unsigned tail_shr = 0;            // UA: the thread that owns the row's last, partial dword shifts it down by this many bits
   {
-    const int dpr = p.row_len >> 2, nd = p.VL >> 2;
+    const int dpr = p.row_len >> 2, nd = UA ? (p.VL + 3) >> 2 : p.VL >> 2;
 #pragma unroll
     for (int k = 0; k < KI; ++k) {
       const int d = min(tid + NT * k, nd - 1);
       const int pl = HWC ? 0 : d / dpr;
       goff[k] = (unsigned)(pl * p.plane_stride) + 4u * (unsigned)(d - pl * dpr);
       voff[k] = 4 * d;
+      if (UA && k == KI - 1 && 4 * d + 4 > p.VL) {     // (KI = ceil(nd / NT): the last dword always lies in slot KI - 1)
+        goff[k] = (unsigned)(p.VL - 4);
+        tail_shr = 8u * (unsigned)(4 * d + 4 - p.VL);
+      }
     }
   }
   // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
@@ -93,7 +97,7 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
   unsigned t0[KD][4], t1[KD][4], wpk[KD][4];    // wpk: (32 - kx) | kx << 16, the two weights of v_dot2_u32_u16
   int soff[KD];
   {
-    const int dpo = p.orow_len >> 2, ndo = p.OVL >> 2;
+    const int dpo = p.orow_len >> 2, ndo = UA ? (p.OVL + 3) >> 2 : p.OVL >> 2;
     // u16 element e of the row lives at position [e0, e2, e1, e3] of its group of four (the vertical pass produces the
     // pairs (0,2) and (1,3) of a source dword; no re-interleaving).  (Swapping the two dwords of a group in every other
     // 64-dword window, so that lanes l and l + 32 of a slope-1 gather use different banks, was measured: no effect --
@@ -114,9 +118,9 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
       int xj = r0 / p.CS, cj = r0 - xj * p.CS;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int x = xj, c = cj;
+        const int x = UA ? min(xj, p.Wo - 1) : xj, c = cj;    // (UA: the bytes behind the row's end in its last dword)
         if (++cj >= p.CS) { cj = 0; ++xj; }
-        const float m = p.mx[(long long)b * p.Wo + x];
+        const float m = mx_b[x];
         const int q = cv_round_q5(m);                               // cvRound
         const int i = q >> 5;
         const int i0 = min(max(i, 0), p.W - 1), i1 = min(max(i + 1, 0), p.W - 1);
@@ -165,6 +169,7 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
 #define ATTWARP_U8I_ROW(q_, vbuf, VOFF, AX, CX, KY)                                                    \
   {                                                                                                    \
     const unsigned w1_ = KY, w0_ = 32u - KY;                                                           \
+    if (UA) { AX[KI - 1] >>= tail_shr; CX[KI - 1] >>= tail_shr; }                                      \
     const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
       /* bytes (0, 2) and (1, 3) zero-extended to two u16: an and, and ONE v_perm_b32 (shift + and before) */ \
@@ -196,6 +201,10 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
         o_ |= (in_ >> 10) << (8 * j);                                                                  \
       }                                                                                                \
       if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, U8I_STORE_NT); \
+      else if (UA && k == KD - 1 && tid + NT * k == (p.OVL >> 2)) {   /* the row's last 1..3 bytes */           \
+        for (int j_ = 0; j_ < (p.OVL & 3); ++j_)                                                       \
+          __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(o_ >> (8 * j_)), rdst, soff[k] + j_, orow_, U8I_STORE_NT); \
+      }                                                                                                \
     }                                                                                                  \
   }
   // Row blocks of this workgroup: rb0, rb0 + wpi, ... -- the column-tap prologue above (a cvRound and two integer
@@ -205,7 +214,7 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
     y0 = rb * p.R;
     nrows = min(y0 + p.R, p.Ho) - y0;
     if (rb != rb0) __syncthreads();          // the previous block's last gather is done with s_my and the row buffers
-    if (tid < nrows) s_my[tid] = p.my[(long long)b * p.Ho + y0 + tid];
+    if (tid < nrows) s_my[tid] = my_b[y0 + tid];
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PD; ++u)
@@ -228,10 +237,28 @@ __device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in
 #undef ATTWARP_U8I_FETCH
 }
 
+// A batch of equally shaped images: bid_in = the workgroup's index in launch order (block % 8 names the XCD it runs on)
+template <int KI, int KD, bool HWC, int PD, bool UA = false>
+__device__ __forceinline__ void remap_rows_u8i_block(const Params& p, int bid_in, float* smem) {
+  int bid = bid_in;
+  {     // block order, as in remap_rows_kernel.hpp
+    const int n = p.nblocks, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
+    if (p.grp == 0) bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    else if (p.grp >= 2) {
+      const int g = p.grp, per = 8 * g, grp = idx / g, within = idx - grp * g, cand = grp * per + xcd * g + within;
+      bid = cand < (n / per) * per ? cand : bid;
+    }
+  }
+  const int b = bid / p.wpi, rb0 = bid - b * p.wpi, bm = b / p.map_div;
+  remap_rows_u8i_rows<KI, KD, HWC, PD, UA>(p, p.src + (long long)b * p.img_stride, (int)p.img_stride,
+                                           p.dst + (long long)b * p.oimg_stride, (int)p.oimg_stride,
+                                           p.mx + (long long)bm * p.Wo, p.my + (long long)bm * p.Ho, rb0, smem);
+}
+
 }  // namespace u8k
 
 // Fills the launch geometry of the integer kernel for a [B,H,W,C] (HWC) or [B,C,H,W] uint8 batch; false when the shape
-// takes another kernel (rows wider than 4096 bytes, unaligned rows, exact mode: remap_u8.hip decides).
+// takes another kernel (rows wider than 4096 bytes, exact mode: remap_u8.hip decides).
 bool u8i_params(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout, int B, int C, int H, int W, int Ho, int Wo,
                 const float* mx, const float* my);
 

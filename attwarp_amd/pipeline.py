@@ -958,3 +958,258 @@ class MaskChainStream:
             self._L(k + 3); self._PF(k + 3); self._R(k + 3)
         self.k += self.depth
         return self.out
+
+
+# ---- the main_batched chain for batches of DIFFERENTLY sized images -------------------------------------------------------
+RAGGED_MAX_ROW_BYTES = 4096          # attwarp_ragged_plan: rows of the integer cv2 resample
+RAGGED_MAX_SIDE = 8192
+
+
+def ragged_eligible(h: int, w: int, c: int, g: int = GRID) -> bool:
+    """Does an [h,w,c] uint8 image run on the ragged chain kernel (attwarp.h: limits of attwarp_ragged_plan)?"""
+    return 4 <= w * c <= RAGGED_MAX_ROW_BYTES and h > g and w > g and max(h, w) <= RAGGED_MAX_SIDE and c <= 4
+
+
+class RaggedBatch:
+    """One batch of differently sized uint8 images [H_i,W_i,C] on the GPU, planned for ``attwarp_mask_chain_ragged``:
+    the table (host copy in pinned memory + device copy), and the batch's own intermediates and outputs --
+    ``rev`` [B,g,g], ``mota`` (the up-sampled masks, packed), ``sums`` (axis sums), ``maps`` and ``out`` [B,H_out,W_out,C].
+    The images are referenced, not copied: keep them alive and unchanged until the batch's resample has run."""
+
+    def __init__(self, images, out_size=(500, 500), g: int = GRID, out: Optional[torch.Tensor] = None):
+        import ctypes
+        images = list(images)
+        if not images:
+            raise ValueError("RaggedBatch: empty batch")
+        dev = require_gpu(*images)
+        C = int(images[0].shape[2]) if images[0].dim() == 3 else -1
+        for im in images:
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != C or not im.is_contiguous():
+                raise TypeError("RaggedBatch: images must be contiguous uint8 [H,W,C] tensors with one channel count")
+        self.images = images
+        self.B, self.C, self.g = len(images), C, int(g)
+        self.Ho, self.Wo = int(out_size[0]), int(out_size[1])
+        self._dev = dev
+        lib = _lib.load()
+        rec = (_lib.RaggedImage * self.B)()
+        self._tables = []                   # (keeps the cached coefficient tensors referenced)
+        for r, im in zip(rec, images):
+            H, W = int(im.shape[0]), int(im.shape[1])
+            bx, kx, ksx = _tables.lanczos_tables(self.g, W, dev)
+            by, ky, ksy = _tables.lanczos_tables(self.g, H, dev)
+            if ksy != 8:
+                raise _lib.AttWarpError(f"RaggedBatch: image of {H} x {W}: the vertical mask up-sampling needs {ksy} taps (> 8)")
+            self._tables.append((bx, kx, by, ky))
+            r.image, r.H, r.W = im.data_ptr(), H, W
+            r.bounds_x, r.kk_x, r.ksize_x = bx.data_ptr(), kx.data_ptr(), ksx
+            r.bounds_y, r.kk_y = by.data_ptr(), ky.data_ptr()
+        nbytes = lib.attwarp_ragged_table_bytes(ctypes.byref(rec), self.B, C, self.g, self.Ho, self.Wo)
+        if nbytes == 0:
+            raise _lib.AttWarpError("attwarp_ragged_table_bytes: " + lib.attwarp_last_error().decode("utf-8", "replace"))
+        self.table_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        call("attwarp_ragged_plan", ctypes.byref(rec), self.B, C, self.g, self.Ho, self.Wo, self.table_host.data_ptr(), nbytes)
+        self.header = _lib.RaggedHeader.from_address(self.table_host.data_ptr())
+        self.table_dev = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        self.table_dev.copy_(self.table_host, non_blocking=True)
+        h = self.header
+        self.rev = torch.empty(self.B, self.g, self.g, device=dev, dtype=torch.float32)
+        self.mota = torch.empty(int(h.mota_bytes), device=dev, dtype=torch.uint8)
+        self.sums = torch.empty(int(h.sums_bytes) // 8, device=dev, dtype=torch.float64)
+        self.map_x = torch.empty(self.B, self.Wo, device=dev, dtype=torch.float32)
+        self.map_y = torch.empty(self.B, self.Ho, device=dev, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(self.B, self.Ho, self.Wo, C, device=dev, dtype=torch.uint8)
+        elif tuple(out.shape) != (self.B, self.Ho, self.Wo, C) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("RaggedBatch: out must be a dense uint8 [B,H_out,W_out,C] tensor on the images' device")
+        self.out = out
+        self.masks = None                   # [B,g,g] float32: set by the caller before V runs
+
+    @property
+    def algorithmic_bytes(self) -> int:
+        """Chain-level bytes of this batch: mask written + read (2 H W), image read (C H W), output written."""
+        px = sum(int(i.shape[0]) * int(i.shape[1]) for i in self.images)
+        return px * (2 + self.C) + self.B * self.Ho * self.Wo * self.C
+
+    def mota_of(self, b: int) -> torch.Tensor:
+        """The up-sampled uint8 mask [H_b,W_b] of image b (what blend_mask returns as ``mota_mask``, llava.py:253)."""
+        import ctypes
+        rec = (_RaggedImageDev * self.B).from_address(self.table_host.data_ptr() + int(self.header.off_images))
+        H, W = int(self.images[b].shape[0]), int(self.images[b].shape[1])
+        off = int(rec[b].mota_off)
+        return self.mota[off:off + H * W].view(H, W)
+
+
+class _RaggedImageDev(__import__("ctypes").Structure):
+    """The per-image record inside a table (chain_ragged.hip: RaggedImage); read here only for ``mota_off``."""
+    import ctypes as _c
+    _fields_ = [("image", _c.c_void_p), ("bounds_x", _c.c_void_p), ("kk_x", _c.c_void_p), ("bounds_y", _c.c_void_p),
+                ("kk_y", _c.c_void_p), ("H", _c.c_int32), ("W", _c.c_int32), ("ksize_x", _c.c_int32), ("plan_w", _c.c_int32),
+                ("plan_h", _c.c_int32), ("l_nchunks", _c.c_int32), ("l_rows_per_chunk", _c.c_int32), ("ki", _c.c_int32),
+                ("mota_off", _c.c_int64), ("sums_off", _c.c_int64)]
+
+
+def ragged_chain_launch(R: Optional[RaggedBatch] = None, F: Optional[RaggedBatch] = None, P: Optional[RaggedBatch] = None,
+                        L: Optional[RaggedBatch] = None, V: Optional[RaggedBatch] = None, enhance_coe=10, kernel_size=3):
+    """ONE launch of ``attwarp_mask_chain_ragged``: the resample of batch R, the map construction of F, the marginals of P,
+    the mask up-sampling of L and revise_mask of V (``V.masks`` [B,g,g] float32) -- five different batches of a stream, or
+    any subset (one batch alone: five launches, V -> L -> P -> F -> R)."""
+    some = next(b for b in (R, F, P, L, V) if b is not None)
+    dev = some._dev
+    def tab(b):
+        return (None, None) if b is None else (b.table_host.data_ptr(), ptr(b.table_dev))
+    if V is not None and (V.masks is None or V.masks.dtype != torch.float32 or tuple(V.masks.shape) != (V.B, V.g, V.g)
+                          or not V.masks.is_contiguous() or V.masks.device != dev):
+        raise ValueError("ragged_chain_launch: V.masks must be a dense float32 [B,g,g] tensor on the batch's device")
+    with torch.cuda.device(dev):
+        call("attwarp_mask_chain_ragged",
+             *tab(R), ptr(R.out) if R else None, ptr(R.map_x) if R else None, ptr(R.map_y) if R else None,
+             *tab(F), ptr(F.sums) if F else None, ptr(F.map_x) if F else None, ptr(F.map_y) if F else None,
+             *tab(P), ptr(P.mota) if P else None, ptr(P.sums) if P else None,
+             *tab(L), ptr(L.rev) if L else None, ptr(L.mota) if L else None,
+             ptr(V.masks) if V else None, V.B if V else 0, some.g, int(kernel_size), float(enhance_coe), ptr(V.rev) if V else None,
+             stream_ptr(dev))
+
+
+def warp_from_masks_ragged(images, attn24: torch.Tensor, out_size=(500, 500), enhance_coe=10, kernel_size=3,
+                           return_batch: bool = False):
+    """The ``main_batched.py:243-287`` chain for a batch of DIFFERENTLY sized images, as that driver holds them:
+    ``images``: list of uint8 [H_i,W_i,C] GPU tensors (any sizes, any width -- 683 x 1024 like 1024 x 768); ``attn24``
+    [B,24,24] -> dense uint8 [B,H_out,W_out,C].  Five launches for the whole batch (revise_mask, LANCZOS up-sampling to
+    every image's own size, float64 marginals, CDF / np.interp maps, cv2 resample), each over all images at once;
+    identity transform and cv2 arithmetic (what main_batched.py passes).  Images outside the ragged kernel's limits
+    (rows wider than 4096 bytes, sides <= 24 or > 8192) run through :func:`warp_from_masks` one by one."""
+    images = list(images)
+    B = len(images)
+    if attn24.shape[0] != B:
+        raise ValueError("warp_from_masks_ragged: one 24 x 24 map per image expected")
+    dev = require_gpu(attn24, *images)
+    g = int(attn24.shape[-1])
+    Ho, Wo = int(out_size[0]), int(out_size[1])
+    ok = [ragged_eligible(int(i.shape[0]), int(i.shape[1]), int(i.shape[2]), g) for i in images]
+    if Wo * int(images[0].shape[2]) > RAGGED_MAX_ROW_BYTES:
+        ok = [False] * B
+    masks = attn24.float().contiguous()
+    if all(ok):
+        rb = RaggedBatch(images, out_size, g)
+        rb.masks = masks
+        for stage in "VLPFR":
+            ragged_chain_launch(**{stage: rb}, enhance_coe=enhance_coe, kernel_size=kernel_size)
+        return (rb.out, rb) if return_batch else rb.out
+    out = torch.empty(B, Ho, Wo, int(images[0].shape[2]), device=dev, dtype=torch.uint8)
+    idx = [b for b in range(B) if ok[b]]
+    if idx:
+        sub = warp_from_masks_ragged([images[b] for b in idx], masks[idx], out_size, enhance_coe, kernel_size)
+        out[idx] = sub
+    for b in range(B):
+        if not ok[b]:
+            out[b] = warp_from_masks(images[b][None], masks[b:b + 1], out_size, enhance_coe, kernel_size)[0]
+    return (out, None) if return_batch else out
+
+
+class RaggedMaskChainStream:
+    """A stream of ragged batches, one launch per batch: R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) of
+    ``attwarp_mask_chain_ragged`` (the ragged twin of :class:`MaskChainStream`).
+
+        st = RaggedMaskChainStream(out_size=(500, 500))
+        for images, attn24 in batches:                 # lists of uint8 [H_i,W_i,3] GPU tensors, [B,24,24]
+            done = st.push(images, attn24)             # -> the RaggedBatch whose resample was just enqueued (4 pushes back)
+            if done is not None: use(done.out)
+        for done in st.flush(): use(done.out)
+
+    Every output equals :func:`warp_from_masks_ragged` on its batch, bit for bit (same stage bodies).  For steady-state
+    measurements ``ring`` + ``run`` replay one launch per batch over prebuilt batches (optionally as HIP graphs)."""
+
+    DEPTH = 4
+
+    def __init__(self, out_size=(500, 500), enhance_coe=10, kernel_size=3, g: int = GRID):
+        self.out_size = (int(out_size[0]), int(out_size[1]))
+        self.enhance_coe, self.kernel_size, self.g = float(enhance_coe), int(kernel_size), int(g)
+        self._q = []                       # the batches in flight, oldest first: [k-4 .. k]
+        self._graphs = {}
+
+    def _launch(self, q):
+        """q: the five batches [R, F, P, L, V] of this step (None where the stream has none)."""
+        if any(b is not None for b in q):
+            ragged_chain_launch(R=q[0], F=q[1], P=q[2], L=q[3], V=q[4], enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+
+    def push(self, images, attn24: torch.Tensor, out: Optional[torch.Tensor] = None):
+        rb = RaggedBatch(images, self.out_size, self.g, out=out)
+        rb.masks = attn24.float().contiguous()
+        self._q.append(rb)
+        q = ([None] * (self.DEPTH + 1) + self._q)[-(self.DEPTH + 1):]
+        self._launch(q)
+        if len(self._q) > self.DEPTH:
+            return self._q.pop(0)
+        return None
+
+    def flush(self):
+        """The launches that finish the batches still in flight; returns them oldest first."""
+        done = []
+        # the youngest batch in flight has had V only, the one before it V and L, ...: one launch moves every batch one
+        # stage on ([R, F, P, L, V] slots, oldest first)
+        q = ([None] * (self.DEPTH + 1) + self._q)[-(self.DEPTH + 1):]
+        q = q[1:] + [None]
+        while any(b is not None for b in q):
+            self._launch(q)
+            if q[0] is not None:
+                done.append(q[0])
+            q = q[1:] + [None]
+        self._q = []
+        return done
+
+    # ---- steady state over prebuilt batches (measurement, or a producer that stays ahead of the ring) ----
+    def ring(self, batches):
+        """Adopt n >= 5 prebuilt RaggedBatch objects (tables on the device, ``masks`` set) as a ring: step k runs
+        R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) on slots k % n .. (k+4) % n."""
+        self._ring = list(batches)
+        if len(self._ring) < self.DEPTH + 1:
+            raise ValueError("RaggedMaskChainStream.ring: at least 5 batches")
+        self.k = 0
+
+    def prime(self):
+        """Run V..F of the first four ring slots serially, so that step 0 finds what it expects."""
+        r = self._ring
+        for j, stages in ((0, "VLPF"), (1, "VLP"), (2, "VL"), (3, "V")):
+            for s in stages:
+                ragged_chain_launch(**{s: r[j]}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+
+    def _step(self, k):
+        r, n = self._ring, len(self._ring)
+        self._launch([r[(k + i) % n] for i in range(self.DEPTH + 1)])
+
+    def run(self, n_steps: int, unroll: int = 0):
+        """n_steps launches over the ring; unroll > 0: replayed as HIP graphs of ``unroll`` steps (one host call each)."""
+        n = len(self._ring)
+        if unroll > 0:
+            unroll = n * max(1, unroll // n)            # a graph covers whole turns of the ring
+            while n_steps >= unroll:
+                key = (self.k % n, unroll)
+                if key not in self._graphs:
+                    self._graphs[key] = capture_steps(self._step, self.k, unroll, self._ring[0]._dev)
+                self._graphs[key].replay()
+                self.k += unroll
+                n_steps -= unroll
+        for _ in range(n_steps):
+            self._step(self.k)
+            self.k += 1
+
+    def drain_ring(self):
+        """Finish the four batches in flight behind the last step, serially (their outputs then equal the stream's)."""
+        r, n, k = self._ring, len(self._ring), self.k
+        for j, stages in ((k, "R"), (k + 1, "FR"), (k + 2, "PFR"), (k + 3, "LPFR")):
+            for s in stages:
+                ragged_chain_launch(**{s: r[j % n]}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+        self.k += self.DEPTH
+
+
+def capture_steps(step_fn, k0: int, n: int, dev: torch.device):
+    """Capture step_fn(k0) .. step_fn(k0 + n - 1) (launches on the current stream, static buffers) as one HIP graph."""
+    g = torch.cuda.CUDAGraph()
+    main = torch.cuda.Stream(device=dev)
+    main.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(main):
+        with torch.cuda.graph(g, stream=main):
+            for u in range(n):
+                step_fn(k0 + u)
+    torch.cuda.current_stream().wait_stream(main)
+    return g

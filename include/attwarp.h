@@ -278,7 +278,7 @@ ATTWARP_API int attwarp_attn_reduce_and_maps(int attn_dtype, const void* rows, i
  * attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8, identity) /
  * attwarp_remap_bilinear(U8, HWC, CV2) compute, bit for bit.  ATTWARP_E_UNSUPPORTED when one of the stages would not
  * run on its staged kernel for this shape (rows wider than 4096 bytes, W not a multiple of 4, W or H equal to g, ...):
- * use the separate entry points then. */
+ * use the separate entry points, or attwarp_mask_chain_ragged (below: any width), then. */
 ATTWARP_API int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int B, int C, int H, int W, int H_out, int W_out,
                             const float* map_x, const float* map_y,
                             const void* sums_in, float* map_x_next, float* map_y_next,
@@ -287,6 +287,73 @@ ATTWARP_API int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int
                             const int32_t* bounds_y, const int32_t* kk_y, int ksize_y, uint8_t* mota_out,
                             const float* masks, int g, int kernel_size, float enhance_coe, float* rev_out,
                             void* stream);
+
+/* ---- the same chain for batches of DIFFERENTLY sized images: what AGW/main_batched.py:243-287 actually holds (`b_images[j]`
+ * are PIL images at their native sizes; blend_mask up-samples the mask to `image.size`, llava.py:253; save_warped_image warps
+ * at that size to width x height = 500 x 500, new_method.py:415-422,478-488).  Output is dense: [B,H_out,W_out,C].
+ *
+ * A batch is described by a TABLE the host builds once per batch and copies to the device unchanged (it is position
+ * independent):
+ *   1. fill attwarp_ragged_image[B] (HOST array of DEVICE pointers): the image, its size, and Pillow's 8-bit LANCZOS
+ *      coefficient tables for g -> W (ksize_x <= 8 columns) and g -> H (exactly 8 columns, zero padded) --
+ *      attwarp_pil_coeffs_8bpc computes them on the host, callers cache them per distinct size;
+ *   2. attwarp_ragged_table_bytes(...) -> size; attwarp_ragged_plan(...) writes the table into HOST memory: an
+ *      attwarp_ragged_header (public, below: buffer sizes the caller must provide) followed by per-image records, numpy's
+ *      pairwise-summation plans of the distinct widths / heights and the block maps of the stages whose block count
+ *      depends on the image;
+ *   3. copy table_bytes to the device (any 8-byte aligned address);
+ *   4. attwarp_mask_chain_ragged(...) with the host AND the device copy of each stage's table.
+ * Limits (ATTWARP_E_UNSUPPORTED from attwarp_ragged_plan otherwise; use the per-image entry points then): rows of 4 ..
+ * 4096 bytes on both sides (W*C, W_out*C), H, W > g (the mask is up-sampled on both axes), max(H,W) <= 8192, g <= 32,
+ * B <= 65535.  Any alignment: 683 x 3-byte rows are served by the same staged kernels as 684 x 3. */
+#define ATTWARP_RAGGED_MAX_LEAVES 64
+enum { ATTWARP_PIL_LANCZOS = 0, ATTWARP_PIL_BICUBIC = 1 };
+typedef struct attwarp_ragged_image {
+  const uint8_t* image;                            /* device: [H,W,C] uint8 interleaved, any byte address */
+  const int32_t* bounds_x; const int32_t* kk_x;    /* device: Pillow tables g -> W: int32 [W,2], int32 [W,ksize_x] */
+  const int32_t* bounds_y; const int32_t* kk_y;    /* device: g -> H: int32 [H,2], int32 [H,8] (zero padded to 8 columns) */
+  int32_t H, W, ksize_x, reserved;
+} attwarp_ragged_image;
+typedef struct attwarp_ragged_header {             /* first bytes of a table written by attwarp_ragged_plan */
+  uint32_t magic;
+  int32_t B, C, g, H_out, W_out;
+  int32_t nL, nP, nR, nplans;                      /* blocks of the up-sampling, marginals and resample stages; distinct plans */
+  int32_t rows_per_block, blocks_per_image, kd, max_hw;
+  uint64_t table_bytes;                            /* size of the table (copy this many bytes to the device) */
+  uint64_t mota_bytes;                             /* the batch's up-sampled masks, packed: uint8 buffer of this size */
+  uint64_t sums_bytes;                             /* the batch's axis-sum workspace (float64) */
+  uint64_t lds_bytes;
+  uint64_t off_images, off_plans, off_lmap, off_pmap;
+} attwarp_ragged_header;
+
+/* HOST: Pillow's ImagingResample coefficient tables for an 8-bit image (precompute_coeffs + normalize_coeffs_8bpc,
+ * libImaging/Resample.c; 22-bit fixed point) for resizing in_size -> out_size with `filter`.  bounds: int32 [out_size,2]
+ * = (first tap, tap count); kk: int32 [out_size,kk_cols], zero padded.  Returns the tap-count bound ksize (<= kk_cols),
+ * 1 with identity tables when in_size == out_size (Pillow skips that pass), or a negative error code. */
+ATTWARP_API int attwarp_pil_coeffs_8bpc(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk, int kk_cols);
+
+/* HOST: size of / contents of the table of one batch (see above).  0 / a negative code when the batch does not run on
+ * the ragged kernel (attwarp_last_error() says which image and why). */
+ATTWARP_API size_t attwarp_ragged_table_bytes(const attwarp_ragged_image* images, int B, int C, int g, int H_out, int W_out);
+ATTWARP_API int attwarp_ragged_plan(const attwarp_ragged_image* images, int B, int C, int g, int H_out, int W_out, void* table,
+                        size_t table_bytes);
+
+/* One launch running up to five stages, each on ITS OWN batch (as attwarp_mask_chain_step; a stage whose host table --
+ * V: whose `masks` -- is NULL is skipped, so one batch alone is five calls with one stage each):
+ *   R(k)    r_*: images of the table + map_x [B,W_out], map_y [B,H_out]          -> out [B,H_out,W_out,C]   (mode cv2)
+ *   F(k+1)  f_*: sums_in (sums_bytes of that table, written by P)               -> map_x_next, map_y_next
+ *   P(k+2)  p_*: mota_in (mota_bytes of that table, written by L)               -> sums_out
+ *   L(k+3)  l_*: rev_in [B,g,g] float32 (written by V) + the images' Pillow tables -> mota_out
+ *   V(k+4)  masks [B_masks,g,g] float32                                          -> rev_out
+ * Every stage computes what attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8,
+ * identity) / attwarp_remap_bilinear(U8, HWC, CV2) compute on that image alone, bit for bit.  The batches of one launch
+ * share C, g and the output size; their B and image sizes are free. */
+ATTWARP_API int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, uint8_t* out, const float* map_x, const float* map_y,
+                              const void* f_host, const void* f_dev, const void* sums_in, float* map_x_next, float* map_y_next,
+                              const void* p_host, const void* p_dev, const uint8_t* mota_in, void* sums_out,
+                              const void* l_host, const void* l_dev, const float* rev_in, uint8_t* mota_out,
+                              const float* masks, int B_masks, int g, int kernel_size, float enhance_coe, float* rev_out,
+                              void* stream);
 
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.

@@ -2721,6 +2721,182 @@ def test_mask_chain_two_batches_per_launch(dev):
         pipeline.pair_slots(list(imgs[:3]))                        # odd
 
 
+# =============================== unaligned rows and the ragged main_batched chain (round 5) ==============================
+UNALIGNED_SHAPES = [(40, 683, 33, 500, 3), (37, 333, 29, 333, 3), (26, 1023, 31, 1023, 3), (30, 501, 28, 501, 3),
+                    (33, 47, 40, 31, 1), (31, 29, 31, 29, 2), (28, 1365, 17, 1365, 3), (25, 4093, 9, 4095, 1), (64, 66, 50, 333, 4)]
+
+
+@pytest.mark.parametrize("shape", UNALIGNED_SHAPES)
+@pytest.mark.parametrize("kind", ["cdf", "wild"])
+def test_remap_uint8_unaligned_rows_stay_on_the_staged_kernel(dev, shape, kind):
+    """uint8 images whose rows are not a multiple of 4 bytes (683 x 3: the portrait TextVQA case) run on
+    the integer cv2 kernel's unaligned form, not on the gather kernel: `remap_variant=3` (tuning flavour) REFUSES a request
+    that would fall back, so a pass here proves which kernel ran.  Interleaved and planar, views that start at an odd byte,
+    every prefetch depth: bit-exact against the oracle and the gather kernel."""
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C = shape
+    rng = np.random.default_rng(H * 17 + W + Wo)
+    B = 3
+    mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+    img = rng.integers(0, 256, (B, H, W, C), dtype=np.uint8)
+    ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], "cv2") for b in range(B)])
+    ti, tx, ty = T(img, dev), T(mx, dev), T(my, dev)
+    tc = T(img.transpose(0, 3, 1, 2), dev)
+    with _lib.debug_override(remap_variant=3):
+        hwc = N(cu.remap_separable(ti, tx, ty, mode="cv2", channels_last=True))
+        chw = N(cu.remap_separable(tc, tx, ty, mode="cv2"))
+    assert np.array_equal(hwc, ref) and np.array_equal(chw.transpose(0, 2, 3, 1), ref)
+    with _lib.debug_override(remap_variant=1):
+        assert np.array_equal(N(cu.remap_separable(ti, tx, ty, mode="cv2", channels_last=True)), ref)
+    for ahead in (1, 2, 4):
+        for rows in (1, 3, 7, 64):
+            with _lib.debug_override(remap_variant=3, u8_ahead=ahead, remap_rows=rows):
+                assert np.array_equal(N(cu.remap_separable(ti, tx, ty, mode="cv2", channels_last=True)), ref), (ahead, rows)
+    # a view that starts at an odd byte of its allocation, written into a destination that does too
+    flat = torch.zeros(img.size + 7, device=dev, dtype=torch.uint8)
+    flat[3:3 + img.size] = ti.reshape(-1)
+    src = flat[3:3 + img.size].view(B, H, W, C)
+    dflat = torch.full((ref.size + 9,), 0xEE, device=dev, dtype=torch.uint8)
+    dst = dflat[5:5 + ref.size].view(B, Ho, Wo, C)
+    with _lib.debug_override(remap_variant=3):
+        cu.remap_separable(src, tx, ty, mode="cv2", channels_last=True, out=dst)
+    assert np.array_equal(N(dst), ref)
+    assert bool((dflat[:5] == 0xEE).all()) and bool((dflat[5 + ref.size:] == 0xEE).all())       # nothing written outside
+
+
+@pytest.mark.parametrize("hw", [(64, 683), (70, 333), (129, 1023), (501, 501), (1024, 683), (90, 130), (33, 26)])
+def test_mask_upsample_and_marginals_unaligned_widths(dev, hw):
+    """The LANCZOS up-sampling of the 24 x 24 mask to a width that is not a multiple of 4, and the float64 marginals of
+    that uint8 mask, on their staged kernels' unaligned forms (column-strip kernel / byte-packed profile kernel): the mask
+    bit-exact against Pillow's arithmetic (the oracle), the maps bit-exact against numpy's summation orders, both equal to
+    the generic kernels."""
+    from attwarp_amd import attention_extraction as ae, new_method as nm
+    H, W = hw
+    rng = np.random.default_rng(H * 3 + W)
+    B = 3
+    rev = rng.random((B, 24, 24), dtype=np.float32)
+    mota = ae.upsample_mask_lanczos(T(rev, dev), (W, H))
+    with _lib.debug_override(lanczos_variant=1):
+        mota2 = ae.upsample_mask_lanczos(T(rev, dev), (W, H))
+    assert torch.equal(mota, mota2)
+    for b in range(B):
+        assert np.array_equal(N(mota[b]), O.lanczos_resize_u8(O.mask_to_u8(rev[b]), W, H)), b
+    for tr in ("identity", "sqrt"):
+        mx, my = nm.attention_axis_maps(mota, 500, 470, tr)
+        with _lib.debug_override(profiles_variant=1):
+            gx, gy = nm.attention_axis_maps(mota, 500, 470, tr)
+        assert torch.equal(mx, gx) and torch.equal(my, gy)
+        for b in range(B):
+            omx, omy = O.maps_from_attention(N(mota[b]), 500, 470, tr)
+            assert np.array_equal(N(mx[b]), omx) and np.array_equal(N(my[b]), omy), (tr, b)
+    # a mask that starts at an odd byte
+    flat = torch.zeros(mota.numel() + 5, device=dev, dtype=torch.uint8)
+    flat[1:1 + mota.numel()] = mota.reshape(-1)
+    vx, vy = nm.attention_axis_maps(flat[1:1 + mota.numel()].view(B, H, W), 500, 470, "identity")
+    mx, my = nm.attention_axis_maps(mota, 500, 470, "identity")
+    assert torch.equal(vx, mx) and torch.equal(vy, my)
+
+
+# (W x H as PIL reports them) of a TextVQA-like batch: OpenImages landscape / portrait / square, Flickr-sized, small ones
+TEXTVQA_LIKE = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]
+
+
+def ragged_batch(dev, B, seed, extra=()):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sizes = [TEXTVQA_LIKE[(b + seed) % len(TEXTVQA_LIKE)] for b in range(B)]
+    for i, wh in enumerate(extra):
+        sizes[(3 * i + 1) % B] = wh
+    images = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes]
+    att = torch.rand(B, 24, 24, device=dev, generator=g) ** 3
+    att = att / att.sum((1, 2), keepdim=True)
+    return images, att
+
+
+def test_main_batched_ragged_chain_vs_oracle_every_image(dev):
+    """The contract of AGW/main_batched.py:243-287 as that driver holds it: a batch of 32 images of DIFFERENT sizes
+    (1024 x 768, 683 x 1024, 1024 x 1024, 500 x 375, 333 x 500, 640 x 427, plus odd ones), each with its 24 x 24 attention
+    map, warped to 500 x 500 by five ragged launches (pipeline.warp_from_masks_ragged).  EVERY image against the oracle
+    stage by stage, as test_main_batched_chain_full_size_vs_oracle does for equal sizes: revised mask <= 1 ulp; given it,
+    the up-sampled uint8 mask (Pillow's arithmetic), the float32 maps and the uint8 pixels bit-exact; and equal to the
+    per-image drop-in (pipeline.warp_from_masks on a batch of one)."""
+    import subprocess
+    from attwarp_amd import pipeline
+    from oracle import c_oracle as C
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle")], check=True, capture_output=True)
+    B = 32
+    images, att = ragged_batch(dev, B, 500, extra=[(1365, 31), (25, 300), (1023, 501), (612, 612)])
+    out, rb = pipeline.warp_from_masks_ragged(images, att, (500, 500), return_batch=True)
+    assert rb is not None and tuple(out.shape) == (B, 500, 500, 3)
+    torch.cuda.synchronize()
+    att_h, rev_h, out_h, mx_h, my_h = N(att), N(rb.rev), N(out), N(rb.map_x), N(rb.map_y)
+    flips = 0
+    for b in range(B):
+        H, W = int(images[b].shape[0]), int(images[b].shape[1])
+        orev = O.revise_mask(att_h[b], 3, 10)
+        u = np.abs(rev_h[b].view(np.int32).astype(np.int64) - orev.view(np.int32).astype(np.int64))
+        assert u.max() <= 1, b
+        mota = N(rb.mota_of(b))
+        assert np.array_equal(mota, O.lanczos_resize_u8(O.mask_to_u8(rev_h[b]), W, H)), (b, H, W)
+        omx, omy = O.maps_from_attention(mota, 500, 500, "identity")
+        assert np.array_equal(mx_h[b], omx) and np.array_equal(my_h[b], omy), (b, H, W)
+        assert np.array_equal(out_h[b], C.remap_bilinear_u8(N(images[b]), omx, omy, "cv2")), (b, H, W)
+        one = pipeline.warp_from_masks(images[b][None], att[b:b + 1], (500, 500))
+        assert torch.equal(one[0], out[b]), (b, H, W)
+        d = np.abs(O.mask_to_u8(orev).astype(int) - O.mask_to_u8(rev_h[b]).astype(int))
+        assert d.max() <= 1
+        flips += int((d > 0).sum())
+    assert flips <= 1e-3 * B * 576
+
+
+def test_ragged_stream_equals_serial_launches(dev):
+    """pipeline.RaggedMaskChainStream -- one launch per batch, R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) on five different
+    ragged batches -- over a stream of batches of different compositions AND different batch sizes (shorter and longer than
+    the pipeline): every output equals warp_from_masks_ragged on that batch byte for byte; likewise the ring form, eager and
+    as HIP graphs."""
+    from attwarp_amd import pipeline
+    comps = [(5, 1, [(683, 512)]), (3, 2, []), (8, 3, [(100, 77), (1365, 40)]), (1, 4, []), (6, 5, [(501, 333)]), (4, 6, []), (7, 7, [])]
+    batches = [ragged_batch(dev, B, seed, extra) for (B, seed, extra) in comps]
+    want = [pipeline.warp_from_masks_ragged(i, a, (120, 136)) for (i, a) in batches]
+    for n in (1, 3, 4, 5, 7):
+        st = pipeline.RaggedMaskChainStream(out_size=(120, 136))
+        got = []
+        for (i, a) in batches[:n]:
+            d = st.push(i, a)
+            if d is not None:
+                got.append(d.out)
+        got += [d.out for d in st.flush()]
+        assert len(got) == n and all(torch.equal(g, w) for g, w in zip(got, want)), n
+    # ring form: 6 prebuilt batches, 2 turns; eager and as graphs
+    for unroll in (0, 6):
+        st = pipeline.RaggedMaskChainStream(out_size=(120, 136))
+        ring = []
+        for (i, a) in batches[:6]:
+            rb = pipeline.RaggedBatch(i, (120, 136)); rb.masks = a.float().contiguous()
+            ring.append(rb)
+        st.ring(ring)
+        st.prime()
+        st.run(12, unroll=unroll)
+        st.drain_ring()
+        torch.cuda.synchronize()
+        assert all(torch.equal(rb.out, w) for rb, w in zip(ring, want)), unroll
+
+
+def test_ragged_falls_back_per_image_outside_its_limits(dev):
+    """Images the ragged kernel does not take (rows wider than 4096 bytes, a side <= 24) run through warp_from_masks one by
+    one inside warp_from_masks_ragged; the rest of the batch still runs ragged; results are those of the per-image path."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(77)
+    sizes = [(40, 1500), (64, 100), (24, 90), (90, 77)]
+    images = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (h, w) in sizes]
+    att = torch.rand(4, 24, 24, device=dev, generator=g)
+    out = pipeline.warp_from_masks_ragged(images, att, (60, 72))
+    for b in range(4):
+        assert torch.equal(out[b], pipeline.warp_from_masks(images[b][None], att[b:b + 1], (60, 72))[0]), b
+    with pytest.raises(_lib.AttWarpError):
+        pipeline.RaggedBatch(images, (60, 72))
+
+
 def test_randomised_differential_runs(dev):
     """A short run of the two fuzzers (tests/fuzz/fuzz_remap.py, tests/fuzz/fuzz_stages.py: random shapes, dtypes, layouts, modes,
     hostile values; every stage entry point against the oracle): no mismatch.  The long runs behind DESIGN section 4 are

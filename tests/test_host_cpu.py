@@ -450,3 +450,136 @@ def test_pair_slots_views():
     with pytest.raises(ValueError):
         pipeline.pair_slots(list(r[:3]))
 
+
+
+# ---- the ragged main_batched chain: host side (coefficient helper, batch table, argument validation) ------------------------
+def test_pil_coeffs_helper_matches_oracle_over_many_sizes(lib):
+    """attwarp_pil_coeffs_8bpc (the library's host helper behind _tables.lanczos_tables) against the oracle's restatement of
+    Pillow's precompute_coeffs / normalize_coeffs_8bpc for the sizes a ragged batch brings (every 7th size up to 1400 and the
+    TextVQA-like ones), zero padding to 8 columns included."""
+    from attwarp_amd import _tables
+    sizes = sorted(set(range(25, 1400, 7)) | {333, 375, 427, 500, 501, 640, 683, 768, 1023, 1024, 1365, 2048, 13})
+    for n in sizes:
+        b, k, ks = _tables._lanczos_tables_host(24, n)
+        bo, ko, kso = O.pil_lanczos_coeffs(24, n)
+        assert ks == kso and np.array_equal(b, bo) and np.array_equal(k, ko), n
+    bounds = np.zeros((683, 2), np.int32); kk = np.full((683, 8), -1, np.int32)
+    assert lib.attwarp_pil_coeffs_8bpc(24, 683, 0, bounds.ctypes.data, kk.ctypes.data, 8) == 7
+    bo, ko, _ = O.pil_lanczos_coeffs(24, 683)
+    assert np.array_equal(kk[:, :7], ko) and (kk[:, 7] == 0).all() and np.array_equal(bounds, bo)
+    assert lib.attwarp_pil_coeffs_8bpc(24, 683, 0, bounds.ctypes.data, kk.ctypes.data, 6) == -1      # 7 taps do not fit
+    assert lib.attwarp_pil_coeffs_8bpc(24, 683, 5, bounds.ctypes.data, kk.ctypes.data, 8) == -1      # unknown filter
+    assert lib.attwarp_pil_coeffs_8bpc(24, 683, 0, None, kk.ctypes.data, 8) == -1
+
+
+def _ragged_records(sizes, base=0x10000):
+    from attwarp_amd import _lib
+    rec = (_lib.RaggedImage * len(sizes))()
+    for i, (h, w) in enumerate(sizes):
+        rec[i].image = base + 0x1000000 * i
+        rec[i].bounds_x = rec[i].kk_x = rec[i].bounds_y = rec[i].kk_y = base
+        rec[i].H, rec[i].W, rec[i].ksize_x = h, w, 8
+    return rec
+
+
+def test_ragged_plan_table_layout_without_gpu(lib):
+    """attwarp_ragged_plan writes a position-independent table: header, per-image records, numpy's pairwise plans of the
+    distinct sizes, and the block maps of the up-sampling / marginals stages."""
+    import ctypes
+    from attwarp_amd import _lib, pipeline
+    sizes = [(768, 1024), (1024, 683), (1024, 1024), (375, 500), (500, 333), (427, 640), (1024, 683)]
+    rec = _ragged_records(sizes)
+    B = len(sizes)
+    n = lib.attwarp_ragged_table_bytes(ctypes.byref(rec), B, 3, 24, 500, 500)
+    assert n > 0 and n % 16 == 0
+    buf = np.zeros(n + 64, np.uint8)
+    assert lib.attwarp_ragged_plan(ctypes.byref(rec), B, 3, 24, 500, 500, buf.ctypes.data, n) == 0
+    assert not buf[n:].any()                                       # nothing written behind the table
+    h = _lib.RaggedHeader.from_address(buf.ctypes.data)
+    assert (h.B, h.C, h.g, h.H_out, h.W_out, h.table_bytes) == (B, 3, 24, 500, 500, n)
+    assert h.rows_per_block == 16 and h.blocks_per_image == 32 and h.nR == 32 * B and h.kd == 2 and h.max_hw == 1024
+    img = (pipeline._RaggedImageDev * B).from_address(buf.ctypes.data + h.off_images)
+    plans = {}
+    # plans: same leaves as numpy's recursion (test_oracle_golden pins that recursion against np.sum itself)
+    def leaves(off, m, out):
+        if m <= 128:
+            out.append((off, m)); return
+        n2 = m // 2; n2 -= n2 % 8
+        leaves(off, n2, out); leaves(off + n2, m - n2, out)
+    plan_words = 4 + 64 + 64 + 32
+    praw = np.frombuffer(buf, np.int32, h.nplans * plan_words, h.off_plans).reshape(h.nplans, plan_words)
+    distinct = sorted({s for hw in sizes for s in hw})
+    assert h.nplans == len(distinct)
+    mota_end = sums_end = 0
+    nL = nP = 0
+    for b, (H, W) in enumerate(sizes):
+        r = img[b]
+        assert (r.H, r.W, r.image) == (H, W, rec[b].image)
+        pw, ph = praw[r.plan_w], praw[r.plan_h]
+        assert pw[3] == W and ph[3] == H
+        for p, m in ((pw, W), (ph, H)):
+            want = []; leaves(0, m, want)
+            assert p[0] == len(want) and [(int(p[4 + i]), int(p[68 + i])) for i in range(p[0])] == want
+        assert r.ki == -(-(-(-W * 3 // 4)) // 256)
+        assert r.mota_off >= mota_end and r.mota_off % 256 == 0
+        mota_end = r.mota_off + H * W
+        assert r.sums_off == sums_end
+        sums_end += W + H * int(pw[0])
+        assert sums_end * 8 - r.sums_off * 8 == lib.attwarp_axis_sums_workspace_bytes(1, H, W)
+        nstrips = -(-W // 256)
+        assert r.l_nchunks * r.l_rows_per_chunk >= H > (r.l_nchunks - 1) * r.l_rows_per_chunk
+        nL += nstrips * r.l_nchunks; nP += int(pw[0])
+    assert h.mota_bytes >= mota_end and h.sums_bytes == sums_end * 8 and (h.nL, h.nP) == (nL, nP)
+    lmap = np.frombuffer(buf, np.uint32, h.nL, h.off_lmap); pmap = np.frombuffer(buf, np.uint32, h.nP, h.off_pmap)
+    for m, per in ((lmap, [-(-w // 256) * img[b].l_nchunks for b, (_, w) in enumerate(sizes)]),
+                   (pmap, [int(praw[img[b].plan_w][0]) for b in range(B)])):
+        want = [(b, s) for b in range(B) for s in range(per[b])]
+        assert [(int(e & 0xffff), int(e >> 16)) for e in m] == want
+    # limits
+    def rc(sz, C=3, Ho=500, Wo=500, g=24):
+        r = _ragged_records(sz)
+        return lib.attwarp_ragged_plan(ctypes.byref(r), len(sz), C, g, Ho, Wo, buf.ctypes.data, buf.size)
+    assert rc([(100, 1366)]) == -2 and b"4096" in lib.attwarp_last_error()       # rows of 4098 bytes
+    assert rc([(100, 1365)]) == 0
+    assert rc([(24, 100)]) == -2 and rc([(100, 24)]) == -2                        # no up-sampling on an axis
+    assert rc([(9000, 100)]) == -2
+    assert rc([(100, 100)], Wo=1400) == -2
+    assert rc([(100, 100)], C=5) == -2 and rc([(100, 100)], g=40) == -2
+    r = _ragged_records([(100, 100)]); r[0].kk_y = None
+    assert lib.attwarp_ragged_plan(ctypes.byref(r), 1, 3, 24, 500, 500, buf.ctypes.data, buf.size) == -1
+    assert lib.attwarp_ragged_plan(ctypes.byref(rec), B, 3, 24, 500, 500, buf.ctypes.data, n - 16) == -1
+    assert lib.attwarp_ragged_table_bytes(ctypes.byref(_ragged_records([(100, 1366)])), 1, 3, 24, 500, 500) == 0
+    assert pipeline.ragged_eligible(100, 1365, 3) and not pipeline.ragged_eligible(100, 1366, 3)
+    assert not pipeline.ragged_eligible(24, 100, 3) and not pipeline.ragged_eligible(100, 9000, 1)
+
+
+def test_mask_chain_ragged_abi_validation_without_gpu(lib):
+    """attwarp_mask_chain_ragged validates before it enqueues (no GPU here: every call must fail in validation)."""
+    import ctypes
+    rec = _ragged_records([(64, 100), (90, 77)])
+    n = lib.attwarp_ragged_table_bytes(ctypes.byref(rec), 2, 3, 24, 80, 88)
+    t1 = np.zeros(n, np.uint8); t2 = np.zeros(n, np.uint8)
+    assert lib.attwarp_ragged_plan(ctypes.byref(rec), 2, 3, 24, 80, 88, t1.ctypes.data, n) == 0
+    assert lib.attwarp_ragged_plan(ctypes.byref(rec), 2, 3, 24, 96, 88, t2.ctypes.data, n) == 0      # another output size
+    P = [ctypes.c_void_p(0x100000 + 4096 * i) for i in range(16)]
+    names = ["r_host", "r_dev", "out", "map_x", "map_y", "f_host", "f_dev", "sums_in", "map_x_next", "map_y_next", "p_host", "p_dev",
+             "mota_in", "sums_out", "l_host", "l_dev", "rev_in", "mota_out", "masks", "B_masks", "g", "kernel_size", "enhance_coe",
+             "rev_out", "stream"]
+    T = ctypes.c_void_p(t1.ctypes.data)
+    ok = dict(r_host=T, r_dev=P[0], out=P[1], map_x=P[2], map_y=P[3], f_host=T, f_dev=P[0], sums_in=P[4], map_x_next=P[5],
+              map_y_next=P[6], p_host=T, p_dev=P[0], mota_in=P[7], sums_out=P[8], l_host=T, l_dev=P[0], rev_in=P[9], mota_out=P[10],
+              masks=P[11], B_masks=2, g=24, kernel_size=3, enhance_coe=10.0, rev_out=P[12], stream=None)
+    f = lib.attwarp_mask_chain_ragged
+    def call(**kw):
+        a = dict(ok, **kw)
+        return f(*[a[k] for k in names])
+    none = dict(r_host=None, f_host=None, p_host=None, l_host=None, masks=None)
+    assert call(**none) == -1 and b"no stage" in lib.attwarp_last_error()
+    assert call(r_dev=None) == -1 and call(out=None) == -1 and call(sums_in=None) == -1 and call(mota_in=None) == -1
+    assert call(rev_in=None) == -1 and call(rev_out=None) == -1
+    assert call(map_x_next=P[2]) == -1 and b"alias" in lib.attwarp_last_error()
+    assert call(sums_out=P[4]) == -1 and call(mota_out=P[7]) == -1 and call(rev_out=P[9]) == -1
+    assert call(kernel_size=4) == -1 and call(g=16) == -1 and call(B_masks=0) == -1
+    assert call(f_host=ctypes.c_void_p(t2.ctypes.data)) == -1 and b"share" in lib.attwarp_last_error()
+    junk = np.zeros(n, np.uint8)
+    assert call(p_host=ctypes.c_void_p(junk.ctypes.data)) == -1 and b"attwarp_ragged_plan" in lib.attwarp_last_error()
