@@ -20,6 +20,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib, _tables
@@ -970,6 +971,41 @@ def ragged_eligible(h: int, w: int, c: int, g: int = GRID) -> bool:
     return 4 <= w * c <= RAGGED_MAX_ROW_BYTES and h > g and w > g and max(h, w) <= RAGGED_MAX_SIDE and c <= 4
 
 
+_RAGGED_IMAGE_DTYPE = np.dtype([("image", "<u8"), ("bounds_x", "<u8"), ("kk_x", "<u8"), ("bounds_y", "<u8"), ("kk_y", "<u8"),
+                                ("H", "<i4"), ("W", "<i4"), ("ksize_x", "<i4"), ("reserved", "<i4")])      # attwarp_ragged_image
+_AXIS_TABLES: dict = {}
+_STAGING: list = []                   # pinned staging buffers: [tensor, event of the last copy out of it]
+
+
+def _axis_tables(g: int, n: int, dev: torch.device):
+    """(bounds pointer, coefficient pointer, ksize) of Pillow's g -> n LANCZOS tables on `dev` (cached per size)."""
+    key = (dev.index, g, n)
+    t = _AXIS_TABLES.get(key)
+    if t is None:
+        b, k, ks = _tables.lanczos_tables(g, n, dev)
+        t = _AXIS_TABLES[key] = (b.data_ptr(), k.data_ptr(), ks, b, k)
+    return t
+
+
+def _upload(host: "np.ndarray", dst: torch.Tensor):
+    """host bytes -> dst (device uint8), asynchronously on the current stream through a pooled pinned buffer."""
+    n = host.size
+    slot = None
+    for s in _STAGING:
+        if s[0].numel() >= n and s[1].query():
+            slot = s
+            break
+    if slot is None:
+        slot = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
+        _STAGING.append(slot)
+        if len(_STAGING) > 64:            # (only if nothing ever completes: keep the pool bounded)
+            torch.cuda.synchronize()
+            del _STAGING[:-1]
+    slot[0][:n].numpy()[:] = host
+    dst.copy_(slot[0][:n], non_blocking=True)
+    slot[1].record()
+
+
 class RaggedBatch:
     """One batch of differently sized uint8 images [H_i,W_i,C] on the GPU, planned for ``attwarp_mask_chain_ragged``:
     the table (host copy in pinned memory + device copy), and the batch's own intermediates and outputs --
@@ -991,26 +1027,28 @@ class RaggedBatch:
         self.Ho, self.Wo = int(out_size[0]), int(out_size[1])
         self._dev = dev
         lib = _lib.load()
-        rec = (_lib.RaggedImage * self.B)()
-        self._tables = []                   # (keeps the cached coefficient tensors referenced)
-        for r, im in zip(rec, images):
-            H, W = int(im.shape[0]), int(im.shape[1])
-            bx, kx, ksx = _tables.lanczos_tables(self.g, W, dev)
-            by, ky, ksy = _tables.lanczos_tables(self.g, H, dev)
-            if ksy != 8:
-                raise _lib.AttWarpError(f"RaggedBatch: image of {H} x {W}: the vertical mask up-sampling needs {ksy} taps (> 8)")
-            self._tables.append((bx, kx, by, ky))
-            r.image, r.H, r.W = im.data_ptr(), H, W
-            r.bounds_x, r.kk_x, r.ksize_x = bx.data_ptr(), kx.data_ptr(), ksx
-            r.bounds_y, r.kk_y = by.data_ptr(), ky.data_ptr()
-        nbytes = lib.attwarp_ragged_table_bytes(ctypes.byref(rec), self.B, C, self.g, self.Ho, self.Wo)
+        # the caller-side records (attwarp_ragged_image) as one structured array: pointers and sizes column by column
+        rec = np.zeros(self.B, dtype=_RAGGED_IMAGE_DTYPE)
+        rec["image"] = [im.data_ptr() for im in images]
+        rec["H"] = hs = [int(im.shape[0]) for im in images]
+        rec["W"] = ws = [int(im.shape[1]) for im in images]
+        tx = [_axis_tables(self.g, w, dev) for w in ws]
+        ty = [_axis_tables(self.g, h, dev) for h in hs]
+        if any(t[2] != 8 for t in ty):
+            raise _lib.AttWarpError("RaggedBatch: an image is too low for the 8-tap vertical mask up-sampling (H < 24)")
+        rec["bounds_x"] = [t[0] for t in tx]; rec["kk_x"] = [t[1] for t in tx]; rec["ksize_x"] = [t[2] for t in tx]
+        rec["bounds_y"] = [t[0] for t in ty]; rec["kk_y"] = [t[1] for t in ty]
+        rp = ctypes.c_void_p(rec.ctypes.data)
+        nbytes = lib.attwarp_ragged_table_bytes(rp, self.B, C, self.g, self.Ho, self.Wo)
         if nbytes == 0:
             raise _lib.AttWarpError("attwarp_ragged_table_bytes: " + lib.attwarp_last_error().decode("utf-8", "replace"))
-        self.table_host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        call("attwarp_ragged_plan", ctypes.byref(rec), self.B, C, self.g, self.Ho, self.Wo, self.table_host.data_ptr(), nbytes)
-        self.header = _lib.RaggedHeader.from_address(self.table_host.data_ptr())
+        # host copy: a plain buffer this batch keeps (the entry point reads the header from it at every launch); the upload
+        # goes through a pooled pinned staging buffer (allocating pinned memory per batch costs more than the five launches)
+        self.table_host = np.empty(nbytes, dtype=np.uint8)
+        call("attwarp_ragged_plan", rp, self.B, C, self.g, self.Ho, self.Wo, self.table_host.ctypes.data, nbytes)
+        self.header = _lib.RaggedHeader.from_address(self.table_host.ctypes.data)
         self.table_dev = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-        self.table_dev.copy_(self.table_host, non_blocking=True)
+        _upload(self.table_host, self.table_dev)
         h = self.header
         self.rev = torch.empty(self.B, self.g, self.g, device=dev, dtype=torch.float32)
         self.mota = torch.empty(int(h.mota_bytes), device=dev, dtype=torch.uint8)
@@ -1033,7 +1071,7 @@ class RaggedBatch:
     def mota_of(self, b: int) -> torch.Tensor:
         """The up-sampled uint8 mask [H_b,W_b] of image b (what blend_mask returns as ``mota_mask``, llava.py:253)."""
         import ctypes
-        rec = (_RaggedImageDev * self.B).from_address(self.table_host.data_ptr() + int(self.header.off_images))
+        rec = (_RaggedImageDev * self.B).from_address(self.table_host.ctypes.data + int(self.header.off_images))
         H, W = int(self.images[b].shape[0]), int(self.images[b].shape[1])
         off = int(rec[b].mota_off)
         return self.mota[off:off + H * W].view(H, W)
@@ -1048,6 +1086,35 @@ class _RaggedImageDev(__import__("ctypes").Structure):
                 ("mota_off", _c.c_int64), ("sums_off", _c.c_int64)]
 
 
+def upload_images(images, device=None):
+    """A batch of host images as the reference's driver holds them (`b_images`: PIL images or uint8 [H,W,C] arrays of
+    different sizes, main_batched.py:246) -> list of uint8 [H_i,W_i,C] GPU tensors: packed back to back into ONE staging
+    buffer and copied with ONE host-to-device transfer (the ragged kernels take images at any byte address, so the views
+    need no padding).  PIL images are taken as RGB; the warp does not depend on the channel order."""
+    dev = torch.device(device) if device is not None else _lib.default_device()
+    arrs = []
+    for im in images:
+        a = np.asarray(im.convert("RGB")) if hasattr(im, "convert") else np.asarray(im)
+        if a.dtype != np.uint8 or a.ndim not in (2, 3):
+            raise TypeError("upload_images: uint8 [H,W] / [H,W,C] arrays or PIL images expected")
+        arrs.append(a[:, :, None] if a.ndim == 2 else a)
+    sizes = [a.size for a in arrs]
+    total = int(sum(sizes))
+    host = np.empty(total, dtype=np.uint8)
+    off = 0
+    for a, n in zip(arrs, sizes):
+        host[off:off + n] = a.reshape(-1)
+        off += n
+    flat = torch.empty(total, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _upload(host, flat)
+    out, off = [], 0
+    for a, n in zip(arrs, sizes):
+        out.append(flat[off:off + n].view(*a.shape))
+        off += n
+    return out
+
+
 def ragged_chain_launch(R: Optional[RaggedBatch] = None, F: Optional[RaggedBatch] = None, P: Optional[RaggedBatch] = None,
                         L: Optional[RaggedBatch] = None, V: Optional[RaggedBatch] = None, enhance_coe=10, kernel_size=3):
     """ONE launch of ``attwarp_mask_chain_ragged``: the resample of batch R, the map construction of F, the marginals of P,
@@ -1056,7 +1123,7 @@ def ragged_chain_launch(R: Optional[RaggedBatch] = None, F: Optional[RaggedBatch
     some = next(b for b in (R, F, P, L, V) if b is not None)
     dev = some._dev
     def tab(b):
-        return (None, None) if b is None else (b.table_host.data_ptr(), ptr(b.table_dev))
+        return (None, None) if b is None else (b.table_host.ctypes.data, ptr(b.table_dev))
     if V is not None and (V.masks is None or V.masks.dtype != torch.float32 or tuple(V.masks.shape) != (V.B, V.g, V.g)
                           or not V.masks.is_contiguous() or V.masks.device != dev):
         raise ValueError("ragged_chain_launch: V.masks must be a dense float32 [B,g,g] tensor on the batch's device")

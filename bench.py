@@ -579,6 +579,7 @@ def leg_main_batched(dev, torch, pipeline, K):
     batches, graph replay), both over a ring of independent batches of >= 2 GiB (every step streams from HBM), exactly K
     steps in the timed region.  Chain-level algorithmic bytes per image: S*S mask written + S*S mask read by
     the marginals + 3*S*S image read + 3*So*So written."""
+    K = max(K + (K & 1), 10)        # the stream needs K >= its pipeline depth (two batches per launch: K / 2 >= depth)
     out = {"workload": "uint8 images [B,S,S,3] + attention maps [B,24,24] -> main_batched chain -> [B,500,500,3] uint8, mode=cv2, "
                        "transform=identity (main_batched.py:280-287)", "unit": "images/s", "steps": K, "cases": []}
     for (B, S, So) in ((32, 336, 500), (64, 336, 500), (256, 336, 500), (32, 1024, 500), (64, 1024, 500), (256, 1024, 500)):
@@ -642,6 +643,110 @@ def leg_main_batched(dev, torch, pipeline, K):
     out["value"] = ref["stream"]["images_per_s"]
     out["value_is"] = ("the stream step at the reference's own scale: B=32, 336 -> 500, one batch per launch "
                        "(`two_batches_per_launch` beside it)")
+    return out
+
+
+TEXTVQA_LIKE_WH = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]      # W x H as PIL reports them
+
+
+def leg_main_batched_ragged(dev, torch, pipeline, K):
+    """The same chain on what the reference's driver actually holds (AGW/main_batched.py:243-287): batches of DIFFERENTLY
+    sized images (`b_images[j]` at native size; a TextVQA-like mix of 1024 x 768, 683 x 1024, 1024 x 1024, 500 x 375,
+    333 x 500, 640 x 427), every mask up-sampled to its image's own size, dense [B,500,500,3] output.  Per case:
+      `per_image`  the loop a driver had to write before: pipeline.warp_from_masks on one image at a time (5 launches each);
+      `serial`     pipeline.warp_from_masks_ragged: table build + upload + five ragged launches per batch;
+      `stream`     pipeline.RaggedMaskChainStream over a ring of prebuilt batches: ONE launch per batch (R(k) | F(k+1) |
+                   P(k+2) | L(k+3) | V(k+4)), eager and replayed as HIP graphs;
+      `equal_size_stream`  pipeline.MaskChainStream on B images of S x S with S*S = the mix's mean pixel count (the round-4
+                   one-launch step for equally sized images): the bar is ragged <= 1.3 x that.
+    Rings of >= 2 GiB of independent batches, exactly K batches through every stage in each timed region; chain-level
+    algorithmic bytes as `also_main_batched`."""
+    K = max(K + (K & 1), 10)
+    So = 500
+    out = {"workload": "uint8 images of different sizes [H_i,W_i,3] + attention maps [B,24,24] -> main_batched chain -> "
+                       "[B,500,500,3] uint8, mode=cv2, transform=identity", "unit": "images/s", "steps": K,
+           "sizes_WxH": TEXTVQA_LIKE_WH, "cases": []}
+    for B in (32, 256):
+        sizes = [TEXTVQA_LIKE_WH[b % len(TEXTVQA_LIKE_WH)] for b in range(B)]
+        px = sum(w * h for (w, h) in sizes)
+        slot = 3 * px + 3 * B * So * So
+        n = max(6, min(40, -(-(2 << 30) // slot)))
+        g = torch.Generator(device=dev).manual_seed(99 + B)
+        ring_imgs = [[torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes]
+                     for _ in range(n)]
+        masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+        bytes_batch = 5 * px + 3 * B * So * So
+        # the drop-in for one batch at a time (table build + upload + five launches)
+        for i in range(2):
+            pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            o = pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
+        torch.cuda.synchronize()
+        t_serial = (time.perf_counter() - t0) / K
+        want0 = o if (K - 1) % n == 0 else pipeline.warp_from_masks_ragged(ring_imgs[0], masks[0], (So, So))
+        # what a driver had to do without it: image by image (timed on a bounded sample of batches)
+        kk = 2 if B > 64 else 4
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(kk):
+            for b in range(B):
+                o = pipeline.warp_from_masks(ring_imgs[i % n][b][None], masks[i % n][b:b + 1], (So, So))
+        torch.cuda.synchronize()
+        t_per_image = (time.perf_counter() - t0) / kk
+        # stream over prebuilt batches
+        ring = []
+        for i in range(n):
+            rb = pipeline.RaggedBatch(ring_imgs[i], (So, So)); rb.masks = masks[i]
+            ring.append(rb)
+        st = pipeline.RaggedMaskChainStream(out_size=(So, So))
+        st.ring(ring)
+        res = {}
+        for name, unroll in (("eager", 0), ("graphs", n)):
+            def run():
+                st.k = 0
+                st.prime(); st.run(K - st.DEPTH, unroll=unroll); st.drain_ring()      # exactly K batches through every stage
+            run(); run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / K
+            res[name] = {"ms_per_batch": round(t * 1e3, 4), "images_per_s": round(B / t, 1),
+                         "step_frac_of_hbm_peak": round(bytes_batch / t / 1e9 / HBM_PEAK_GBS, 4)}
+        same = bool(torch.equal(ring[0].out, want0)) and all(
+            bool(torch.equal(ring[i].out, pipeline.warp_from_masks_ragged(ring_imgs[i], masks[i], (So, So)))) for i in range(1, min(n, 4)))
+        del ring, st
+        # the equal-size stream step at the same total pixels
+        S = int(round((px / B) ** 0.5 / 4)) * 4
+        ne = n + (n & 1)
+        images_e = list(torch.randint(0, 256, (ne, B, S, S, 3), device=dev, dtype=torch.uint8, generator=g))
+        masks_e = list(torch.rand(ne, B, 24, 24, device=dev, generator=g))
+        mc = pipeline.MaskChainStream(images_e, masks_e, (So, So))
+        def run_e():
+            mc.reset(); mc.prime(); mc.run(K - mc.depth); mc.drain()
+        run_e(); run_e()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_e()
+        torch.cuda.synchronize()
+        t_eq = (time.perf_counter() - t0) / K
+        best = min(res["eager"]["ms_per_batch"], res["graphs"]["ms_per_batch"])
+        out["cases"].append({
+            "B": B, "pixels_per_batch": px, "ring_batches": n, "chain_algorithmic_bytes_per_batch": bytes_batch,
+            "stream": res, "bit_identical_to_serial": same,
+            "serial": {"ms_per_batch": round(t_serial * 1e3, 4), "images_per_s": round(B / t_serial, 1),
+                       "includes": "table build on the host, its upload, buffer allocation, five launches"},
+            "per_image": {"ms_per_batch": round(t_per_image * 1e3, 4), "images_per_s": round(B / t_per_image, 1)},
+            "equal_size_stream": {"S": S, "pattern": mc.pattern, "ms_per_batch": round(t_eq * 1e3, 4),
+                                  "images_per_s": round(B / t_eq, 1)},
+            "ragged_over_equal_size": round(best / (t_eq * 1e3), 3)})
+        del mc, images_e, masks_e, ring_imgs, masks
+        torch.cuda.empty_cache()
+    ref = out["cases"][0]
+    out["value"] = max(ref["stream"]["eager"]["images_per_s"], ref["stream"]["graphs"]["images_per_s"])
+    out["value_is"] = "the ragged stream step at the reference's batch size (B=32), one launch per batch"
     return out
 
 
@@ -807,6 +912,7 @@ LEGS = {
     "336": "BASELINE configs[1] and configs[3]'s per-rank batch as graph-replayed one-launch steps (also, also_336x256)",
     "fp16_attention": "configs[3]'s per-rank batch with float16 attention rows (also_336x256_fp16_attention)",
     "main_batched": "the reference's own uint8 chain (main_batched.py:243-287) as a stream step vs its serial launches (also_main_batched)",
+    "main_batched_ragged": "the same chain on batches of DIFFERENTLY sized images, as that driver holds them: one ragged launch per batch vs the per-image loop and vs the equal-size stream step (also_main_batched_ragged)",
     "pool_input": "configs[2]'s other input form: full-resolution attention [B,1,S,S] -> 24x24 pool -> maps -> warp (also_pool_input)",
     "config5": "configs[4] data flow with a random-weight CLIP ViT-L/14-336 tower, per-leg ms (also_config5)",
 }
@@ -817,7 +923,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["config5", "main_batched"], default="1024")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["config5", "main_batched", "main_batched_ragged"], default="1024")
     ap.add_argument("--mode", choices=["cv2", "exact"], default="cv2", help="resample arithmetic of the main line")
     ap.add_argument("--layout", choices=["hwc", "chw"], default="hwc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -847,7 +953,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no torch import, no GPU call
 
-    if args.workload in ("config5", "main_batched"):
+    if args.workload in ("config5", "main_batched", "main_batched_ragged"):
         import torch
         from attwarp_amd import _lib, pipeline
         if not torch.cuda.is_available():
@@ -856,10 +962,11 @@ def main():
         dev = torch.device("cuda", args.device or 0)
         torch.cuda.set_device(dev)
         res = leg_config5(dev, torch, pipeline, 64, max(args.steps // 4, 3)) if args.workload == "config5" else \
-            leg_main_batched(dev, torch, pipeline, max(args.steps, 48))
+            leg_main_batched(dev, torch, pipeline, max(args.steps, 48)) if args.workload == "main_batched" else \
+            leg_main_batched_ragged(dev, torch, pipeline, max(args.steps, 48))
         print(json.dumps(dict({"metric": "warped images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
-                               "dtype": "u8" if args.workload == "main_batched" else "f16 tower / f32 MarginalNet / u8 warp",
+                               "dtype": "u8" if args.workload.startswith("main_batched") else "f16 tower / f32 MarginalNet / u8 warp",
                                "config": {"workload": res["workload"]}}, **res)), flush=True)
         return
     B, S, cfg_idx = WORKLOADS[args.workload]
@@ -1077,6 +1184,7 @@ def main():
     if world == 1 and args.workload == "1024":
         # (a failure inside one of these legs -- e.g. `transformers` missing for the vision tower -- must not cost the main line)
         for key, leg in (("main_batched", lambda: leg_main_batched(dev, torch, pipeline, n2)),
+                         ("main_batched_ragged", lambda: leg_main_batched_ragged(dev, torch, pipeline, n2)),
                          ("pool_input", lambda: leg_pool_input(dev, torch, pipeline, B, S, args.mode, args.steps)),
                          ("config5", lambda: leg_config5(dev, torch, pipeline, 32, 3))):
             if key in want:

@@ -8,7 +8,8 @@ The reference's Python files are loaded by path with small stub modules for the
 third-party packages that are absent here (cv2, torchvision, llava, ...).  The
 ``cv2.remap`` stub records the float32 maps the reference hands to OpenCV; the
 resample itself is not available (OpenCV is neither vendored nor installed), so
-no golden exists for it -- "parity unpinned" at that boundary.
+no golden exists for it -- "parity unpinned" at that boundary.  ``--with-opencv`` writes that
+golden (remap_cv2.npz) on a machine where the real OpenCV imports.
 
 Only inputs and the reference's outputs are stored (data, never source).
 """
@@ -354,7 +355,44 @@ def make_random_cases(new_method, ckpt, llava):
     print("random_cases.npz", os.path.getsize(os.path.join(OUT, "random_cases.npz")) / 1024, "KiB,", len(names), "cases")
 
 
+def make_opencv_golden():
+    """`--with-opencv`: when the REAL OpenCV is importable (it is not in the build container: no network), record
+    cv2.remap(INTER_LINEAR, BORDER_REPLICATE) / cv2.resize(INTER_LINEAR) outputs on seeded inputs as remap_cv2.npz -- the
+    fixture that pins oracle.remap_bilinear(mode="cv2") and every HIP resample kernel to OpenCV itself on machines without
+    it (tests/test_oracle_golden.py::test_remap_cv2_fixture_if_present, the -m gpu twin).  Needs no reference import."""
+    try:
+        import cv2
+    except ImportError:
+        print("--with-opencv: cv2 is not importable here; nothing written (tests/test_oracle_vs_opencv.py skips the same way)")
+        return
+    if not hasattr(cv2, "getBuildInformation"):
+        print("--with-opencv: `cv2` is a stub, not OpenCV; nothing written")
+        return
+    rng = np.random.default_rng(2024)
+    out, names = {}, []
+    for (H, W, Ho, Wo) in ((48, 64, 52, 72), (336, 336, 500, 500), (100, 683, 90, 500), (33, 47, 40, 31)):
+        for dt in (np.uint8, np.float32, np.float64):
+            for C in (1, 3, 4):
+                img = rng.integers(0, 256, (H, W, C), dtype=np.uint8) if dt == np.uint8 else rng.random((H, W, C)).astype(dt)
+                mx = np.sort(rng.random(Wo).astype(np.float32) * (W + 2) - 1)
+                my = np.sort(rng.random(Ho).astype(np.float32) * (H + 2) - 1)
+                mx[:4] = np.array([0.015625, 0.046875, -7.25, W - 0.015625], np.float32)
+                X, Y = np.meshgrid(mx, my)
+                res = cv2.remap(img if C > 1 else img[:, :, 0], X, Y, interpolation=cv2.INTER_LINEAR, borderMode=cv2.BORDER_REPLICATE)
+                key = f"{H}x{W}x{C}_{Ho}x{Wo}_{np.dtype(dt).name}"
+                out[f"{key}|img"] = img if C > 1 else img[:, :, 0]
+                out[f"{key}|mx"] = mx; out[f"{key}|my"] = my; out[f"{key}|out"] = res
+                names.append(key)
+    out["cases"] = np.array(names)
+    out["opencv_build"] = np.array(f"OpenCV {cv2.__version__}")
+    np.savez_compressed(os.path.join(OUT, "remap_cv2.npz"), **out)
+    print("remap_cv2.npz", os.path.getsize(os.path.join(OUT, "remap_cv2.npz")) / 1024, "KiB,", len(names), "cases,", cv2.__version__)
+
+
 def main():
+    if "--with-opencv" in sys.argv:
+        make_opencv_golden()
+        return
     if "--only-random" in sys.argv:
         _install_stubs()
         torch.set_num_threads(1)

@@ -36,6 +36,14 @@ def N(t):
     return t.detach().cpu().numpy()
 
 
+def for_each(items, fn, workers=None):
+    """fn(item) for every item on a pool of host threads (numpy and the ctypes C oracle release the GIL): the full-size
+    tests check EVERY image of a batch against the oracle, not a sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers or min(16, os.cpu_count() or 1)) as ex:
+        list(ex.map(fn, items))
+
+
 def softmax_rows(rng, shape, peak=None):
     lg = rng.standard_normal(shape).astype(np.float32)
     if peak is not None:
@@ -1384,8 +1392,8 @@ def test_pipeline_masks_chain_main_batched(dev, golden):
 @pytest.mark.parametrize("cfg", [(64, 336, 500), (256, 1024, 500)])
 @pytest.mark.parametrize("form", ["serial", "stream"])
 def test_main_batched_chain_full_size_vs_oracle(dev, cfg, form):
-    """The reference's own chain (AGW/main_batched.py:243-287) at full size -- every image of B=64 @ 336 -> 500, a
-    stratified 33 of B=256 @ 1024 -> 500 -- against the oracle STAGE BY STAGE: the revised mask (<= 1 ulp), the uint8
+    """The reference's own chain (AGW/main_batched.py:243-287) at full size -- EVERY image of B=64 @ 336 -> 500 and of
+    B=256 @ 1024 -> 500 -- against the oracle STAGE BY STAGE: the revised mask (<= 1 ulp), the uint8
     LANCZOS mask given the GPU's revised mask (bit-exact; from the oracle's own revised mask at most a few cells flip by
     1 LSB where the x255 truncation sits on a 1-ulp difference), the float32 maps given the mask (bit-exact), the uint8
     pixels given the maps (bit-exact), for pipeline.warp_from_masks and for the one-launch stream step
@@ -1414,24 +1422,27 @@ def test_main_batched_chain_full_size_vs_oracle(dev, cfg, form):
     mota = ae.upsample_mask_lanczos(rev, (S, S))
     mx, my = nm.attention_axis_maps(mota, So, So, "identity")
     assert torch.equal(nm.remap_hwc(imgs, mx, my, "cv2"), out)           # the drop-in is these four launches
-    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
-    idx = torch.tensor(sel, device=dev)
-    att_h, rev_h, mota_h, mx_h, my_h = N(att[idx]), N(rev[idx]), N(mota[idx]), N(mx[idx]), N(my[idx])
-    img_h, out_h = N(imgs[idx]), N(out[idx])
-    flips = 0
-    for i, b in enumerate(sel):
-        orev = O.revise_mask(att_h[i], 3, 10)
-        u = np.abs(rev_h[i].view(np.int32).astype(np.int64) - orev.view(np.int32).astype(np.int64))
-        assert u.max() <= 1, b
-        # given the GPU's revised mask everything downstream is bit-exact
-        assert np.array_equal(mota_h[i], O.lanczos_resize_u8(O.mask_to_u8(rev_h[i]), S, S)), b
-        omx, omy = O.maps_from_attention(mota_h[i], So, So, "identity")
-        assert np.array_equal(mx_h[i], omx) and np.array_equal(my_h[i], omy), b
-        assert np.array_equal(out_h[i], C.remap_bilinear_u8(img_h[i], omx, omy, "cv2")), b
-        # from the oracle's own revised mask: 24 x 24 cells may flip by one grey level, nothing else
-        d = np.abs(O.mask_to_u8(orev).astype(int) - O.mask_to_u8(rev_h[i]).astype(int))
-        assert d.max() <= 1
-        flips += int((d > 0).sum())
+    att_h, rev_h, mx_h, my_h = N(att), N(rev), N(mx), N(my)
+    flips = [0] * B
+    for c0 in range(0, B, 32):                                    # every image, 32 at a time through host memory
+        sel = list(range(c0, min(c0 + 32, B)))
+        mota_h, img_h, out_h = N(mota[c0:c0 + 32]), N(imgs[c0:c0 + 32]), N(out[c0:c0 + 32])
+        def check(b):
+            i = b - c0
+            orev = O.revise_mask(att_h[b], 3, 10)
+            u = np.abs(rev_h[b].view(np.int32).astype(np.int64) - orev.view(np.int32).astype(np.int64))
+            assert u.max() <= 1, b
+            # given the GPU's revised mask everything downstream is bit-exact
+            assert np.array_equal(mota_h[i], O.lanczos_resize_u8(O.mask_to_u8(rev_h[b]), S, S)), b
+            omx, omy = O.maps_from_attention(mota_h[i], So, So, "identity")
+            assert np.array_equal(mx_h[b], omx) and np.array_equal(my_h[b], omy), b
+            assert np.array_equal(out_h[i], C.remap_bilinear_u8(img_h[i], omx, omy, "cv2")), b
+            # from the oracle's own revised mask: 24 x 24 cells may flip by one grey level, nothing else
+            d = np.abs(O.mask_to_u8(orev).astype(int) - O.mask_to_u8(rev_h[b]).astype(int))
+            assert d.max() <= 1
+            flips[b] = int((d > 0).sum())
+        for_each(sel, check)
+    flips, sel = sum(flips), range(B)
     assert flips <= 1e-3 * len(sel) * 576
 
 
@@ -1537,8 +1548,8 @@ def test_full_size_properties(dev, cfg, mode):
     (1) identity maps reproduce the input bit-for-bit; (2) the streaming kernel and the independent
     gather kernel agree bit-for-bit on attention-driven maps (HWC and CHW, float32 and uint8); (3) a constant image
     stays constant (partition of unity; in cv2 mode the four table weights sum to 1 exactly); (4) every output lies
-    within the input's range; (5) first and last image equal the CPU oracle bit-for-bit (every image / a stratified
-    32: test_whole_batch_vs_c_oracle)."""
+    within the input's range; (5) first and last image equal the CPU oracle bit-for-bit (every image:
+    test_whole_batch_vs_c_oracle)."""
     from attwarp_amd import checkpoint_utils as cu, pipeline
     B, S = cfg
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -1600,8 +1611,8 @@ def _attention24(B, kind, dev, gen):
 @pytest.mark.parametrize("kind", ["random", "peaked", "zero", "smooth"])
 def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
     """BASELINE configs[1] and [2] at full size against the ORACLE (oracle/warp_ref.c, itself pinned to the numpy oracle
-    and through it to the reference fixtures) -- not against a sibling kernel: EVERY image of B=64 @ 336x336 and a
-    stratified 32 of B=256 @ 1024x1024 (first, every 8th, last), both arithmetic modes, HWC and CHW, float32 and uint8,
+    and through it to the reference fixtures) -- not against a sibling kernel: EVERY image of B=64 @ 336x336 and of
+    B=256 @ 1024x1024, both arithmetic modes, HWC and CHW, float32 and uint8,
     maps and pixels bit for bit; on SURVEY 8d's value distributions: random-softmax attention on white noise, one 3x3 hot
     spot x100 (strong magnification / minification), all-zero attention (the fallback branch), and a smooth image."""
     import subprocess
@@ -1623,16 +1634,15 @@ def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
     img = img.contiguous()
     px, py = cu.gt_marginals(att.view(B, 1, 24, 24))
     mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S))
-    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
-    assert len(sel) == (64 if S <= 512 else 33)
-    # maps of the selected images: the C oracle's own chain from the 24 x 24 map
+    # maps of EVERY image: the C oracle's own chain from the 24 x 24 map
     inv = O.right_inverse_core(24, S)
     att_h, mx_h, my_h = N(att), N(mx), N(my)
-    for b in sel:
+    def check_maps(b):
         opx, opy = C.marginals(att_h[b])
         omx = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opx, S, inv, clamp0=True)), S)
         omy = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opy, S, inv, clamp0=True)), S)
         assert np.array_equal(mx_h[b], omx) and np.array_equal(my_h[b], omy), b
+    for_each(range(B), check_maps)
     if kind == "zero":
         assert float(mx.max()) <= S and bool(torch.isfinite(mx).all())
     img8 = (img * 255).to(torch.uint8)
@@ -1641,11 +1651,13 @@ def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
     c = cu.remap_separable(img.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
     c8 = cu.remap_separable(img8.permute(0, 3, 1, 2).contiguous(), mx, my, mode=mode)
     assert torch.equal(c.permute(0, 2, 3, 1), a) and torch.equal(c8.permute(0, 2, 3, 1), a8)     # all B images
-    idx = torch.tensor(sel, device=dev)
-    img_h, img8_h, a_h, a8_h = N(img[idx]), N(img8[idx]), N(a[idx]), N(a8[idx])
-    for i, b in enumerate(sel):
-        assert np.array_equal(a_h[i], C.remap_bilinear(img_h[i], mx_h[b], my_h[b], "hwc", mode)), (b, "float32")
-        assert np.array_equal(a8_h[i], C.remap_bilinear_u8(img8_h[i], mx_h[b], my_h[b], mode)), (b, "uint8")
+    for c0 in range(0, B, 32):                                    # every image, 32 at a time through host memory
+        img_h, img8_h, a_h, a8_h = N(img[c0:c0 + 32]), N(img8[c0:c0 + 32]), N(a[c0:c0 + 32]), N(a8[c0:c0 + 32])
+        def check(b):
+            i = b - c0
+            assert np.array_equal(a_h[i], C.remap_bilinear(img_h[i], mx_h[b], my_h[b], "hwc", mode)), (b, "float32")
+            assert np.array_equal(a8_h[i], C.remap_bilinear_u8(img8_h[i], mx_h[b], my_h[b], mode)), (b, "uint8")
+        for_each(range(c0, min(c0 + 32, B)), check)
 
 
 @pytest.mark.parametrize("cfg", [(64, 336), (256, 1024)])
@@ -1653,7 +1665,7 @@ def test_whole_batch_vs_c_oracle(dev, cfg, mode, kind):
 def test_stack_chain_full_size_vs_oracle(dev, cfg, adt):
     """The exact chain bench.py times, at its full sizes, FROM THE STACK: attention rows [T=20, B, 32 heads, kv=640]
     (float32, and float16 as LLaVA emits them), image tokens at 35 + b mod 8 -> A1 -> A2 .. A11 -> A12 on [B,S,S,3] float32.
-    The aggregated 24 x 24 maps, the 1-D maps and the pixels of every image (336) / a stratified 33 (1024) against the
+    The aggregated 24 x 24 maps, the 1-D maps and the pixels of EVERY image (both sizes) against the
     oracle chain (numpy A1/A2 in the row dtype, oracle/warp_ref.c for everything behind it; float32 rows also through
     warp_ref.c's own whole-path entry point).  The stream forms (pipeline.OverlappedWarp patterns "am" and "fused") must
     produce the same bytes as the serial launches for ALL images."""
@@ -1674,24 +1686,26 @@ def test_stack_chain_full_size_vs_oracle(dev, cfg, adt):
     steps = pipeline.attention_step_maps(rows, starts)
     mx, my, att = pipeline.axis_maps_from_attention_steps(steps, (S, S), return_attention=True)
     out = pipeline.warp_from_attention_stack(img, rows, starts, channels_last=True, mode="cv2")
-    sel = list(range(B)) if S <= 512 else sorted(set(list(range(0, B, 8)) + [B - 1]))
-    idx = torch.tensor(sel, device=dev)
-    rows_h, st_h = N(rows[:, idx]), N(starts[idx])
-    att_o = O.attn_reduce_stack(rows_h, st_h)                     # numpy A1 + A2 in the row dtype
-    assert att_o.dtype == (np.float32 if adt == torch.float32 else np.float16)
-    assert np.array_equal(N(att[idx]), att_o.astype(np.float32))
+    st_h, att_h, mx_h, my_h = N(starts), N(att), N(mx), N(my)
     inv = O.right_inverse_core(24, S)
-    mx_h, my_h, img_h, out_h = N(mx[idx]), N(my[idx]), N(img[idx]), N(out[idx])
-    for i, b in enumerate(sel):
-        a24 = att_o[i].astype(np.float32).reshape(24, 24)
-        opx, opy = C.marginals(a24)
-        omx = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opx, S, inv, clamp0=True)), S)
-        omy = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opy, S, inv, clamp0=True)), S)
-        assert np.array_equal(mx_h[i], omx) and np.array_equal(my_h[i], omy), b
-        assert np.array_equal(out_h[i], C.remap_bilinear(img_h[i], omx, omy, "hwc", "cv2")), b
-        if adt == torch.float32 and i % 4 == 0:                    # the C oracle's own whole path (its A1 included)
-            assert np.array_equal(out_h[i], C.warp_from_attention_stack(img_h[i], rows_h[:, i], st_h[i], inv, inv, "hwc", "cv2")), b
-    del img_h, out_h
+    for c0 in range(0, B, 32):                                    # every image, 32 at a time through host memory
+        rows_h = N(rows[:, c0:c0 + 32])
+        att_o = O.attn_reduce_stack(rows_h, st_h[c0:c0 + 32])     # numpy A1 + A2 in the row dtype
+        assert att_o.dtype == (np.float32 if adt == torch.float32 else np.float16)
+        assert np.array_equal(att_h[c0:c0 + 32], att_o.astype(np.float32))
+        img_h, out_h = N(img[c0:c0 + 32]), N(out[c0:c0 + 32])
+        def check(b):
+            i = b - c0
+            a24 = att_o[i].astype(np.float32).reshape(24, 24)
+            opx, opy = C.marginals(a24)
+            omx = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opx, S, inv, clamp0=True)), S)
+            omy = C.axis_map_from_cdf(C.cdf_from_density(C.right_inverse(opy, S, inv, clamp0=True)), S)
+            assert np.array_equal(mx_h[b], omx) and np.array_equal(my_h[b], omy), b
+            assert np.array_equal(out_h[i], C.remap_bilinear(img_h[i], omx, omy, "hwc", "cv2")), b
+            if adt == torch.float32 and b % 8 == 0:                # the C oracle's own whole path (its A1 included)
+                assert np.array_equal(out_h[i], C.warp_from_attention_stack(img_h[i], np.ascontiguousarray(rows_h[:, i]), st_h[b], inv, inv, "hwc", "cv2")), b
+        for_each(range(c0, min(c0 + 32, B)), check)
+    del img_h, out_h, rows_h
     for pattern in ("am", "fused"):
         ow = pipeline.OverlappedWarp(img, rows, starts, channels_last=True, mode="cv2", pattern=pattern)
         ow.reset(); ow.prime(); ow.prime2()
@@ -2880,6 +2894,44 @@ def test_ragged_stream_equals_serial_launches(dev):
         st.drain_ring()
         torch.cuda.synchronize()
         assert all(torch.equal(rb.out, w) for rb, w in zip(ring, want)), unroll
+
+
+def test_remap_kernels_vs_real_opencv_fixture_if_present(dev):
+    """tests/golden/remap_cv2.npz = REAL cv2.remap outputs (written by `make_golden.py --with-opencv` on a machine that has
+    OpenCV; absent until then: the cv2 arithmetic is pinned to OpenCV's published algorithm only).  When it is
+    there, every resample kernel family must reproduce it bit for bit."""
+    from attwarp_amd import checkpoint_utils as cu
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "remap_cv2.npz")
+    if not os.path.exists(path):
+        pytest.skip("no remap_cv2.npz: OpenCV has not been available to this repository yet")
+    g = np.load(path, allow_pickle=False)
+    for key in [str(k) for k in g["cases"]]:
+        img, mx, my, want = g[f"{key}|img"], g[f"{key}|mx"], g[f"{key}|my"], g[f"{key}|out"]
+        x = img[None, :, :, None] if img.ndim == 2 else img[None]
+        for variant in (-1, 1):
+            with _lib.debug_override(remap_variant=variant):
+                got = N(cu.remap_separable(T(x, dev), T(mx[None], dev), T(my[None], dev), mode="cv2", channels_last=True))[0]
+            assert np.array_equal(got.reshape(want.shape), want), (key, variant, str(g["opencv_build"]))
+
+
+def test_upload_images_packs_host_images_for_the_ragged_chain(dev):
+    """pipeline.upload_images: PIL images / arrays of different sizes -> one staging buffer, one transfer, GPU views at
+    whatever byte offsets the packing gives (odd ones included) -> the ragged chain; equals the chain on separately
+    allocated copies."""
+    from PIL import Image
+    from attwarp_amd import pipeline
+    rng = np.random.default_rng(91)
+    sizes = [(75, 101), (64, 99), (33, 131), (90, 64)]
+    host = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w) in sizes]
+    mixed = [Image.fromarray(host[0]), host[1], Image.fromarray(host[2]), host[3]]
+    up = pipeline.upload_images(mixed, dev)
+    assert [tuple(u.shape) for u in up] == [(h, w, 3) for (h, w) in sizes]
+    assert any(u.data_ptr() % 4 for u in up)                         # the packing really produces unaligned images
+    assert all(np.array_equal(N(u), h) for u, h in zip(up, host))
+    att = torch.rand(4, 24, 24, device=dev)
+    a = pipeline.warp_from_masks_ragged(up, att, (60, 72))
+    b = pipeline.warp_from_masks_ragged([T(h, dev) for h in host], att, (60, 72))
+    assert torch.equal(a, b)
 
 
 def test_ragged_falls_back_per_image_outside_its_limits(dev):
