@@ -28,6 +28,16 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // W = 700, below it the all-planes form wins (336: 252 of 256 lanes busy with three planes per row, 84 with one).
   bool split = layout == ATTWARP_CHW && C > 1 && (long long)W * 4 >= 3072 && (long long)B * C <= 2147483647LL;
   if (const int se = tune(TUNE_REMAP_CHW_SPLIT); se >= 0) split = layout == ATTWARP_CHW && C > 1 && se != 0;
+  // "unaligned": a row length that is not a multiple of 4 floats, or an image / plane that does not start on a 16-byte
+  // boundary.  Served by the UA instantiations (remap_rows_ua.hip: interleaved rows that fit the LDS row; planar images
+  // plane by plane); the fused step, column-tiled rows and rows of fewer than 4 floats take the generic gather kernel.
+  const bool ua = ((long long)W * (layout == ATTWARP_HWC ? C : 1)) % 4 != 0 || (reinterpret_cast<uintptr_t>(src) & 15u) != 0 ||
+                  (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 : ((long long)H * W) % 4 != 0);
+  if (ua && (ex || (reinterpret_cast<uintptr_t>(src) & 3u) != 0)) return ATTWARP_OK;
+  if (ua && layout == ATTWARP_CHW && C > 1) {
+    if ((long long)B * C > 2147483647LL) return ATTWARP_OK;
+    split = true;
+  }
   if (split) {
     p.map_div = C;
     B *= C;
@@ -38,16 +48,14 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.row_len = W * p.CS;
   p.orow_len = Wo * p.CS;
   const long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
-  // 16-byte vector loads need every plane row to start on a 16-byte boundary
-  if (p.row_len % 4 != 0) return ATTWARP_OK;
-  if ((reinterpret_cast<uintptr_t>(src) & 15u) != 0) return ATTWARP_OK;
-  if (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 : ((long long)H * W) % 4 != 0) return ATTWARP_OK;
   // LDS indices are 16 bit and the tap tables live in VGPRs: up to 4096 floats per staged row.  Wider interleaved /
   // one-plane rows are processed in column tiles; wider multi-plane rows take the generic kernel.
   const bool tiled = VL > 4096 || OVL > 4096;
+  if (ua && (tiled || VL < 4 || p.NP != 1)) return ATTWARP_OK;
+  p.unaligned = ua ? 1 : 0;
   if (tiled && (p.NP != 1 || VL > 2147483647LL / 8 || OVL > 2147483647LL / 8)) return ATTWARP_OK;
   if (tiled && tune(TUNE_REMAP_TILED) == 0) return ATTWARP_OK;
-  p.VLV = (int)(VL / 4);
+  p.VLV = (int)((VL + 3) / 4);
   p.OVL = (int)OVL;
   p.ntiles = 1;
   p.plane_stride = (layout == ATTWARP_HWC) ? 0 : (long long)H * W;
@@ -127,6 +135,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   //  4-wave workgroups -- no gain, so a single workgroup size is instantiated)
   const int tile_ko = tiled ? TILE_KO : 0;
   if (ex) ex->nR8 = (p.nblocks + 7) / 8;
+  if (ua) return launch_rows_ua(p, mode, st);
   if (mode == ATTWARP_CV2) return launch_rows_cv2(p, tile_ko, st, ex);
   return launch_rows_exact(p, tile_ko, st, ex);
 }

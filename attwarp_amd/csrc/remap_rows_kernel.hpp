@@ -38,6 +38,9 @@
 // (the register sets are clang vectors, not HIP's float4 struct: struct copies are memcpy's, and the row loop's control flow
 // left an array of them in scratch memory)
 typedef float rows_v4f __attribute__((ext_vector_type(4)));
+// the same four floats at any 4-byte boundary (UA: rows whose length is not a multiple of 4 floats -- 683 x 3)
+typedef float rows_v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+#define ATTWARP_ROW_V4(ptr_) (UA ? rows_v4f(*reinterpret_cast<const rows_v4f_a4*>(ptr_)) : *reinterpret_cast<const rows_v4f*>(ptr_))
 #ifdef ATTWARP_TUNING
 #define ATTWARP_ROW_STORE(ptr_, v_)                                                                                 \
   do { if (p.nt_loads & 2) __builtin_nontemporal_store((v_), (ptr_)); else *(ptr_) = (v_); } while (0)
@@ -45,12 +48,12 @@ typedef float rows_v4f __attribute__((ext_vector_type(4)));
   if (p.nt_loads & 1) {                                                                                             \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = __builtin_nontemporal_load(reinterpret_cast<const rows_v4f*>(rp_ + goff[k])); \
   } else {                                                                                                          \
-    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]);         \
+    _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = ATTWARP_ROW_V4(rp_ + goff[k]);                             \
   }
 #else
 #define ATTWARP_ROW_STORE(ptr_, v_) (*(ptr_) = (v_))
 #define ATTWARP_ROW_LOAD(X, rp_)                                                                                    \
-  { _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = *reinterpret_cast<const rows_v4f*>(rp_ + goff[k]); }
+  { _Pragma("unroll") for (int k = 0; k < KI; ++k) X[k] = ATTWARP_ROW_V4(rp_ + goff[k]); }
 #endif
 
 namespace attwarp {
@@ -144,6 +147,7 @@ struct RowsParams {
 #endif
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
+  int unaligned;     // rows / images that are not 16-byte aligned: the UA instantiations (remap_rows_ua.hip)
 };
 
 constexpr int RMAX = 64;
@@ -172,8 +176,14 @@ constexpr int NT_BIG = 256;    // threads per workgroup (4 waves share a row)
 // to direct global taps for that tile only.
 // SINGLE (CV2, rows wider than 12 KB, and the one-launch step's 8-12 KB rows): one [top | bottom] buffer and two
 // barriers per row instead of two buffers and one barrier (half the LDS; two buffers of 16 KB rows would not fit 64 KB).
-template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE>
+// UA ("unaligned", interleaved rows that fit the LDS row): a row length that is not a multiple of 4 floats, or an image
+// that does not start on a 16-byte boundary.  Rows still start on float boundaries, so the loads stay 16-byte loads
+// relative to the ROW start (unaligned access mode); the row's last vector is loaded END-aligned -- the four floats that
+// end with the row: nothing behind the image is read -- and staged at its own float index in the LDS row (it overlaps the
+// vector in front of it with the same values), so the gather needs no change at all.
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE, bool UA = false>
 __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int block_index, float* smem) {
+  static_assert(!UA || (HWC && !TILED && !AFF), "unaligned rows: interleaved, not column-tiled, per-element output offsets");
   constexpr bool CV = MODE == ATTWARP_CV2;
   float* s_my = smem;                                   // RMAX floats
   constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
@@ -284,6 +294,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
       const int f = min(tid + NT * k, p.VLV - 1) * 4;
       const int pl = HWC ? 0 : plane_of(f, p.row_len);
       goff[k] = ((unsigned)(pl * p.plane_stride) + (unsigned)(f - pl * p.row_len)) * 4u;
+      if (UA && f + 4 > p.row_len) goff[k] = (unsigned)(p.row_len - 4) * 4u;       // the row's last vector, end-aligned
     }
   }
 
@@ -314,16 +325,21 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   do {                                                                                              \
     rows_v4f* rowv_ = reinterpret_cast<rows_v4f*>(rowbuf);                                          \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                \
-      if (CV) {                                                                                     \
-        rowv_[tid + NT * k] = XA[k];                                                                \
-        rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                                     \
-      } else {                                                                                      \
-        rows_v4f v_;                                                                                \
+      rows_v4f v_;                                                                                  \
+      if (CV) v_ = XA[k];                                                                           \
+      else {                                                                                        \
         v_.x = lerp_rn(XA[k].x, XC[k].x, fy);                                                       \
         v_.y = lerp_rn(XA[k].y, XC[k].y, fy);                                                       \
         v_.z = lerp_rn(XA[k].z, XC[k].z, fy);                                                       \
         v_.w = lerp_rn(XA[k].w, XC[k].w, fy);                                                       \
+      }                                                                                             \
+      if (UA && k == KI - 1) {   /* interleaved: a vector's float index in the row = its byte offset / 4 */ \
+        float* at_ = reinterpret_cast<float*>(rowbuf) + (goff[k] >> 2);                             \
+        *reinterpret_cast<rows_v4f_a4*>(at_) = v_;                                                  \
+        if (CV) *reinterpret_cast<rows_v4f_a4*>(at_ + ROWF) = XC[k];                                \
+      } else {                                                                                      \
         rowv_[tid + NT * k] = v_;                                                                   \
+        if (CV) rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                             \
       }                                                                                             \
     }                                                                                               \
   } while (0)
@@ -516,13 +532,13 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
 #undef ATTWARP_COLUMN_TAPS
 }
 
-template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false>
+template <int NT, int KI, int KO, bool HWC, bool AFF, bool TILED, int MODE, bool SINGLE = false, bool UA = false>
 __global__ __launch_bounds__(NT) void remap_rows_kernel(const RowsParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef ATTWARP_TUNING
   const TraceStart t0 = trace_now();
 #endif
-  remap_rows_block<NT, KI, KO, HWC, AFF, TILED, MODE, SINGLE>(p, blockIdx.x, smem);
+  remap_rows_block<NT, KI, KO, HWC, AFF, TILED, MODE, SINGLE, UA>(p, blockIdx.x, smem);
 #ifdef ATTWARP_TUNING
   trace_block(p.trace, t0, 2);
 #endif
@@ -706,6 +722,9 @@ static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st, co
   if constexpr (KIMIN <= 4 && 4 <= KIMAX) if (ki >= 4) return launch_rows_ki<NT, 4, MODE, SINGLE, FUSED>(p, ko, st, ex);
   return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: variant for %d float4 per thread not built", ki);
 }
+
+// the unaligned form (UA) of the plain resample, both modes: remap_rows_ua.hip
+int launch_rows_ua(const RowsParams& p, int mode, hipStream_t st);
 
 // defined in remap_rows.hip / remap_rows_cv2.hip (plain resample; ex == nullptr) and remap_step_exact.hip /
 // remap_step_cv2.hip (the fused step; ex != nullptr)

@@ -2778,6 +2778,42 @@ def test_remap_uint8_unaligned_rows_stay_on_the_staged_kernel(dev, shape, kind):
     assert bool((dflat[:5] == 0xEE).all()) and bool((dflat[5 + ref.size:] == 0xEE).all())       # nothing written outside
 
 
+@pytest.mark.parametrize("shape", [(40, 683, 33, 500, 3), (37, 333, 29, 333, 3), (26, 1023, 31, 1023, 3), (30, 501, 28, 501, 3),
+                                   (33, 47, 40, 31, 1), (31, 29, 31, 29, 2), (28, 1365, 17, 1365, 3), (25, 4093, 9, 4095, 1),
+                                   (30, 1023, 24, 1024, 3), (27, 683, 20, 1024, 3)])
+@pytest.mark.parametrize("mode", ["cv2", "exact"])
+def test_remap_float32_unaligned_rows_stay_on_the_staged_kernel(dev, shape, mode):
+    """float32 images whose rows are not a multiple of 4 floats (W * C % 4 != 0: 683 x 3, 333 x 3, 1023 x 3, 501 x 3) run
+    on remap_rows_kernel's unaligned form in both arithmetic modes -- `remap_variant=3` refuses a fall-back to the gather
+    kernel -- interleaved and planar (plane by plane), every rows-per-block / row-blocks-per-workgroup setting, and from a
+    view that starts 4 bytes into a 16-byte line: bit-exact against the oracle and the gather kernel."""
+    from attwarp_amd import checkpoint_utils as cu
+    H, W, Ho, Wo, C = shape
+    rng = np.random.default_rng(H * 19 + W + Wo)
+    B = 3
+    for kind in ("cdf", "wild"):
+        mx, my = make_maps(rng, B, H, W, Ho, Wo, kind)
+        img = rng.random((B, H, W, C), dtype=np.float32)
+        ref = np.stack([O.remap_bilinear(img[b], mx[b], my[b], mode) for b in range(B)])
+        ti, tx, ty = T(img, dev), T(mx, dev), T(my, dev)
+        tc = T(img.transpose(0, 3, 1, 2), dev)
+        with _lib.debug_override(remap_variant=3):
+            hwc = N(cu.remap_separable(ti, tx, ty, mode=mode, channels_last=True))
+            chw = N(cu.remap_separable(tc, tx, ty, mode=mode))
+        assert np.array_equal(hwc, ref), kind
+        assert np.array_equal(chw.transpose(0, 2, 3, 1), ref), kind
+        with _lib.debug_override(remap_variant=1):
+            assert np.array_equal(N(cu.remap_separable(ti, tx, ty, mode=mode, channels_last=True)), ref)
+        for rows, cpw in ((1, 1), (3, 2), (7, 3), (64, 1)):
+            with _lib.debug_override(remap_variant=3, remap_rows=rows, remap_cpw=cpw):
+                assert np.array_equal(N(cu.remap_separable(ti, tx, ty, mode=mode, channels_last=True)), ref), (kind, rows, cpw)
+        flat = torch.zeros(img.size + 8, device=dev, dtype=torch.float32)
+        flat[1:1 + img.size] = ti.reshape(-1)
+        with _lib.debug_override(remap_variant=3):
+            got = cu.remap_separable(flat[1:1 + img.size].view(B, H, W, C), tx, ty, mode=mode, channels_last=True)
+        assert np.array_equal(N(got), ref), kind
+
+
 @pytest.mark.parametrize("hw", [(64, 683), (70, 333), (129, 1023), (501, 501), (1024, 683), (90, 130), (33, 26)])
 def test_mask_upsample_and_marginals_unaligned_widths(dev, hw):
     """The LANCZOS up-sampling of the 24 x 24 mask to a width that is not a multiple of 4, and the float64 marginals of
