@@ -112,7 +112,7 @@ class RaggedHeader(ctypes.Structure):
                 ("max_hw", ctypes.c_int32),
                 ("table_bytes", ctypes.c_uint64), ("mota_bytes", ctypes.c_uint64), ("sums_bytes", ctypes.c_uint64),
                 ("lds_bytes", ctypes.c_uint64), ("off_images", ctypes.c_uint64), ("off_plans", ctypes.c_uint64),
-                ("off_lmap", ctypes.c_uint64), ("off_pmap", ctypes.c_uint64)]
+                ("off_lmap", ctypes.c_uint64), ("off_pmap", ctypes.c_uint64), ("off_order", ctypes.c_uint64)]
 
 
 _lib = None            # the library every call goes to: the product, or the tuning flavour inside debug_override()

@@ -66,9 +66,9 @@ struct RaggedStepArgs {
   // P(k+2)
   const RaggedImage* p_img; const RaggedPlan* p_plans; const uint32_t* p_map; const uint8_t* mota_in; double* sums_out;
   // F(k+1)
-  const RaggedImage* f_img; const RaggedPlan* f_plans; const double* sums_in; float* map_x_next; float* map_y_next;
+  const RaggedImage* f_img; const RaggedPlan* f_plans; const uint32_t* f_order; const double* sums_in; float* map_x_next; float* map_y_next;
   // R(k)
-  const RaggedImage* r_img; uint8_t* out; const float* map_x; const float* map_y;
+  const RaggedImage* r_img; const uint32_t* r_order; uint8_t* out; const float* map_x; const float* map_y;
   int r_rows, r_nblk;                       // output rows per resample block, blocks per image
 #ifdef ATTWARP_TUNING
   unsigned long long* trace;
@@ -82,7 +82,7 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
   const int kind = chain_order_decode(a.ord, blockIdx.x, j);
   if (kind == CHAIN_F) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
-    const int b = j >> 1;
+    const int b = (int)a.f_order[j >> 1];           // largest images first: their chains are the longest blocks of the launch
     const RaggedImage& im = a.f_img[b];
     const RaggedPlan& Pw = a.f_plans[im.plan_w];
     const RaggedPlan& Ph = a.f_plans[im.plan_h];
@@ -115,12 +115,19 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
                               im.l_nchunks, im.l_rows_per_chunk, nullptr};
     lanczos_strip_block<8, true>(la, bx, (size_t)b * a.g * a.g, a.mota_out + im.mota_off, pool);
   } else if (kind == CHAIN_R) {
-    int bid = j;
-    {     // a contiguous range of row blocks per XCD (block % 8 names the XCD), as remap_rows_u8i_block with grp = 0
-      const int n = a.ord.nR, q = n >> 3, r = n & 7, xcd = bid & 7, idx = bid >> 3;
-      bid = (xcd < r) ? xcd * (q + 1) + idx : r * (q + 1) + (xcd - r) * q + idx;
+    // Whole images per XCD (block % 8 names the XCD: the halo row two neighbouring row blocks share is an L2 hit), dealt
+    // round robin from the size-sorted order so that every XCD gets large and small images alike: image rank s * 8 + xcd.
+    // (A batch that is not a multiple of 8 images takes the plain order: consecutive row blocks on consecutive XCDs.)
+    int bi, rb0;
+    if ((a.ord.nR / a.r_nblk) % 8 == 0) {
+      const int xcd = j & 7, idx = j >> 3, sl = idx / a.r_nblk;
+      bi = sl * 8 + xcd;
+      rb0 = idx - sl * a.r_nblk;
+    } else {
+      bi = j / a.r_nblk;
+      rb0 = j - bi * a.r_nblk;
     }
-    const int b = bid / a.r_nblk, rb0 = bid - b * a.r_nblk;
+    const int b = (int)a.r_order[bi];
     const RaggedImage& im = a.r_img[b];
     u8k::Params p;
     p.H = im.H; p.W = im.W; p.Ho = a.Ho; p.Wo = a.Wo;
@@ -176,7 +183,7 @@ struct RaggedLayout {
   attwarp_ragged_header h;
   std::vector<RaggedImage> img;
   std::vector<RaggedPlan> plans;
-  std::vector<uint32_t> lmap, pmap;
+  std::vector<uint32_t> lmap, pmap, order;
 };
 
 static bool ragged_plan_of(int n, RaggedPlan& out) {
@@ -248,8 +255,6 @@ static int ragged_layout(const attwarp_ragged_image* images, int B, int C, int g
     nchunks = (in.H + rows_per_chunk - 1) / rows_per_chunk;
     im.l_nchunks = (int)nchunks; im.l_rows_per_chunk = rows_per_chunk;
     if (nstrips * nchunks > 65535) return fail(ATTWARP_E_UNSUPPORTED, "ragged_plan: image %d: too many up-sampling blocks", b);
-    for (int s = 0; s < nstrips * (int)nchunks; ++s) L.lmap.push_back((uint32_t)b | ((uint32_t)s << 16));
-    for (int jl = 0; jl < Pw.nleaves; ++jl) L.pmap.push_back((uint32_t)b | ((uint32_t)jl << 16));
     im.ki = (int)((((VL + 3) >> 2) + u8k::NT - 1) / u8k::NT);
     im.mota_off = (int64_t)mota;
     mota = align_up(mota + (size_t)in.H * in.W, 256);
@@ -262,6 +267,20 @@ static int ragged_layout(const attwarp_ragged_image* images, int B, int C, int g
     const size_t f = (size_t)(std::max(in.H, in.W) + 2) * 8 + (PROF_NT / WAVE) * 8 + (size_t)Pw.depth * PROF_NT * 8 + (size_t)nl * 8 +
                      plan_view_lds_bytes(Pw.nleaves) + plan_view_lds_bytes(Ph.nleaves);
     lds = std::max(lds, f);
+  }
+  // Block order inside every stage: the largest images first.  A block's duration grows with its image (the marginals
+  // blocks walk all H rows of a 128-column strip, the finalize blocks run an H- / W-long dependent chain): dispatched in
+  // batch order a large image near the end of the batch would be the tail of the launch.
+  L.order.resize(B);
+  for (int b = 0; b < B; ++b) L.order[b] = (uint32_t)b;
+  std::stable_sort(L.order.begin(), L.order.end(), [&](uint32_t x, uint32_t y) {
+    return (long long)L.img[x].H * L.img[x].W > (long long)L.img[y].H * L.img[y].W;
+  });
+  for (uint32_t b : L.order) {
+    const RaggedImage& im = L.img[b];
+    const int nstrips = (im.W + MASK_NT - 1) / MASK_NT;
+    for (int sblk = 0; sblk < nstrips * im.l_nchunks; ++sblk) L.lmap.push_back(b | ((uint32_t)sblk << 16));
+    for (int jl = 0; jl < L.plans[im.plan_w].nleaves; ++jl) L.pmap.push_back(b | ((uint32_t)jl << 16));
   }
   lds = std::max(lds, std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
                                std::max(lanczos_strip_lds_bytes(g, g), mask_postproc_lds_bytes())));
@@ -282,7 +301,8 @@ static int ragged_layout(const attwarp_ragged_image* images, int B, int C, int g
   h.off_plans = align_up(h.off_images + (size_t)B * sizeof(RaggedImage), 8);
   h.off_lmap = h.off_plans + L.plans.size() * sizeof(RaggedPlan);
   h.off_pmap = h.off_lmap + L.lmap.size() * sizeof(uint32_t);
-  h.table_bytes = align_up(h.off_pmap + L.pmap.size() * sizeof(uint32_t), 16);
+  h.off_order = h.off_pmap + L.pmap.size() * sizeof(uint32_t);
+  h.table_bytes = align_up(h.off_order + L.order.size() * sizeof(uint32_t), 16);
   return ATTWARP_OK;
 }
 
@@ -364,6 +384,7 @@ extern "C" int attwarp_ragged_plan(const attwarp_ragged_image* images, int B, in
   memcpy(t + L.h.off_plans, L.plans.data(), L.plans.size() * sizeof(RaggedPlan));
   memcpy(t + L.h.off_lmap, L.lmap.data(), L.lmap.size() * sizeof(uint32_t));
   memcpy(t + L.h.off_pmap, L.pmap.data(), L.pmap.size() * sizeof(uint32_t));
+  memcpy(t + L.h.off_order, L.order.data(), L.order.size() * sizeof(uint32_t));
   return ATTWARP_OK;
 }
 
@@ -396,6 +417,7 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
     if (!h) return ATTWARP_E_ARG;
     ATTWARP_REQUIRE(out && map_x && map_y, "mask_chain_ragged: null pointer in the R stage");
     a.r_img = reinterpret_cast<const RaggedImage*>(static_cast<const uint8_t*>(r_dev) + h->off_images);
+    a.r_order = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(r_dev) + h->off_order);
     a.out = out; a.map_x = map_x; a.map_y = map_y;
     a.r_rows = h->rows_per_block; a.r_nblk = h->blocks_per_image;
     a.ord.nR = h->nR;
@@ -409,6 +431,7 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
     const uint8_t* t = static_cast<const uint8_t*>(f_dev);
     a.f_img = reinterpret_cast<const RaggedImage*>(t + h->off_images);
     a.f_plans = reinterpret_cast<const RaggedPlan*>(t + h->off_plans);
+    a.f_order = reinterpret_cast<const uint32_t*>(t + h->off_order);
     a.sums_in = static_cast<const double*>(sums_in); a.map_x_next = map_x_next; a.map_y_next = map_y_next;
     a.ord.nF = 2 * h->B;
   }

@@ -47,6 +47,7 @@ struct ChainStepArgs {
   u8k::Params rp;
 #ifdef ATTWARP_TUNING
   unsigned long long* trace;                // block timeline (common.hpp: trace_buffer), null = off
+  int bound;                                // TUNE_BOUND (upper-bound experiments, garbage output)
 #endif
 };
 
@@ -66,12 +67,22 @@ __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const Pa
     mask_postproc_block(a.masks, a.g, a.ks, a.coe, a.rev_out, j, x, red, fred);
   } else if (kind == CHAIN_P) {
     const int b = j / Pw.nleaves, leaf = j - b * Pw.nleaves;
-    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in + (size_t)b * a.fa.h * a.fa.w, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0},
+#ifdef ATTWARP_TUNING
+    const int bsrc = (a.bound & 2) ? (b & 1) : b;     // bound: every image reads the mask of image 0 / 1 (L2 hits)
+#else
+    const int bsrc = b;
+#endif
+    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in + (size_t)bsrc * a.fa.h * a.fa.w, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0},
                                           Pw.off[leaf], Pw.len[leaf], Pw.nleaves, leaf, a.col_out + (size_t)b * a.fa.w,
                                           a.ls_out + (size_t)b * a.fa.h * Pw.nleaves, pool);
   } else if (kind == CHAIN_L) {
     const int b = j / a.l_bx, bx = j - b * a.l_bx;
-    lanczos_strip_block<8>(a.la, bx, (size_t)b * a.la.h * a.la.w, a.la.out + (size_t)b * a.la.out_h * a.la.out_w, pool);
+#ifdef ATTWARP_TUNING
+    const int bdst = (a.bound & 2) ? (b & 1) : b;     // bound: every image's mask is written over image 0 / 1
+#else
+    const int bdst = b;
+#endif
+    lanczos_strip_block<8>(a.la, bx, (size_t)b * a.la.h * a.la.w, a.la.out + (size_t)bdst * a.la.out_h * a.la.out_w, pool);
   } else if (kind == CHAIN_R) {
     u8k::remap_rows_u8i_block<KI, KD, true, PD>(a.rp, j, reinterpret_cast<float*>(pool));
   }
@@ -180,6 +191,8 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
 #ifdef ATTWARP_TUNING
   a.trace = trace_buffer();
   a.fa.trace = a.trace;
+  a.bound = tune(TUNE_BOUND) > 0 ? tune(TUNE_BOUND) : 0;
+  a.fa.bound = a.bound;
 #endif
   const long long octs = chain_order_octets(a.ord);
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");

@@ -184,6 +184,10 @@ enum TuneKey {
   TUNE_CHAIN_WAVES,         // 6 / 8: waves per SIMD its register allocation leaves room for
   TUNE_REMAP_CV2_DOUBLE,    // cv2 rows of 8-12 KB: 0 = one [top | bottom] LDS buffer and two barriers per row instead of two buffers and one (48 KB)
   TUNE_STEP_PRIO,           // one-launch steps: 1 = the latency-chain blocks (maps / finalize / revise) run at raised wave priority
+  TUNE_BOUND,               // UPPER-BOUND experiments (outputs are garbage; docs/experiments.md round 5): bit 0 float32 cv2 resample stages
+                            //   only the top row in a 3-row LDS pool (what a three-slot ring could save at most); bit 1 chain step: the
+                            //   up-sampled masks of all images alias two images (L's stores and P's loads stay in L2: what fusing L
+                            //   into P could save at most); bit 2 finalize body without its np.cumsum chain; bit 3 finalize body returns at once
   TUNE_TRACE_LO,            // block timeline of the one-launch steps (tools/gantt.py): bits 0..23 and 24..47 of the address of a
   TUNE_TRACE_HI,            //   device buffer of TRACE_WORDS x uint64 per block (layout below)
   TUNE_COUNT

@@ -26,7 +26,7 @@ int tune(TuneKey k) { return g_tune[k].load(std::memory_order_relaxed) - 1; }
 
 static const char* const kTuneNames[TUNE_COUNT] = {
     "remap_variant", "remap_rows", "remap_chw_split", "remap_tiled", "remap_tile_ko", "remap_alt", "remap_noswz",
-    "remap_ldspad", "remap_nt", "lanczos_variant", "lanczos_rows", "clip_variant", "profiles_variant", "remap_cpw", "remap_skew", "attn_hu", "u8_ahead", "chain_seq", "chain_waves", "remap_cv2_double", "step_prio", "trace_lo", "trace_hi"};
+    "remap_ldspad", "remap_nt", "lanczos_variant", "lanczos_rows", "clip_variant", "profiles_variant", "remap_cpw", "remap_skew", "attn_hu", "u8_ahead", "chain_seq", "chain_waves", "remap_cv2_double", "step_prio", "bound", "trace_lo", "trace_hi"};
 
 #endif
 

@@ -367,12 +367,15 @@ struct MapsFinalizeArgs {
   int depth_w;               // pw_depth of the row plan (the per-thread stack of the leaf-combine program)
 #ifdef ATTWARP_TUNING
   unsigned long long* trace; // block timeline (common.hpp), null = off
+  int bound;                 // TUNE_BOUND bits 2 / 3 (upper-bound experiments, garbage output)
 #endif
 };
 #ifdef ATTWARP_TUNING
 #define ATTWARP_F_MARK(i_) trace_mark(a.trace, i_);
+#define ATTWARP_F_BOUND(bit_) (a.bound & (bit_))
 #else
 #define ATTWARP_F_MARK(i_)
+#define ATTWARP_F_BOUND(bit_) false
 #endif
 // LDS of one workgroup: knots (max(h,w) + 2 doubles) | red | per-thread stacks | leaf sums | the two plans
 inline size_t maps_finalize_lds_bytes(int h, int w, const PairwisePlan& Pw, const PairwisePlan& Ph) {
@@ -385,6 +388,7 @@ template <typename SrcPlan>
 __device__ __forceinline__ void attention_maps_finalize_block(const SrcPlan& Pw_arg, const SrcPlan& Ph_arg,
                                                               const MapsFinalizeArgs& a, int axis, double* lds) {
   constexpr int NT = PROF_NT;
+  if (ATTWARP_F_BOUND(8)) return;
   const double* __restrict__ col = a.col; const double* __restrict__ ls = a.ls;
   const int h = a.h, w = a.w, new_w = a.new_w, new_h = a.new_h, transform = a.transform, apply_inverse = a.apply_inverse;
   const double exp_scale = a.exp_scale, exp_divisor = a.exp_divisor;
@@ -409,8 +413,21 @@ __device__ __forceinline__ void attention_maps_finalize_block(const SrcPlan& Pw_
   double* xn = smem_d;                   // n+1 knots; xn[1..n] first holds the profile
 
   // row r of the y profile = numpy's pairwise tree over that row's leaf sums
+  // (rows of <= 8 leaves, i.e. W <= 1024: the row's leaf sums are requested together -- one memory round trip per row
+  //  instead of one per leaf, the leaves of a row share a 64-byte line -- and the combine program, whose leaf index is
+  //  block uniform, picks them through a uniform switch; measured with tools/gantt.py, docs/experiments.md round 5)
   auto row_sum = [&](int r) -> double {
     const double* l = ls + (size_t)r * nl;
+    if (nl <= 8) {
+      double v0 = l[0], v1 = l[min(1, nl - 1)], v2 = l[min(2, nl - 1)], v3 = l[min(3, nl - 1)], v4 = l[min(4, nl - 1)],
+             v5 = l[min(5, nl - 1)], v6 = l[min(6, nl - 1)], v7 = l[min(7, nl - 1)];
+      return pw_combine(Pw, [&](int j) -> double {
+        switch (__builtin_amdgcn_readfirstlane(j)) {
+          case 0: return v0; case 1: return v1; case 2: return v2; case 3: return v3;
+          case 4: return v4; case 5: return v5; case 6: return v6; default: return v7;
+        }
+      }, pstack + threadIdx.x, NT);
+    }
     return pw_combine(Pw, [&](int j) { return l[j]; }, pstack + threadIdx.x, NT);
   };
   auto inv_bias = [&](double v, int terms) -> double {
@@ -446,7 +463,7 @@ __device__ __forceinline__ void attention_maps_finalize_block(const SrcPlan& Pw_
     total = (total != total) ? total : (total > 1e-9 ? total : 1e-9);   // python max(total, EPS): NaN stays
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && !ATTWARP_F_BOUND(4)) {
     // np.cumsum: sequential running sum (adds only; the division below is elementwise and parallel).  32 values are
     // requested from LDS before the first add of a batch: one LDS round trip per 32 dependent adds instead of per 4
     // (the lane spent most of its time waiting: 1024 knots 16 us -> 5 us).
@@ -480,6 +497,7 @@ __device__ __forceinline__ void attention_maps_finalize_block(const SrcPlan& Pw_
   ATTWARP_F_MARK(7)
 }
 #undef ATTWARP_F_MARK
+#undef ATTWARP_F_BOUND
 // the arguments of image b of a dense batch
 __device__ __forceinline__ MapsFinalizeArgs maps_finalize_image(MapsFinalizeArgs a, int b, int nleaves_w) {
   a.col += (size_t)b * a.w;

@@ -128,6 +128,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   p.lds_pad = 0;
   if (const int v = tune(TUNE_REMAP_LDSPAD); v >= 0 && v <= 90000) p.lds_pad = v;
   p.trace = trace_buffer();
+  p.bound = tune(TUNE_BOUND) > 0 ? (tune(TUNE_BOUND) & 1) : 0;
   p.nt_loads = tune(TUNE_REMAP_NT) > 0 ? tune(TUNE_REMAP_NT) : 0;      // bit 0: nontemporal loads of block-private rows, bit 1: nontemporal stores
 #endif
   *handled = true;

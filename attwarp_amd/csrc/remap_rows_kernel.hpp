@@ -141,9 +141,10 @@ struct RowsParams {
   int lds_pad;       // extra dynamic LDS bytes (occupancy experiments)
   int skew;          // block order 0: XCD x starts x * skew blocks into its contiguous range
   int nt_loads;      // bit 0: nontemporal loads of the source rows, bit 1: nontemporal stores
+  int bound;         // TUNE_BOUND bit 0: stage only the top row, 3-row LDS pool (upper bound of a three-slot ring; garbage output)
   unsigned long long* trace;   // block timeline (common.hpp: trace_buffer): phase cycles of this block go to words 7..10
 #else
-  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0;
+  static constexpr int alt_dir = 1, lds_pad = 0, skew = 0, nt_loads = 0, bound = 0;
 #endif
   int map_div;       // maps belong to image b / map_div (planes of a planar image dispatched as images)
   int ntiles;        // TILED: column tiles per row (each KO*NT output elements), else 1
@@ -189,7 +190,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
   constexpr int ROWF = KI * NT * 4;                     // floats per staged source row (padded to whole waves)
   constexpr int BUF = CV ? 2 * ROWF : ROWF;             // floats per LDS buffer (CV2: top row, then bottom row)
   float* rows0 = smem + RMAX;                           // two buffers, addressed with immediates
-  float* rows1 = SINGLE ? rows0 : rows0 + BUF;
+  float* rows1 = SINGLE ? rows0 : rows0 + ((CV && p.bound) ? ROWF : BUF);
   const int tid = threadIdx.x;
 
   // XCD-aware block order: blocks bid, bid+8, ... share an XCD (and its L2); hand each XCD a
@@ -339,7 +340,7 @@ __device__ __forceinline__ void remap_rows_block(const RowsParams& p, const int 
         if (CV) *reinterpret_cast<rows_v4f_a4*>(at_ + ROWF) = XC[k];                                \
       } else {                                                                                      \
         rowv_[tid + NT * k] = v_;                                                                   \
-        if (CV) rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                             \
+        if (CV && !p.bound) rowv_[ROWF / 4 + tid + NT * k] = XC[k];                                 \
       }                                                                                             \
     }                                                                                               \
   } while (0)
@@ -648,6 +649,7 @@ constexpr size_t rows_lds_bytes(int KI, int NT) {
 template <int NT, int KI, int KO, int MODE, bool SINGLE, bool FUSED>
 static int launch_rows_t(const RowsParams& p, hipStream_t st, const StepExtra* ex) {
   size_t lds = rows_lds_bytes<MODE, SINGLE>(KI, NT) + (size_t)p.lds_pad;
+  if (MODE == ATTWARP_CV2 && !SINGLE && p.bound) lds = (size_t)(RMAX + 3 * KI * NT * 4) * sizeof(float);
   const dim3 t(NT);
   if constexpr (FUSED) {   // warp_step_kernel: map blocks, then the reduce blocks, then the resample blocks
     if (ex->nA > 0) lds = std::max(lds, attn_v4_lds_bytes<3>());

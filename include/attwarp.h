@@ -299,8 +299,8 @@ ATTWARP_API int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int
  *      attwarp_pil_coeffs_8bpc computes them on the host, callers cache them per distinct size;
  *   2. attwarp_ragged_table_bytes(...) -> size; attwarp_ragged_plan(...) writes the table into HOST memory: an
  *      attwarp_ragged_header (public, below: buffer sizes the caller must provide) followed by per-image records, numpy's
- *      pairwise-summation plans of the distinct widths / heights and the block maps of the stages whose block count
- *      depends on the image;
+ *      pairwise-summation plans of the distinct widths / heights, the block maps of the stages whose block count
+ *      depends on the image and the order in which the stages visit the images (largest first);
  *   3. copy table_bytes to the device (any 8-byte aligned address);
  *   4. attwarp_mask_chain_ragged(...) with the host AND the device copy of each stage's table.
  * Limits (ATTWARP_E_UNSUPPORTED from attwarp_ragged_plan otherwise; use the per-image entry points then): rows of 4 ..
@@ -323,7 +323,7 @@ typedef struct attwarp_ragged_header {             /* first bytes of a table wri
   uint64_t mota_bytes;                             /* the batch's up-sampled masks, packed: uint8 buffer of this size */
   uint64_t sums_bytes;                             /* the batch's axis-sum workspace (float64) */
   uint64_t lds_bytes;
-  uint64_t off_images, off_plans, off_lmap, off_pmap;
+  uint64_t off_images, off_plans, off_lmap, off_pmap, off_order;
 } attwarp_ragged_header;
 
 /* HOST: Pillow's ImagingResample coefficient tables for an 8-bit image (precompute_coeffs + normalize_coeffs_8bpc,

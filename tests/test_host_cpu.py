@@ -531,9 +531,12 @@ def test_ragged_plan_table_layout_without_gpu(lib):
         nL += nstrips * r.l_nchunks; nP += int(pw[0])
     assert h.mota_bytes >= mota_end and h.sums_bytes == sums_end * 8 and (h.nL, h.nP) == (nL, nP)
     lmap = np.frombuffer(buf, np.uint32, h.nL, h.off_lmap); pmap = np.frombuffer(buf, np.uint32, h.nP, h.off_pmap)
+    # the stages visit the images largest first (stable): the longest blocks of a launch start first
+    order = np.frombuffer(buf, np.uint32, B, h.off_order).tolist()
+    assert order == sorted(range(B), key=lambda b: -sizes[b][0] * sizes[b][1]) and order[:3] == [2, 0, 1]
     for m, per in ((lmap, [-(-w // 256) * img[b].l_nchunks for b, (_, w) in enumerate(sizes)]),
                    (pmap, [int(praw[img[b].plan_w][0]) for b in range(B)])):
-        want = [(b, s) for b in range(B) for s in range(per[b])]
+        want = [(b, s) for b in order for s in range(per[b])]
         assert [(int(e & 0xffff), int(e >> 16)) for e in m] == want
     # limits
     def rc(sz, C=3, Ho=500, Wo=500, g=24):

@@ -3,6 +3,7 @@
 usage: python tools/gantt.py chain B S So [tune=key:value,...]      mask_chain_step_kernel   (kinds F V P L R)
        python tools/gantt.py step B S [f16] [tune=...]              warp_step_kernel         (kinds M A R)
        python tools/gantt.py remap B S [exact] [tune=...]           remap_rows_kernel        (the float32 resample alone)
+       python tools/gantt.py ragged B [tune=...]                    mask_chain_ragged_kernel (TextVQA-like size mix, -> 500 x 500)
 Prints, for the LAST step of a graph-replayed stream in its steady state: when each kind of block starts and ends, how long
 its blocks take, how many blocks are resident over time (2 us bins) and which kind holds the tail of the launch."""
 import os, sys, time, contextlib
@@ -39,6 +40,28 @@ if what == "chain":
         run(K); torch.cuda.synchronize()
     depth = mc.depth
     run_steady = lambda: mc.run(K)
+elif what == "ragged":
+    B = int(pos[1])
+    names = {0: "F finalize", 1: "V revise", 2: "P marginals", 3: "L lanczos", 4: "R resample", -1: "(padding)"}
+    WH = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]
+    sizes = [WH[b % len(WH)] for b in range(B)]
+    px = sum(w * h for (w, h) in sizes)
+    n = max(6, min(24, -(-(1 << 30) // (3 * px + 3 * B * 250000))))
+    g = torch.Generator(device=dev).manual_seed(B)
+    ring = []
+    for _ in range(n):
+        rb = pipeline.RaggedBatch([torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes], (500, 500))
+        rb.masks = torch.rand(B, 24, 24, device=dev, generator=g)
+        ring.append(rb)
+    st_ = pipeline.RaggedMaskChainStream(out_size=(500, 500))
+    st_.ring(ring)
+    depth = 0
+    ctx = _lib.debug_override(**over)
+    ctx.__enter__()          # eager launches: the overrides stay on for the whole run
+    st_.prime()
+    def run_steady():
+        st_.run(K)
+    run_steady(); torch.cuda.synchronize()
 elif what == "remap":
     from attwarp_amd import checkpoint_utils as cu
     B, S = int(pos[1]), int(pos[2])
