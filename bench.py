@@ -392,6 +392,18 @@ def calibration_of(step, n: int = 20):
             "achieved": round(alg / (mean * 1e-3) / 1e9, 1), "frac": round(alg / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
+def pmc_traffic_source(workload: str, mode: str) -> str:
+    """Where `roofline.traffic` comes from: NOT counters of this run (PMC passes need the profiler) but the committed summary
+    of separate rocprofv3 --pmc passes over this same command; the lease they were collected on is recorded with them."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            e = json.load(f).get(f"{workload}_{mode}", {})
+        return ("profiles/pmc_traffic.json: a COMMITTED constant, not a counter read in this run -- separate rocprofv3 --pmc "
+                f"FETCH_SIZE / WRITE_SIZE passes of this command (lease: {e.get('lease', 'unrecorded')}; {e.get('same_lease_as', '')})")
+    except Exception:
+        return "profiles/pmc_traffic.json (committed constant)"
+
+
 def load_pmc_traffic(workload: str, mode: str):
     """HBM bytes per launch of the remap kernel from the committed rocprofv3 --pmc summary
     (profiles/pmc_traffic.json, collected with this same command).  None if absent."""
@@ -494,12 +506,21 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn
     # form on the same ring; the faster one is the line, the other is attached (B=256: equal within noise, not run).
     paired = None
     if B * S * S <= 64 * 336 * 336 and ow.n % 2 == 0 and K % 2 == 0 and K >= 8 and layout in ("hwc", "chw"):
+        # construction and warm-up can fail on ONE rank only (out of memory, an ineligible shape): the ranks first agree --
+        # a collective OUTSIDE any try -- that all of them are ready, and only then enter the timed collectives together
+        pw, err = None, ""
         try:
             pw = pipeline.PairedStepWarp([x[0] for x in st.sets], [x[1] for x in st.sets], st.starts,
                                          channels_last=(layout == "hwc"), mode=mode)
             def run_pw():
                 pw.reset(); pw.prime(); pw.run(K - 4); pw.tail()      # exactly K of each piece of work
             run_pw(); run_pw()
+            torch.cuda.synchronize()
+        except Exception as e:                     # (an ineligible shape keeps the one-launch-per-batch line)
+            pw, err = None, str(e)[:200]
+        if D.max_over_ranks(0.0 if pw is not None else 1.0) > 0.0:
+            paired = {"unavailable": err or "another rank could not build the paired step"}
+        else:
             D.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             run_pw()
@@ -514,9 +535,7 @@ def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn
                 del ref
             paired = {"ms_per_step": round(wall_p / K * 1e3, 4), "images_per_s": round(B * K / wall_p, 1),
                       "bit_identical_to_serial": same_p, "wall": wall_p, "wall_local": wall_p_local}
-            del pw
-        except Exception as e:                     # (an ineligible shape keeps the one-launch-per-batch line)
-            paired = {"unavailable": str(e)[:200]}
+        del pw
     w_e, _ = time_steps(st, K, W, D)
     sb = step_bytes(B, S, esize)
     one = {"ms_per_step": round(wall / K * 1e3, 4), "images_per_s": round(B * K / wall, 1), "bit_identical_to_serial": same}
@@ -552,7 +571,8 @@ def traffic_note(roof):
     if roof.get("traffic") is None:
         roof["traffic_source"] = "null: no rocprofv3 --pmc pass committed for this variant (profiles/pmc_traffic.json)"
     else:
-        roof["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on an earlier lease)"
+        roof["traffic_source"] = ("profiles/pmc_traffic.json: a COMMITTED constant (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes; the lease is recorded in that file), not a counter read in this run")
     return roof
 
 
@@ -666,7 +686,7 @@ def leg_main_batched_ragged(dev, torch, pipeline, K):
     out = {"workload": "uint8 images of different sizes [H_i,W_i,3] + attention maps [B,24,24] -> main_batched chain -> "
                        "[B,500,500,3] uint8, mode=cv2, transform=identity", "unit": "images/s", "steps": K,
            "sizes_WxH": TEXTVQA_LIKE_WH, "cases": []}
-    for B in (32, 256):
+    for B in (32, 64, 256):      # (64: two of the driver's batches of 32 as ONE ragged batch -- free for ragged batches, any sizes mix)
         sizes = [TEXTVQA_LIKE_WH[b % len(TEXTVQA_LIKE_WH)] for b in range(B)]
         px = sum(w * h for (w, h) in sizes)
         slot = 3 * px + 3 * B * So * So
@@ -922,7 +942,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=3,
+                    help="W untimed warm-up steps of the timed loop itself.  They run BEHIND the device pre-conditioning of "
+                         "--prewarm (also untimed, reported as `prewarm_steps` in the JSON line): the untimed work in front of "
+                         "the K timed steps is prewarm + W, and `--prewarm 0` makes it exactly W")
+    ap.add_argument("--prewarm", type=int, default=-1,
+                    help="untimed device pre-conditioning in front of the warm-up: steps of the 1024 workload (default "
+                         f"{PREWARM_STEPS}: the first ~20 launches of a process run 1-2 %% slower, clock ramp) / tenths of a second of "
+                         "graph replays for the 336 workloads (default 5); 0 = none")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["config5", "main_batched", "main_batched_ragged"], default="1024")
     ap.add_argument("--mode", choices=["cv2", "exact"], default="cv2", help="resample arithmetic of the main line")
     ap.add_argument("--layout", choices=["hwc", "chw"], default="hwc")
@@ -1046,7 +1073,8 @@ def main():
         # configs[1] / configs[3]: the step is ~0.09-0.25 ms, so the timed loop is a HIP-graph replay with no host call
         # per kernel (the eager three-launch line with HIP events is attached as "also_eager")
         res, wall, wall_local, step, ow = small_workload(B, S, dev, 1234 + rank, args.mode, args.layout, args.steps,
-                                                         args.warmup, D, torch, pipeline, prewarm_s=PREWARM_SMALL_S)
+                                                         args.warmup, D, torch, pipeline,
+                                                         prewarm_s=PREWARM_SMALL_S if args.prewarm < 0 else args.prewarm / 10.0)
         roof = res["eager"]["roofline"]
         roof["measured_in"] = "the eager pass right after the timed graph region (a graph replay has no per-kernel events)"
         extra = {"step_algorithmic_bytes": res["step_algorithmic_bytes"], "step_TBps": res["step_TBps"],
@@ -1058,7 +1086,8 @@ def main():
         step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
         # device pre-conditioning, untimed and outside the contract's W warm-up steps: the first ~20 launches after
         # start-up run 1-2 % slower (clock ramp), which would only penalise whichever measurement comes first.
-        for _ in range(PREWARM_STEPS):
+        n_prewarm = PREWARM_STEPS if args.prewarm < 0 else args.prewarm
+        for _ in range(n_prewarm):
             step()
         torch.cuda.synchronize()
         # (a) the plain step: reduce -> maps -> resample of ONE batch, three eager launches (reported as "also_eager")
@@ -1080,8 +1109,7 @@ def main():
         wall, wall_local = time_steps(main_step, args.steps, args.warmup, D)
         roof = roofline_of(main_step, load_pmc_traffic(args.workload, args.mode))
         if roof["traffic"] is not None:                 # a committed constant, not a counter read in this run
-            roof["traffic_source"] = ("profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "command on an earlier lease)")
+            roof["traffic_source"] = pmc_traffic_source(args.workload, args.mode)
         ref_main = pipeline.warp_from_attention_stack(step.sets[0][0], step.sets[0][1], step.starts,
                                                       channels_last=(args.layout == "hwc"), mode=args.mode)
         extra = {"bit_identical_to_serial": bool(torch.equal(main_step.ow.out, ref_main)),
@@ -1110,7 +1138,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "prewarm_steps": getattr(time_overlapped, "prewarm_steps", 0) if small else PREWARM_STEPS,
+        "prewarm_steps": getattr(time_overlapped, "prewarm_steps", 0) if small else n_prewarm,
         "config": {"workload": workload_txt, "mode": args.mode, "batch_per_gpu": B, "image_size": S,
                    "layout": args.layout.upper(), "global_batch": world * B, "rotating_batches": nrot,
                    "sharding": "contiguous image blocks per rank, no data-path collective"},

@@ -230,7 +230,43 @@ def g_mask_chain_stream():
         ok = ok and bool(torch.equal(mc.outs[j % n], pipeline.warp_from_masks(imgs[j % n], msk[j % n], (Ho, So))))
     return ok, (B, S, So, Ho, n, nb, mc.pattern)
 
-for name, gen in (("MaskChainStream vs warp_from_masks", g_mask_chain_stream), ("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
+def g_ragged_chain():
+    """pipeline.warp_from_masks_ragged / RaggedMaskChainStream on batches of random sizes (unaligned widths, sides near the
+    24-pixel limit, rows up to the 4096-byte limit, ineligible images mixed in): every image against the per-image drop-in
+    (warp_from_masks on a batch of one, itself checked against the oracle above) and one image per batch against the oracle."""
+    B = int(rng.integers(1, 9)); Ho, Wo = int(rng.integers(3, 300)), int(rng.integers(2, 400))
+    def side():
+        r = rng.random()
+        return int(rng.integers(25, 90)) if r < 0.4 else int(rng.integers(90, 500)) if r < 0.85 else int(rng.integers(500, 1366))
+    nb = int(rng.integers(1, 7))
+    batches = []
+    for _ in range(nb):
+        sizes = [(side(), side()) for _ in range(B)]
+        if rng.random() < 0.15: sizes[0] = (int(rng.integers(8, 25)), side())          # not eligible: falls back per image
+        if rng.random() < 0.1: sizes[-1] = (side(), int(rng.integers(1366, 1800)))     # rows wider than 4096 bytes: likewise
+        batches.append(([T(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for (h, w) in sizes],
+                        T(rng.random((B, 24, 24), dtype=np.float32) ** int(rng.integers(1, 5)))))
+    ok = True
+    outs = [pipeline.warp_from_masks_ragged(i, a, (Ho, Wo)) for (i, a) in batches]
+    for (imgs, att), out in zip(batches, outs):
+        for b in range(B):
+            ok = ok and bool(torch.equal(out[b], pipeline.warp_from_masks(imgs[b][None], att[b:b + 1], (Ho, Wo))[0]))
+    imgs, att = batches[0]
+    b = int(rng.integers(0, B)); h, w = int(imgs[b].shape[0]), int(imgs[b].shape[1])
+    rev = N(ae.revise_mask(att[b:b + 1]))[0]
+    ref = O.warp_image_by_attention(N(imgs[b]), O.lanczos_resize_u8(O.mask_to_u8(rev), w, h), Wo, Ho, "identity")
+    ok = ok and np.array_equal(N(outs[0][b]), ref)
+    if all(pipeline.ragged_eligible(int(i.shape[0]), int(i.shape[1]), 3) for (im, _) in batches for i in im) and Wo * 3 <= 4096:
+        st = pipeline.RaggedMaskChainStream(out_size=(Ho, Wo))
+        got = []
+        for (im, a) in batches:
+            d = st.push(im, a)
+            if d is not None: got.append(d.out)
+        got += [d.out for d in st.flush()]
+        ok = ok and len(got) == nb and all(bool(torch.equal(g, o)) for g, o in zip(got, outs))
+    return ok, (B, nb, Ho, Wo, [tuple(i.shape[:2]) for i in imgs])
+
+for name, gen in (("ragged chain vs per-image + oracle", g_ragged_chain), ("MaskChainStream vs warp_from_masks", g_mask_chain_stream), ("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
                   ("warp_image_by_attention chain", g_chain_u8), ("attention stack -> warp (bench path)", g_stack_chain),
                   ("attention_axis_maps (A13)", g_att_maps), ("axis_maps_from_pdf (A8-A11)", g_pdf_chain),
                   ("cdf / repair / resample (A9-A10)", g_cdf_stages), ("attn reduce step (A1)", g_attn),

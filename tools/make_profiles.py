@@ -3,8 +3,8 @@ under profiles/: kernel-stats table, HBM traffic of the resample kernel from the
 bench lines, stage / chain benches.   usage: make_profiles.py [src_tag] [name]   (default r2 round2)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src_tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
-tag = sys.argv[2] if len(sys.argv) > 2 else "round4"
+src_tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[2] if len(sys.argv) > 2 else "round5"
 SRC = os.path.join(ROOT, "gpurun_out", src_tag)
 DST = os.path.join(ROOT, "profiles")
 
@@ -70,16 +70,20 @@ for mode in ("cv2", "exact", "cv2_chw"):
                 f"--no-also --steps 5 --mode {mode.split('_')[0]}{' --layout chw' if mode.endswith('_chw') else ''}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
                 f"MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}
     print(mode, "traffic ratio", total / alg)
+lease = open(os.path.join(SRC, "lease.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(SRC, "lease.txt")) else "unrecorded"
+for v in traffic.values():
+    v["lease"] = lease
+    v["same_lease_as"] = f"profiles/{tag}_bench.json, {tag}_bench_kernel_stats.* (one run of tools/refresh_profiles.sh {src_tag})"
 json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 bench_line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, f"{tag}_bench.json"), "w").write(bench_line)
-for name in ("bench_336", "bench_336x256", "bench_main_batched", "bench_config5", "bench_force_dist"):
+for name in ("bench_336", "bench_336x256", "bench_main_batched", "bench_main_batched_ragged", "bench_config5", "bench_force_dist"):
     if os.path.exists(os.path.join(SRC, f"{name}.json")):
         open(os.path.join(DST, f"{tag}_{name}.json"), "w").write([l for l in open(os.path.join(SRC, f"{name}.json")) if l.startswith("{")][-1])
 for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench", "chain_stream",
              "pair_step", "chain_step_kernel_stats", "remap_lines", "timeline_chain_32_336_500", "timeline_chain_64_336_500",
              "timeline_chain_256_1024_500", "timeline_step_64_336", "timeline_step_256_336", "timeline_remap_256_1024",
-             "timeline_remap_256_336"):
+             "timeline_remap_256_336", "timeline_ragged_32", "timeline_ragged_256", "bounds", "ragged_kernel_stats"):
     if os.path.exists(os.path.join(SRC, f"{name}.txt")):
         shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)

@@ -5,6 +5,7 @@ targets
   remap [B S] [peaked] [key=value ...]   float32 resample at BASELINE configs[2]; key=value: attwarp_debug_set overrides
   chain [B S So]             every kernel of the main_batched chain (pipeline.warp_from_masks), default 256 1024 500
   chain_step [B S So]        the one-launch chain step (pipeline.MaskChainStream pattern "fused")
+  ragged [B]                 the ragged chain (TextVQA-like size mix -> 500 x 500): five launches per batch, then the one-launch stream step
   attn                       attention reduce, float32 + float16 rows, bench shape
   steps                      attention reduce + axis_maps_from_steps at the bench shapes
   steps summarize <csv>      per-grid-size medians of a --kernel-trace CSV of the above
@@ -65,6 +66,19 @@ elif target in ("chain", "chain_step"):
         mc.prime()
         for _ in range(12):
             mc.step()
+elif target == "ragged":
+    B = ints[0] if ints else 32
+    WH = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]
+    g = torch.Generator(device=dev).manual_seed(B)
+    ring = []
+    for _ in range(6):
+        rb = pipeline.RaggedBatch([torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in (WH[b % 6] for b in range(B))], (500, 500))
+        rb.masks = torch.rand(B, 24, 24, device=dev, generator=g)
+        ring.append(rb)
+    for _ in range(3):
+        pipeline.warp_from_masks_ragged(ring[0].images, ring[0].masks, (500, 500))
+    st = pipeline.RaggedMaskChainStream(out_size=(500, 500))
+    st.ring(ring); st.prime(); st.run(24); st.drain_ring()
 elif target == "attn":
     B = 256
     rows = torch.softmax(torch.randn(20, B, 32, 640, device=dev), -1)

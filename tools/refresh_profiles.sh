@@ -3,10 +3,12 @@
 # under gpurun_out/<tag>/.  tools/make_profiles.py turns it into the committed summaries.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"   # (on the GPU box; gpurun merges into the local gpurun_out/, where older files may remain)
 cd /tmp && export TMPDIR=/tmp
+# which lease this is: every number under $OUT -- the bench line AND the PMC traffic passes -- comes from this one box
+{ echo "host $(hostname)  $(date -u +%Y-%m-%dT%H:%M:%SZ)"; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -1; } > $OUT/lease.txt
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # the headline agreement: ONLY the main measurement (25 pre-conditioning + 3 warm-up + 20 timed steps), so that the
 # average duration of remap_rows_kernel in the stats is the average of the launches bench.py times
@@ -31,11 +33,17 @@ python3 $ROOT/tools/probe_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/probe_bench.
 python3 $ROOT/tools/remap_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_bench.txt
 python3 $ROOT/tools/chain_stream_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/chain_stream.txt
 python3 $ROOT/tools/pair_step_bench.py 2>&1 | grep -v amdgpu.ids > $OUT/pair_step.txt
-for c in "chain 32 336 500" "chain 64 336 500" "chain 256 1024 500" "step 64 336" "step 256 336" "remap 256 1024" "remap 256 336"; do
+for c in "chain 32 336 500" "chain 64 336 500" "chain 256 1024 500" "step 64 336" "step 256 336" "remap 256 1024" "remap 256 336" "ragged 32" "ragged 256"; do
   python3 $ROOT/tools/gantt.py $c bin=8 2>&1 | grep -v amdgpu.ids > "$OUT/timeline_$(echo $c | tr ' ' _).txt"
 done
 python3 $ROOT/tools/remap_lines.py 2>&1 | grep -v amdgpu.ids > $OUT/remap_lines.txt
 python3 $ROOT/bench.py --workload main_batched > $OUT/bench_main_batched.json 2> $OUT/bench_main_batched.err
+python3 $ROOT/bench.py --workload main_batched_ragged > $OUT/bench_main_batched_ragged.json 2> $OUT/bench_main_batched_ragged.err
+bash $ROOT/tools/bounds.sh 2>&1 | grep -v amdgpu.ids > $OUT/bounds.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ragged_trace -- python3 $ROOT/tools/prof.py ragged 32 > /dev/null 2>&1
+python3 $ROOT/tools/kstats.py $(find $OUT/ragged_trace -name "*kernel_stats.csv" | head -1) > $OUT/ragged_kernel_stats.txt
+rm -rf $OUT/ragged_trace
+cd /tmp
 python3 $ROOT/bench.py --workload config5 > $OUT/bench_config5.json 2> $OUT/bench_config5.err
 python3 $ROOT/bench.py --gpus 1 --force-dist --no-cpu-baseline --legs none > $OUT/bench_force_dist.json 2> $OUT/bench_force_dist.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/chain_step_trace -- python3 $ROOT/tools/prof.py chain_step 256 1024 500 > /dev/null 2>&1
