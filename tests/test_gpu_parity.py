@@ -1779,6 +1779,33 @@ def test_integration_md_stub_runs(dev):
         ns["warp_from_cdf_torch"](T(img, dev), T(Fx[:, :50], dev), T(Fy, dev))
 
 
+def test_integration_md_driver_loop_snippet_runs(dev, tmp_path):
+    """The replacement INTEGRATION.md shows for the per-sample block of AGW/main_batched.py:243-287, exec'd as written on
+    stand-ins for the driver's variables (PIL images of different sizes, 24 x 24 maps): the PNGs it writes hold what the
+    reference's chain computes (oracle; `cv2.imwrite` of its BGR result = this RGB array), the saved mota masks are blend_mask's."""
+    import re, types
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(from attwarp_amd import pipeline\nimgs = pipeline.upload_images.*?)```", text, re.S).group(1)
+    rng = np.random.default_rng(62)
+    sizes = [(61, 100), (90, 77), (64, 64)]
+    host = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for (h, w) in sizes]
+    att = [torch.rand(24, 24, device=dev) ** 2 for _ in sizes]
+    wdir, adir = tmp_path / "warped", tmp_path / "att"
+    wdir.mkdir(); adir.mkdir()
+    ns = dict(b_images=[Image.fromarray(h) for h in host], attn_maps=att, model=types.SimpleNamespace(device=dev), torch=torch, np=np,
+              os=os, Image=Image, DEFAULT_HEIGHT=80, DEFAULT_WIDTH=88, enhance_coe=10, kernel_size=3, current_bs=len(sizes),
+              sample_id=lambda j: f"img{j}", WARPED_IMAGES_DIR=str(wdir), ATTENTION_MAPS_DIR=str(adir))
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    for j, (h, w) in enumerate(sizes):
+        rev = N(__import__("attwarp_amd").attention_extraction.revise_mask(att[j][None]))[0]
+        mota = O.lanczos_resize_u8(O.mask_to_u8(rev), w, h)
+        assert np.array_equal(np.load(adir / f"img{j}_mota_mask.npy"), mota)
+        ref = O.warp_image_by_attention(host[j], mota, 88, 80, "identity")
+        assert np.array_equal(np.asarray(Image.open(wdir / f"img{j}_identity.png")), ref)
+
+
 def test_hook_plumbing_with_dummy_decoder(dev):
     """batch_hook_logger on a stand-in model: the hook is registered on layers[i].self_attn, the patched
     forward forces output_attentions=True for that layer only, and generation steps accumulate."""

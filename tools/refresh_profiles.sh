@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"   # (on the GPU box; gpurun merges into the local gpurun_out/, where older files may remain)
 cd /tmp && export TMPDIR=/tmp
 # which lease this is: every number under $OUT -- the bench line AND the PMC traffic passes -- comes from this one box
-{ echo "host $(hostname)  $(date -u +%Y-%m-%dT%H:%M:%SZ)"; rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -1; } > $OUT/lease.txt
+{ echo "host $(hostname)  $(date -u +%Y-%m-%dT%H:%M:%SZ)"; rocm-smi --showuniqueid 2>/dev/null | grep -i "GPU\[" | head -1; } > $OUT/lease.txt
 python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # the headline agreement: ONLY the main measurement (25 pre-conditioning + 3 warm-up + 20 timed steps), so that the
 # average duration of remap_rows_kernel in the stats is the average of the launches bench.py times
