@@ -50,7 +50,8 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   const long long VL = (long long)p.NP * p.row_len, OVL = (long long)p.NP * p.orow_len;
   // LDS indices are 16 bit and the tap tables live in VGPRs: up to 4096 floats per staged row.  Wider interleaved /
   // one-plane rows are processed in column tiles; wider multi-plane rows take the generic kernel.
-  const bool tiled = VL > 4096 || OVL > 4096;
+  // (tuning flavour, remap_tiled = 2: column tiles also for rows that fit the LDS row -- the experiment of round 5)
+  const bool tiled = VL > 4096 || OVL > 4096 || (tune(TUNE_REMAP_TILED) == 2 && p.NP == 1 && !ua && !ex);
   if (ua && (tiled || VL < 4 || p.NP != 1)) return ATTWARP_OK;
   p.unaligned = ua ? 1 : 0;
   if (tiled && (p.NP != 1 || VL > 2147483647LL / 8 || OVL > 2147483647LL / 8)) return ATTWARP_OK;
@@ -71,7 +72,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
   // Measured, 2048x2048x3 float32 B=64 (near-identity / peaked maps): KO=8 R=8 5.1 / 5.2 TB/s, KO=12 R=8 5.2 / 4.3
   // (more tiles on the direct path), generic gather kernel 2.4.
   int TILE_KO = 8;
-  if (const int v = tune(TUNE_REMAP_TILE_KO); v == 8 || v == 12) TILE_KO = v;
+  if (const int v = tune(TUNE_REMAP_TILE_KO); v == 8 || v == 12 || v == 4) TILE_KO = v;
   if (tiled) p.ntiles = (int)((OVL + TILE_KO * NT_BIG - 1) / (TILE_KO * NT_BIG));
   const long long row_bytes = tiled ? (long long)TILE_KO * NT_BIG * 4 : VL * 4;
   // (4 KB rows, 336x336x3: R=6 4.85 TB/s, R=12 4.62 at B=256; flat at B=64)

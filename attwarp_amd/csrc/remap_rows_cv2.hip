@@ -6,7 +6,7 @@ namespace attwarp {
 
 int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st, const StepExtra* ex) {
   if (ex) return launch_step_cv2(p, tile_ko, st, ex);
-  const int ki = tile_ko == 12 ? 4 : tile_ko == 8 ? 3 : (p.VLV + NT_BIG - 1) / NT_BIG;
+  const int ki = tile_ko == 12 ? 4 : tile_ko == 8 ? 3 : tile_ko == 4 ? 2 : (p.VLV + NT_BIG - 1) / NT_BIG;
   // Rows of <= 12 KB: two [top | bottom] buffers, one barrier per row (<= 48 KB of LDS).  Wider rows: ONE buffer and two
   // barriers per row (two buffers would not fit the 64 KB a launch gets by default).  History of the 8-12 KB class
   // (1024x1024x3, B=256): with the row loop of rounds 1-3 the one-buffer form won (1.157 against 1.181 ms: 48 KB leave 3

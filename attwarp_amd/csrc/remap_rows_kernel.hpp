@@ -700,6 +700,16 @@ static int launch_rows_mode(const RowsParams& p, int tile_ko, hipStream_t st, co
   if constexpr (FUSED) {
     if (tile_ko != 0) return fail(ATTWARP_E_UNSUPPORTED, "warp_step_fused: rows wider than 4096 floats are not fused");
   } else {
+#ifdef ATTWARP_TUNING
+    if (tile_ko == 4) {     // round-5 experiment: 1024-float column tiles (4 KB, like the rows of a planar batch)
+      if constexpr (KIMIN <= 2 && 2 <= KIMAX) {
+        const size_t lds = rows_lds_bytes<MODE, SINGLE>(2, NT) + (size_t)p.lds_pad;
+        hipLaunchKernelGGL((remap_rows_kernel<NT, 2, 4, true, false, true, MODE, SINGLE>), dim3(p.nblocks), dim3(NT), lds, st, p);
+        return check_launch("remap_rows_kernel");
+      }
+      return fail(ATTWARP_E_UNSUPPORTED, "remap_rows: tile variant not built");
+    }
+#endif
     if (tile_ko == 8) {
       if constexpr (KIMIN <= 3 && 3 <= KIMAX) {
         const size_t lds = rows_lds_bytes<MODE, SINGLE>(3, NT) + (size_t)p.lds_pad;
