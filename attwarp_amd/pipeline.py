@@ -975,6 +975,7 @@ _RAGGED_IMAGE_DTYPE = np.dtype([("image", "<u8"), ("bounds_x", "<u8"), ("kk_x", 
                                 ("H", "<i4"), ("W", "<i4"), ("ksize_x", "<i4"), ("reserved", "<i4")])      # attwarp_ragged_image
 _AXIS_TABLES: dict = {}
 _STAGING: list = []                   # pinned staging buffers: [tensor, event of the last copy out of it]
+_STAGING_LOCK = __import__("threading").Lock()     # (host threads on their own streams share the pool)
 
 
 def _axis_tables(g: int, n: int, dev: torch.device):
@@ -990,20 +991,25 @@ def _axis_tables(g: int, n: int, dev: torch.device):
 def _upload(host: "np.ndarray", dst: torch.Tensor):
     """host bytes -> dst (device uint8), asynchronously on the current stream through a pooled pinned buffer."""
     n = host.size
-    slot = None
-    for s in _STAGING:
-        if s[0].numel() >= n and s[1].query():
-            slot = s
-            break
-    if slot is None:
-        slot = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event()]
-        _STAGING.append(slot)
-        if len(_STAGING) > 64:            # (only if nothing ever completes: keep the pool bounded)
-            torch.cuda.synchronize()
-            del _STAGING[:-1]
-    slot[0][:n].numpy()[:] = host
-    dst.copy_(slot[0][:n], non_blocking=True)
-    slot[1].record()
+    with _STAGING_LOCK:
+        slot = None
+        for s in _STAGING:
+            if s[0].numel() >= n and s[2] and s[1].query():
+                slot = s
+                break
+        if slot is None:
+            if len(_STAGING) >= 64:           # (only if nothing ever completes: keep the pool bounded)
+                torch.cuda.synchronize()
+                del _STAGING[1:]
+            slot = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event(), True]
+            _STAGING.append(slot)
+        slot[2] = False                       # taken: nobody else may pick it until its copy has been enqueued and recorded
+    try:
+        slot[0][:n].numpy()[:] = host
+        dst.copy_(slot[0][:n], non_blocking=True)
+        slot[1].record()
+    finally:
+        slot[2] = True
 
 
 class RaggedBatch:
