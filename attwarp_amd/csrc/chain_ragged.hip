@@ -141,12 +141,28 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
     const float* mx_b = a.map_x + (size_t)b * a.Wo;
     const float* my_b = a.map_y + (size_t)b * a.Ho;
     float* smem = reinterpret_cast<float*>(pool);
-    switch (im.ki) {     // block uniform (rows requested ahead: as launch_u8i_depth, remap_u8.hip)
-      case 1: u8k::remap_rows_u8i_rows<1, KD, true, 4, true>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem); break;
-      case 2: u8k::remap_rows_u8i_rows<2, KD, true, 4, true>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem); break;
-      case 3: u8k::remap_rows_u8i_rows<3, KD, true, 2, true>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem); break;
-      default: u8k::remap_rows_u8i_rows<4, KD, true, 2, true>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem); break;
+    // block uniform: source dwords per thread (rows requested ahead: as launch_u8i_depth, remap_u8.hip) x whether THIS image's
+    // rows are dword aligned -- the unaligned form holds two aligned dwords per row dword until the row is consumed, so it
+    // requests its rows half as far ahead to stay inside the kernel's register budget
+    const bool ua = ((p.row_len | (int)(reinterpret_cast<uintptr_t>(im.image) & 3u)) & 3) != 0;
+#define ATTWARP_RAGGED_R(KI_, PD_, UA_) \
+    u8k::remap_rows_u8i_rows<KI_, KD, true, PD_, UA_>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem)
+    if (!ua) {
+      switch (im.ki) {
+        case 1: ATTWARP_RAGGED_R(1, 4, false); break;
+        case 2: ATTWARP_RAGGED_R(2, 4, false); break;
+        case 3: ATTWARP_RAGGED_R(3, 2, false); break;
+        default: ATTWARP_RAGGED_R(4, 2, false); break;
+      }
+    } else {
+      switch (im.ki) {
+        case 1: ATTWARP_RAGGED_R(1, 4, true); break;
+        case 2: ATTWARP_RAGGED_R(2, 2, true); break;
+        case 3: ATTWARP_RAGGED_R(3, 1, true); break;
+        default: ATTWARP_RAGGED_R(4, 1, true); break;
+      }
     }
+#undef ATTWARP_RAGGED_R
   }
   return kind;
 }

@@ -388,6 +388,7 @@ static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout
             ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) != 0 ||
             (layout == ATTWARP_HWC ? ((long long)H * W * C) % 4 != 0 || ((long long)Ho * Wo * C) % 4 != 0
                                    : ((long long)H * W) % 4 != 0 || ((long long)Ho * Wo) % 4 != 0);
+  if (tune(TUNE_BOUND) > 0 && (tune(TUNE_BOUND) & 16) && mode == ATTWARP_CV2 && layout == ATTWARP_HWC) ua = true;   // experiment: the UA form on aligned data
   if (ua && (mode != ATTWARP_CV2 || tune(TUNE_REMAP_VARIANT) == 2)) return false;
   p.map_div = 1;
   p.ntiles = 1;

@@ -56,10 +56,14 @@ constexpr size_t u8i_lds_bytes() { return (size_t)RMAX * sizeof(float) + 2 * (si
 // row_len, VL, ..., R, nblk, wpi); p.src / p.dst / p.mx / p.my / p.img_stride are not read here, so the ragged chain
 // (chain_ragged.hip) can fill a Params per image from its descriptor table.  smem: u8i_lds_bytes() of LDS.
 // UA ("unaligned", interleaved images only): rows whose byte length is not a multiple of 4 and images that start anywhere
-// -- e.g. 683 x 3 bytes per row, the portrait TextVQA case.  The loads and stores stay dwords relative to the ROW start
-// (gfx950 runs with unaligned access mode on: a wave's 256 contiguous bytes at a byte offset touch one more cache line);
-// only the LAST dword of a row differs: it is loaded END-aligned (the four bytes that end with the row: nothing behind
-// the image is ever read) and shifted down in registers, and the last output dword of a row is stored byte by byte.
+// -- e.g. 683 x 3 bytes per row, the portrait TextVQA case.  gfx950 does serve dword loads at any byte address, but at a
+// price: a wave's 64 misaligned dwords cost ~40 % of this kernel's time (tools/ua_cost.py: 684-wide images from a view
+// that starts one byte in: 0.192 ms against 0.138 ms).  So the loads stay ALIGNED: the buffer descriptor starts at the
+// image's base rounded down to a dword, a row's scalar offset is rounded down likewise, every thread loads the aligned
+// dword its row dword starts in AND the next one, and one v_alignbyte_b32 with the row's (block-uniform) byte shift puts
+// the row dword together when the row is consumed.  Nothing behind the image's last aligned dword is read (the descriptor
+// ends there: a dword that begins behind it returns 0 and only ever supplies bytes behind the row's end).  The last output
+// dword of a row is stored byte by byte; output dwords in front of it are dword stores at the row's own offset.
 template <int KI, int KD, bool HWC, int PD, bool UA>
 __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8_t* src_b, int img_bytes, uint8_t* dst_b,
                                                     int oimg_bytes, const float* mx_b, const float* my_b, int rb0, float* smem) {
@@ -71,13 +75,14 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
   uint16_t* vrow1 = vrow0 + U8I_VLP;
   const int tid = threadIdx.x;
   // per-image buffer descriptors (block uniform; images are < 2 GiB: plane_stride * NP is checked by the host)
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src_b), 0, img_bytes, 0x00020000);
+  const unsigned base_sh = UA ? (unsigned)(reinterpret_cast<uintptr_t>(src_b) & 3u) : 0u;      // block uniform
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t*>(src_b) - base_sh, 0, UA ? (int)((img_bytes + base_sh + 3u) & ~3u) : img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdst = __builtin_amdgcn_make_buffer_rsrc(dst_b, 0, oimg_bytes, 0x00020000);
 
   // source dwords this thread owns (clamped: padding lanes repeat the last dword)
   unsigned goff[KI];                // byte offset inside the image (row 0): unsigned, so the loads take the SGPR-base form
   int voff[KI];                     // u16 index in the LDS row
-  unsigned tail_shr = 0;            // UA: the thread that owns the row's last, partial dword shifts it down by this many bits
   {
     const int dpr = p.row_len >> 2, nd = UA ? (p.VL + 3) >> 2 : p.VL >> 2;
 #pragma unroll
@@ -86,10 +91,6 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
       const int pl = HWC ? 0 : d / dpr;
       goff[k] = (unsigned)(pl * p.plane_stride) + 4u * (unsigned)(d - pl * dpr);
       voff[k] = 4 * d;
-      if (UA && k == KI - 1 && 4 * d + 4 > p.VL) {     // (KI = ceil(nd / NT): the last dword always lies in slot KI - 1)
-        goff[k] = (unsigned)(p.VL - 4);
-        tail_shr = 8u * (unsigned)(4 * d + 4 - p.VL);
-      }
     }
   }
   // output dwords this thread produces; per byte: LDS byte offsets of the two taps (u16 elements in [e0,e2,e1,e3]
@@ -149,15 +150,26 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
   // PD register sets: the two source rows of output row q sit in set q % PD, requested PD rows ahead
   unsigned ky[PD];                  // their vertical fractions
   uint32_t A[PD][KI], C[PD][KI];
+  uint32_t A1[PD][UA ? KI : 1], C1[PD][UA ? KI : 1];      // UA: the aligned dword behind A / C
+  unsigned sha[PD], shc[PD];        // UA: byte shift of the top / bottom row against its aligned start (block uniform)
   int y0 = 0, nrows = 0;
   /* buffer loads / stores: image base in an SGPR descriptor, row offset in the scalar offset, the thread's dword in the
      32-bit vector offset -- no per-access 64-bit address arithmetic (a v_lshl_add_u64 per load and store before) */
-#define ATTWARP_U8I_FETCH(AX, CX)                                                                      \
+#define ATTWARP_U8I_FETCH(AX, CX, AX1, CX1, SA, SC)                                                    \
   {                                                                                                    \
-    const int ra_ = ci0 * p.row_len, rc_ = ci1 * p.row_len;      /* block uniform: SGPRs */              \
+    int ra_ = ci0 * p.row_len, rc_ = ci1 * p.row_len;            /* block uniform: SGPRs */              \
+    if (UA) {                                                                                          \
+      ra_ += (int)base_sh; rc_ += (int)base_sh;                                                        \
+      SA = (unsigned)ra_ & 3u; SC = (unsigned)rc_ & 3u;                                                \
+      ra_ &= ~3; rc_ &= ~3;                                                                            \
+    }                                                                                                  \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
       AX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], ra_, 0);                         \
       CX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], rc_, 0);                         \
+      if (UA) {                                                                                        \
+        AX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, ra_, 0);                  \
+        CX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, rc_, 0);                  \
+      }                                                                                                \
     }                                                                                                  \
   }
   /* One output row.  Its two source rows were requested PD rows ahead (a workgroup's own row takes about a microsecond
@@ -166,10 +178,15 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
      Horizontal pass: (32 - kx) * v0 + kx * v1 + 512 is one v_dot2_u32_u16 on the tap pair.  Measured and dropped: both
      taps into one register with ds_read_u16_d16 / _d16_hi -- on this part (SRAM ECC) a d16 load clears the other half
      instead of preserving it. */
-#define ATTWARP_U8I_ROW(q_, vbuf, VOFF, AX, CX, KY)                                                    \
+#define ATTWARP_U8I_ROW(q_, vbuf, VOFF, AX, CX, KY, AX1, CX1, SA, SC)                                  \
   {                                                                                                    \
     const unsigned w1_ = KY, w0_ = 32u - KY;                                                           \
-    if (UA) { AX[KI - 1] >>= tail_shr; CX[KI - 1] >>= tail_shr; }                                      \
+    if (UA) {   /* the row dwords out of the aligned pairs: (hi:lo) >> 8 * shift */                    \
+      _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                  \
+        AX[k] = __builtin_amdgcn_alignbyte(AX1[k], AX[k], SA);                                         \
+        CX[k] = __builtin_amdgcn_alignbyte(CX1[k], CX[k], SC);                                         \
+      }                                                                                                \
+    }                                                                                                  \
     const us2 w0p_ = {(unsigned short)w0_, (unsigned short)w0_}, w1p_ = {(unsigned short)w1_, (unsigned short)w1_}; \
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
       /* bytes (0, 2) and (1, 3) zero-extended to two u16: an and, and ONE v_perm_b32 (shift + and before) */ \
@@ -184,7 +201,7 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
     }                                                                                                  \
     if ((q_) + PD < nrows) { /* this register set is free: request the rows of output row q + PD */   \
       row_taps(s_my[(q_) + PD], ci0, ci1, KY);                                                         \
-      ATTWARP_U8I_FETCH(AX, CX)                                                                        \
+      ATTWARP_U8I_FETCH(AX, CX, AX1, CX1, SA, SC)                                                      \
     }                                                                                                  \
     __syncthreads();                                                                                   \
     const int orow_ = (y0 + (q_)) * p.orow_len;                                                        \
@@ -220,18 +237,18 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
     for (int u = 0; u < PD; ++u)
       if (u < nrows) {
         row_taps(s_my[u], ci0, ci1, ky[u]);
-        ATTWARP_U8I_FETCH(A[u], C[u])
+        ATTWARP_U8I_FETCH(A[u], C[u], A1[u], C1[u], sha[u], shc[u])
       }
     int q = 0;
     for (; q + 3 < nrows; q += 4) {          // unrolled by 4: LDS buffer q & 1 and register set q % PD are compile-time
-      ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
-      ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
-      ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
-      ATTWARP_U8I_ROW(q + 3, vrow1, 2u * U8I_VLP, A[3 % PD], C[3 % PD], ky[3 % PD])
+      ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0], A1[0], C1[0], sha[0], shc[0])
+      ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD], A1[1 % PD], C1[1 % PD], sha[1 % PD], shc[1 % PD])
+      ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD], A1[2 % PD], C1[2 % PD], sha[2 % PD], shc[2 % PD])
+      ATTWARP_U8I_ROW(q + 3, vrow1, 2u * U8I_VLP, A[3 % PD], C[3 % PD], ky[3 % PD], A1[3 % PD], C1[3 % PD], sha[3 % PD], shc[3 % PD])
     }
-    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0])
-    if (q + 1 < nrows) ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD])
-    if (q + 2 < nrows) ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD])
+    if (q < nrows) ATTWARP_U8I_ROW(q, vrow0, 0u, A[0], C[0], ky[0], A1[0], C1[0], sha[0], shc[0])
+    if (q + 1 < nrows) ATTWARP_U8I_ROW(q + 1, vrow1, 2u * U8I_VLP, A[1 % PD], C[1 % PD], ky[1 % PD], A1[1 % PD], C1[1 % PD], sha[1 % PD], shc[1 % PD])
+    if (q + 2 < nrows) ATTWARP_U8I_ROW(q + 2, vrow0, 0u, A[2 % PD], C[2 % PD], ky[2 % PD], A1[2 % PD], C1[2 % PD], sha[2 % PD], shc[2 % PD])
   }
 #undef ATTWARP_U8I_ROW
 #undef ATTWARP_U8I_FETCH
