@@ -166,10 +166,10 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
     _Pragma("unroll") for (int k = 0; k < KI; ++k) {                                                    \
       AX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], ra_, 0);                         \
       CX[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k], rc_, 0);                         \
-      if (UA) {                                                                                        \
-        AX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, ra_, 0);                  \
-        CX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, rc_, 0);                  \
-      }                                                                                                \
+      /* (a row that happens to start on a dword boundary -- every fourth row of a 683-pixel image -- needs no second   \
+         dword: v_alignbyte_b32 with shift 0 returns the low operand whatever the stale high one holds) */ \
+      if (UA && SA) AX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, ra_, 0);      \
+      if (UA && SC) CX1[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)goff[k] + 4, rc_, 0);      \
     }                                                                                                  \
   }
   /* One output row.  Its two source rows were requested PD rows ahead (a workgroup's own row takes about a microsecond
