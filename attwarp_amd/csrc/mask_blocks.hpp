@@ -223,7 +223,10 @@ __device__ __forceinline__ void lanczos_strip_block(const LanczosStripArgs& a, i
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(s3) : "v"(win[0][3]), "s"(kv[0]), "v"(round_half));
 #pragma unroll
     for (int y = 1; y < 8; ++y) {
-      if (y == 7 && kv[7] == 0) break;                       // 24 -> 1024 has 7 taps: the padded 8th is skipped (uniform)
+      // Up-sampling never has more than 6 non-zero taps (support 3: int(c + 3.5) - int(c - 2.5) = 6 source pixels; ksize = 7
+      // is Pillow's allocation bound): the zero 7th and the padded 8th are skipped (wave uniform; adding 0 * pixel is exact)
+      if (y == 6 && kv[6] == 0 && kv[7] == 0) break;
+      if (y == 7 && kv[7] == 0) break;
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s0) : "v"(win[y][0]), "s"(kv[y]));
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s1) : "v"(win[y][1]), "s"(kv[y]));
       asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(s2) : "v"(win[y][2]), "s"(kv[y]));

@@ -586,3 +586,60 @@ def test_mask_chain_ragged_abi_validation_without_gpu(lib):
     assert call(f_host=ctypes.c_void_p(t2.ctypes.data)) == -1 and b"share" in lib.attwarp_last_error()
     junk = np.zeros(n, np.uint8)
     assert call(p_host=ctypes.c_void_p(junk.ctypes.data)) == -1 and b"attwarp_ragged_plan" in lib.attwarp_last_error()
+
+
+def test_ragged_stream_schedule_without_gpu(monkeypatch):
+    """RaggedMaskChainStream's schedule is host logic: for any number of batches every batch gets V, L, P, F, R exactly once,
+    in that order, one stage per launch, and a launch never runs two stages of one batch (they depend on each other);
+    push returns a batch right after the launch that ran its R; the ring form primes / drains the same way."""
+    from attwarp_amd import pipeline
+    log = []                                   # one dict per launch: stage -> batch id
+
+    class FakeBatch:
+        def __init__(self, images, out_size, g, out=None):
+            self.id = images
+            self._dev = None
+            self.masks = None
+
+    def fake_launch(R=None, F=None, P=None, L=None, V=None, enhance_coe=10, kernel_size=3):
+        log.append({k: b.id for k, b in (("R", R), ("F", F), ("P", P), ("L", L), ("V", V)) if b is not None})
+
+    monkeypatch.setattr(pipeline, "RaggedBatch", FakeBatch)
+    monkeypatch.setattr(pipeline, "ragged_chain_launch", fake_launch)
+
+    class FakeMask:
+        def float(self): return self
+        def contiguous(self): return self
+
+    for n in range(1, 12):
+        log.clear()
+        st = pipeline.RaggedMaskChainStream(out_size=(8, 8))
+        done = []
+        for i in range(n):
+            d = st.push(i, FakeMask())
+            if d is not None:
+                assert log[-1].get("R") == d.id            # returned right behind the launch that resampled it
+                done.append(d.id)
+        done += [d.id for d in st.flush()]
+        assert done == list(range(n))
+        per_batch = {i: [] for i in range(n)}
+        for launch in log:
+            assert len(set(launch.values())) == len(launch)   # five DIFFERENT batches per launch
+            for stage, b in launch.items():
+                per_batch[b].append(stage)
+        assert all(v == list("VLPFR") for v in per_batch.values()), per_batch
+        assert len(log) == n + 4
+    # ring form: prime -> steps -> drain leave every slot with all five stages an equal number of times
+    for nring, steps in ((5, 5), (6, 12), (7, 3)):
+        log.clear()
+        st = pipeline.RaggedMaskChainStream(out_size=(8, 8))
+        st.ring([FakeBatch(i, None, None) for i in range(nring)])
+        st.prime(); st.run(steps); st.drain_ring()
+        count = {}
+        for launch in log:
+            for stage, b in launch.items():
+                count[(b, stage)] = count.get((b, stage), 0) + 1
+        total = steps + 4                                     # batches that went through the pipeline
+        for b in range(nring):
+            per = [count.get((b, s), 0) for s in "VLPFR"]
+            assert len(set(per)) == 1 and per[0] == (total // nring + (1 if b < total % nring else 0)), (nring, steps, b, per)
