@@ -757,7 +757,9 @@ class MaskChainStream:
                     step (existing kernels, the hardware schedules workgroups of the branches side by side)
         "fused":    R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as block ranges of ONE launch per step
                     (attwarp_mask_chain_step), replayed as graphs of ``unroll`` steps
-        "auto":     "fused" when the shapes are eligible, else "branches"
+        "ragged":   the same one launch per step through attwarp_mask_chain_ragged (every image described by a table entry):
+                    equally sized images whose shape the uniform step refuses -- a width that is not a multiple of 4
+        "auto":     "fused" when the shapes are eligible, else "ragged" when the ragged kernel takes them, else "branches"
 
     ``images`` / ``masks`` are rings of n static buffers (lists of equal length; a single tensor = a ring of one): batch k
     lives in slot k % n and is warped into ``outs[k % n]``.  Usage (d = pipeline depth: 2 for "branches", 4 for "fused"):
@@ -771,7 +773,7 @@ class MaskChainStream:
     Every step is bit-identical to ``warp_from_masks`` on its batch (same arithmetic per stage; the parity tests compare
     both with the oracle)."""
 
-    PATTERNS = ("auto", "serial", "branches", "fused")
+    PATTERNS = ("auto", "serial", "branches", "fused", "ragged")
 
     def __init__(self, images, masks, out_size=(500, 500), enhance_coe=10, kernel_size=3, transform="identity",
                  exp_scale=1.0, exp_divisor=1.0, apply_inverse=False, mode: str = "cv2", pattern: str = "auto"):
@@ -823,7 +825,15 @@ class MaskChainStream:
                 if pattern == "fused":
                     raise
                 self.pattern = "branches"
-        self.depth = {"serial": 0, "branches": 2, "fused": 4}[self.pattern]
+        if pattern == "ragged" or (pattern == "auto" and self.pattern == "branches"):
+            ok = (self.mode == "cv2" and self.transform == "identity" and not self.apply_inverse
+                  and ragged_eligible(H, W, C, self.g) and self.Wo * C <= RAGGED_MAX_ROW_BYTES)
+            if ok:
+                self.pattern = "ragged"
+                self._rb = {}                 # (ring slot, batch parity) -> RaggedBatch: the slot's images / masks / output,
+            elif pattern == "ragged":         # intermediates of that parity
+                raise _lib.AttWarpError("MaskChainStream: this shape / these options do not run on the ragged chain kernel")
+        self.depth = {"serial": 0, "branches": 2, "fused": 4, "ragged": 4}[self.pattern]
 
     # ---- the stages on static buffers (same entry points as warp_from_masks) ----
     def _V(self, j):
@@ -869,10 +879,30 @@ class MaskChainStream:
                  ptr(self.masks[(k + 4) % self.n]), self.g, self.kernel_size, self.enhance_coe, ptr(self.rev[p]),   # V(k+4)
                  stream_ptr(self._dev))
 
+    def _ragged(self, j):
+        """Batch j of the stream as a RaggedBatch over slot j % n (its images, masks and output buffer) with the
+        intermediates of parity j & 1 -- built once per (slot, parity)."""
+        key = (j % self.n, j & 1)
+        rb = self._rb.get(key)
+        if rb is None:
+            img = self.images[key[0]]
+            rb = RaggedBatch([img[b] for b in range(self.B)], (self.Ho, self.Wo), self.g, out=self.outs[key[0]])
+            rb.masks = self.masks[key[0]]
+            self._rb[key] = rb
+        return rb
+
+    def _ragged_launch(self, **stages):
+        ragged_chain_launch(**{s: self._ragged(j) for s, j in stages.items()}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+
     # ---- driving ----
     def prime(self):
         """Everything the first step expects to find done for the batches at ring positions k .. k+depth-1 (serial)."""
         k = self.k
+        if self.pattern == "ragged":
+            for j, stages in ((k, "VLPF"), (k + 1, "VLP"), (k + 2, "VL"), (k + 3, "V")):
+                for st in stages:
+                    self._ragged_launch(**{st: j})
+            return
         if self.pattern == "branches":      # step k runs R(k) | PF(k+1) | VL(k+2)
             self._V(k); self._L(k); self._PF(k)
             self._V(k + 1); self._L(k + 1)
@@ -888,6 +918,8 @@ class MaskChainStream:
             self._V(k); self._L(k); self._PF(k); self._R(k)
         elif self.pattern == "fused":
             self._fused_launch(k)
+        elif self.pattern == "ragged":
+            self._ragged_launch(R=k, F=k + 1, P=k + 2, L=k + 3, V=k + 4)
         else:
             raise RuntimeError("branches are only defined inside a capture")
 
@@ -950,7 +982,11 @@ class MaskChainStream:
     def drain(self) -> torch.Tensor:
         """The last ``depth`` batches of a stream that ends (no further masks): the remaining stages, serially."""
         k = self.k
-        if self.pattern == "branches":
+        if self.pattern == "ragged":
+            for j, stages in ((k, "R"), (k + 1, "FR"), (k + 2, "PFR"), (k + 3, "LPFR")):
+                for st in stages:
+                    self._ragged_launch(**{st: j})
+        elif self.pattern == "branches":
             self._R(k); self._PF(k + 1); self._R(k + 1)
         elif self.pattern == "fused":
             self._R(k)

@@ -2703,7 +2703,28 @@ def test_paired_step_warp_equals_serial(dev, S, B, layout, mode, adt, n):
         assert torch.equal(got[j], refs[j]), j
 
 
-@pytest.mark.parametrize("case", [dict(S=50, So=33, Ho=47, transform="identity"),          # W % 4 != 0: nothing runs on a staged kernel
+@pytest.mark.parametrize("shape", [(50, 50, 33, 47), (64, 683, 500, 500), (90, 77, 61, 88)])
+@pytest.mark.parametrize("n", [1, 2, 4, 5])
+def test_mask_chain_stream_unaligned_shapes_take_the_ragged_step(dev, shape, n):
+    """Equally sized images whose width the uniform one-launch step refuses (W % 4 != 0) get the one-launch step of the
+    ragged kernel through the SAME class (pattern "ragged", depth 4): rings of every length -- one static buffer included --
+    graphs, primed and drained ends; every batch equals warp_from_masks."""
+    from attwarp_amd import pipeline
+    H, W, Wo, Ho = shape
+    g = torch.Generator(device=dev).manual_seed(H + W + n)
+    B = 3
+    imgs = [torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, Wo))
+    assert mc.pattern == "ragged" and mc.depth == 4
+    mc.prime(); mc.run(7); mc.drain()
+    for j in range(n):
+        assert torch.equal(mc.outs[j], pipeline.warp_from_masks(imgs[j], msk[j], (Ho, Wo))), j
+    with pytest.raises(_lib.AttWarpError):
+        pipeline.MaskChainStream(imgs, msk, (Ho, Wo), pattern="fused")
+
+
+@pytest.mark.parametrize("case", [dict(S=22, So=33, Ho=47, transform="identity"),          # sides below the 24-pixel mask grid: no staged mask up-sampling
                                   dict(S=96, So=80, Ho=80, transform="sqrt"),               # a transform the one-launch step does not take
                                   dict(S=24, So=64, Ho=64, transform="identity"),           # no up-sampling of the mask
                                   dict(S=96, So=80, Ho=80, transform="identity", mode="exact")])
