@@ -35,6 +35,7 @@ def _right_inverse_inv_host(n_out: int, n_in: int, eps: float) -> np.ndarray:
 
 
 _DEV_CACHE: dict = {}
+_DEV_CACHE_MAX = 8192          # entries (callers keep the tensors they use alive; eviction only drops the cache's reference)
 
 
 def right_inverse_inv(n_out: int, n_in: int, eps: float, device: torch.device) -> torch.Tensor:
@@ -75,6 +76,8 @@ def lanczos_tables(n_in: int, n_out: int, device: torch.device, filt: str = "lan
     key = (filt, n_in, n_out, str(device))
     t = _DEV_CACHE.get(key)
     if t is None:
+        while len(_DEV_CACHE) >= _DEV_CACHE_MAX:          # bounded: ragged batches bring two tables per distinct image size
+            _DEV_CACHE.pop(next(iter(_DEV_CACHE)))
         bounds, kk, ksize = _lanczos_tables_host(n_in, n_out, filt)
         if ksize < 8:           # rows of exactly 8 zero-padded coefficients enable the register-window kernels (attwarp.h)
             kk = np.concatenate([kk, np.zeros((kk.shape[0], 8 - ksize), dtype=np.int32)], axis=1)

@@ -1014,12 +1014,18 @@ _STAGING: list = []                   # pinned staging buffers: [tensor, event o
 _STAGING_LOCK = __import__("threading").Lock()     # (host threads on their own streams share the pool)
 
 
+_AXIS_TABLES_MAX = 4096              # distinct (device, g, size) entries kept (40 KB of device memory each at size 1024)
+
+
 def _axis_tables(g: int, n: int, dev: torch.device):
-    """(bounds pointer, coefficient pointer, ksize) of Pillow's g -> n LANCZOS tables on `dev` (cached per size)."""
+    """(bounds pointer, coefficient pointer, ksize, bounds tensor, coefficient tensor) of Pillow's g -> n LANCZOS tables on
+    `dev`, cached per size (bounded: the oldest entries go first; a RaggedBatch keeps the tensors it points to alive)."""
     key = (dev.index, g, n)
     t = _AXIS_TABLES.get(key)
     if t is None:
         b, k, ks = _tables.lanczos_tables(g, n, dev)
+        while len(_AXIS_TABLES) >= _AXIS_TABLES_MAX:
+            _AXIS_TABLES.pop(next(iter(_AXIS_TABLES)))
         t = _AXIS_TABLES[key] = (b.data_ptr(), k.data_ptr(), ks, b, k)
     return t
 
@@ -1080,6 +1086,7 @@ class RaggedBatch:
             raise _lib.AttWarpError("RaggedBatch: an image is too low for the 8-tap vertical mask up-sampling (H < 24)")
         rec["bounds_x"] = [t[0] for t in tx]; rec["kk_x"] = [t[1] for t in tx]; rec["ksize_x"] = [t[2] for t in tx]
         rec["bounds_y"] = [t[0] for t in ty]; rec["kk_y"] = [t[1] for t in ty]
+        self._keep = [t[3:] for t in tx] + [t[3:] for t in ty]      # the coefficient tensors the table points to
         rp = ctypes.c_void_p(rec.ctypes.data)
         nbytes = lib.attwarp_ragged_table_bytes(rp, self.B, C, self.g, self.Ho, self.Wo)
         if nbytes == 0:
