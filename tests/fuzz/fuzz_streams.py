@@ -1,5 +1,5 @@
 """Test infrastructure: concurrency stress.  N host threads, each with its own HIP stream, run random stage calls
-(resample, maps from attention, PDF chain, LANCZOS up-sample, attention reduce, CLIP epilogue) on private inputs and
+(resample, maps from attention, PDF chain, LANCZOS up-sample, attention reduce, CLIP epilogue, ragged chain batches) on private inputs and
 compare every result with the one the same call produced serially beforehand: kernels are stateless and stream ordered,
 the host-side table caches are shared.   usage: fuzz_streams.py [seconds] [threads] [seed]"""
 import os, sys, threading, time
@@ -15,7 +15,7 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 def make_jobs(rng, n):
     jobs = []
     for _ in range(n):
-        k = int(rng.integers(0, 6))
+        k = int(rng.integers(0, 7))
         if k == 0:
             B, H, W, C = int(rng.integers(1, 4)), int(rng.integers(8, 400)), int(rng.integers(8, 400)), int(rng.integers(1, 5))
             Ho, Wo = int(rng.integers(4, 400)), int(rng.integers(4, 400))
@@ -41,10 +41,15 @@ def make_jobs(rng, n):
             rows = torch.softmax(torch.randn(T_, B, heads, kv, device=dev), -1)
             starts = torch.randint(0, kv - 576 + 1, (B,), device=dev, dtype=torch.int32)
             jobs.append(lambda rows=rows, starts=starts: ae.attn_reduce_stack(rows, starts, 576))
-        else:
+        elif k == 5:
             B, H, W = int(rng.integers(1, 3)), int(rng.integers(16, 600)), int(rng.integers(16, 600))
             img = (torch.rand(B, H, W, 3, device=dev) * 255).to(torch.uint8)
             jobs.append(lambda img=img: pipeline.clip_preprocess(img, 224, torch.float32))
+        else:       # a ragged batch: host-side plan, the shared staging pool and table caches, five ragged launches
+            B = int(rng.integers(1, 5))
+            imgs = [(torch.rand(int(rng.integers(25, 300)), int(rng.integers(25, 300)), 3, device=dev) * 255).to(torch.uint8) for _ in range(B)]
+            m = torch.rand(B, 24, 24, device=dev)
+            jobs.append(lambda imgs=imgs, m=m: pipeline.warp_from_masks_ragged(imgs, m, (60, 72)))
     return jobs
 
 rng = np.random.default_rng(seed)
