@@ -338,7 +338,7 @@ static int launch_ragged(const RaggedStepArgs& a, size_t lds, unsigned grid, hip
 
 using namespace attwarp;
 
-extern "C" int attwarp_pil_coeffs_8bpc(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk, int kk_cols) {
+extern "C" int attwarp_pil_coeffs_8bpc(int in_size, int out_size, int filter, int32_t* bounds, int32_t* kk, int kk_cols) try {
   ATTWARP_REQUIRE(bounds && kk, "pil_coeffs_8bpc: null pointer");
   ATTWARP_REQUIRE(in_size > 0 && out_size > 0 && kk_cols > 0, "pil_coeffs_8bpc: non-positive size");
   ATTWARP_REQUIRE(filter == ATTWARP_PIL_LANCZOS || filter == ATTWARP_PIL_BICUBIC, "pil_coeffs_8bpc: unknown filter %d", filter);
@@ -379,16 +379,22 @@ extern "C" int attwarp_pil_coeffs_8bpc(int in_size, int out_size, int filter, in
     bounds[2 * o] = lo; bounds[2 * o + 1] = cnt;
   }
   return ksize;
+} catch (...) {
+  return fail(ATTWARP_E_UNSUPPORTED, "pil_coeffs_8bpc: out of host memory");
 }
 
-extern "C" size_t attwarp_ragged_table_bytes(const attwarp_ragged_image* images, int B, int C, int g, int H_out, int W_out) {
+// (the host helpers allocate std::vectors: an allocation failure must not travel through the C ABI as an exception)
+extern "C" size_t attwarp_ragged_table_bytes(const attwarp_ragged_image* images, int B, int C, int g, int H_out, int W_out) try {
   RaggedLayout L;
   if (ragged_layout(images, B, C, g, H_out, W_out, L) != ATTWARP_OK) return 0;
   return (size_t)L.h.table_bytes;
+} catch (...) {
+  fail(ATTWARP_E_UNSUPPORTED, "ragged_table_bytes: out of host memory");
+  return 0;
 }
 
 extern "C" int attwarp_ragged_plan(const attwarp_ragged_image* images, int B, int C, int g, int H_out, int W_out, void* table,
-                                   size_t table_bytes) {
+                                   size_t table_bytes) try {
   ATTWARP_REQUIRE(table, "ragged_plan: null table");
   RaggedLayout L;
   if (const int rc = ragged_layout(images, B, C, g, H_out, W_out, L)) return rc;
@@ -402,6 +408,8 @@ extern "C" int attwarp_ragged_plan(const attwarp_ragged_image* images, int B, in
   memcpy(t + L.h.off_pmap, L.pmap.data(), L.pmap.size() * sizeof(uint32_t));
   memcpy(t + L.h.off_order, L.order.data(), L.order.size() * sizeof(uint32_t));
   return ATTWARP_OK;
+} catch (...) {
+  return fail(ATTWARP_E_UNSUPPORTED, "ragged_plan: out of host memory");
 }
 
 extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, uint8_t* out, const float* map_x, const float* map_y,
