@@ -305,6 +305,7 @@ static int ragged_layout(const attwarp_ragged_image* images, int B, int C, int g
   h.magic = RAGGED_MAGIC; h.B = B; h.C = C; h.g = g; h.H_out = Ho; h.W_out = Wo;
   h.nL = (int32_t)L.lmap.size(); h.nP = (int32_t)L.pmap.size();
   h.rows_per_block = (OVL >= 2048) ? 32 : 16;           // as plan_u8 (remap_u8.hip)
+  if (const int v = tune(TUNE_REMAP_ROWS); v >= 1 && v <= u8k::RMAX) h.rows_per_block = v;     // (tuning flavour: sweeps)
   if (h.rows_per_block > Ho) h.rows_per_block = Ho;
   h.blocks_per_image = (Ho + h.rows_per_block - 1) / h.rows_per_block;
   if ((long long)h.blocks_per_image * B > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "ragged_plan: grid too large");

@@ -49,6 +49,8 @@ elif what == "ragged":
     n = max(6, min(24, -(-(1 << 30) // (3 * px + 3 * B * 250000))))
     g = torch.Generator(device=dev).manual_seed(B)
     ring = []
+    ctx = _lib.debug_override(**over)
+    ctx.__enter__()          # the tables are planned under the overrides too; eager launches: they stay on for the whole run
     for _ in range(n):
         rb = pipeline.RaggedBatch([torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes], (500, 500))
         rb.masks = torch.rand(B, 24, 24, device=dev, generator=g)
@@ -56,8 +58,6 @@ elif what == "ragged":
     st_ = pipeline.RaggedMaskChainStream(out_size=(500, 500))
     st_.ring(ring)
     depth = 0
-    ctx = _lib.debug_override(**over)
-    ctx.__enter__()          # eager launches: the overrides stay on for the whole run
     st_.prime()
     def run_steady():
         st_.run(K)
