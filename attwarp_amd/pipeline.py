@@ -1205,8 +1205,13 @@ def warp_from_masks_ragged(images, attn24: torch.Tensor, out_size=(500, 500), en
     if Wo * int(images[0].shape[2]) > RAGGED_MAX_ROW_BYTES:
         ok = [False] * B
     masks = attn24.float().contiguous()
+    rb = None
     if all(ok):
-        rb = RaggedBatch(images, out_size, g)
+        try:
+            rb = RaggedBatch(images, out_size, g)
+        except _lib.AttWarpError:          # a limit ragged_eligible does not model (e.g. the LDS of a very long axis): per image
+            ok = [False] * B
+    if rb is not None:
         rb.masks = masks
         for stage in "VLPFR":
             ragged_chain_launch(**{stage: rb}, enhance_coe=enhance_coe, kernel_size=kernel_size)

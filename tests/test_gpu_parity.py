@@ -3037,6 +3037,12 @@ def test_ragged_falls_back_per_image_outside_its_limits(dev):
         assert torch.equal(out[b], pipeline.warp_from_masks(images[b][None], att[b:b + 1], (60, 72))[0]), b
     with pytest.raises(_lib.AttWarpError):
         pipeline.RaggedBatch(images, (60, 72))
+    # an axis so long that the finalize body's LDS does not fit: ragged_eligible says yes, the plan says no -> per image
+    tall = [torch.randint(0, 256, (7600, 40, 3), device=dev, dtype=torch.uint8, generator=g), images[1]]
+    assert pipeline.ragged_eligible(7600, 40, 3)
+    out = pipeline.warp_from_masks_ragged(tall, att[:2], (60, 72))
+    for b in range(2):
+        assert torch.equal(out[b], pipeline.warp_from_masks(tall[b][None], att[b:b + 1], (60, 72))[0]), b
 
 
 def test_randomised_differential_runs(dev):
