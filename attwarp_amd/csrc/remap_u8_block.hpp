@@ -37,8 +37,8 @@ struct Params {
 //     16-bit values (half the LDS bytes), in the order [e0, e2, e1, e3] per group of 4 (no re-interleaving: the tap
 //     offsets know the order);
 //   * horizontal: a lane produces 4 CONSECUTIVE output bytes: 8 ds_read_u16, per byte
-//     ((32 - kx)*v0 + kx*v1 + 512) >> 10 (one v_dot2_u32_u16 on the tap pair), packed and stored as one dword -- no LDS
-//     output row, no flush pass;
+//     ((32 - kx)*v0 + kx*v1 + 512) >> 10 (one v_dot2_u32_u16 on the tap pair, weights scaled by 64 so that the byte is
+//     byte 2 of the result), packed with two v_perm_b32 and stored as one dword -- no LDS output row, no flush pass;
 //     tap 1 is always "tap 0's pixel + 1" with kx forced to 0 where OpenCV clamps both taps to the same pixel (integer
 //     arithmetic: a zero weight is exact), so the clamped cases need no second offset logic.
 // Bit-identical to blend<uint8_t, CV2> of remap.hip / the oracle.
@@ -132,7 +132,7 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
         t1[k][j] = lds_off(e1);
         // opaque, or address-mode sinking moves the "+ base" back in front of every read of the row loop
         asm volatile("" : "+v"(t0[k][j]), "+v"(t1[k][j]));
-        wpk[k][j] = (32u - kx) | (kx << 16);
+        wpk[k][j] = ((32u - kx) << 6) | (kx << 22);      // both weights x 64: the result byte lands on a byte boundary
       }
     }
   }
@@ -211,12 +211,15 @@ __device__ __forceinline__ void remap_rows_u8i_rows(const Params& p, const uint8
         v0_[j] = *(lds_cu16*)(uintptr_t)(t0[k][j] + (VOFF));                                           \
         v1_[j] = *(lds_cu16*)(uintptr_t)(t1[k][j] + (VOFF));                                           \
       }                                                                                                \
-      unsigned o_ = 0;                                                                                 \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {   /* (32 - kx) * v0 + kx * v1 + 512: one v_dot2_u32_u16 */ \
+      /* 64 * ((32 - kx) * v0 + kx * v1 + 512) < 2^24: one v_dot2_u32_u16 with the weights scaled by 64, so that     \
+         ((..) >> 10) -- the output byte -- is BYTE 2 of the result; four results are packed with two v_perm_b32 and  \
+         an or (a shift and a shift-or per byte before) */                                             \
+      unsigned r_[4];                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
         const us2 pr_ = {(unsigned short)v0_[j], (unsigned short)v1_[j]};                               \
-        const unsigned in_ = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u, false); \
-        o_ |= (in_ >> 10) << (8 * j);                                                                  \
+        r_[j] = __builtin_amdgcn_udot2(pr_, __builtin_bit_cast(us2, wpk[k][j]), 512u << 6, false);      \
       }                                                                                                \
+      const unsigned o_ = __builtin_amdgcn_perm(r_[1], r_[0], 0x0c0c0602u) | __builtin_amdgcn_perm(r_[3], r_[2], 0x06020c0cu); \
       if (tid + NT * k < (p.OVL >> 2)) __builtin_amdgcn_raw_buffer_store_b32(o_, rdst, soff[k], orow_, U8I_STORE_NT); \
       else if (UA && k == KD - 1 && tid + NT * k == (p.OVL >> 2)) {   /* the row's last 1..3 bytes */           \
         for (int j_ = 0; j_ < (p.OVL & 3); ++j_)                                                       \

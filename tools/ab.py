@@ -1,5 +1,5 @@
 """Dev tool: same-box A/B of builds of libattwarp_hip.so (alternating subprocesses, one build per process).
-usage: python tools/ab.py <target> libA.so libB.so [...]     targets: attn | remap | headline | step
+usage: python tools/ab.py <target> libA.so libB.so [...]     targets: attn | remap | headline | step | u8
 (variants inside ONE build are compared with attwarp_debug_set through the tools that take key=value / tune= arguments)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,6 +54,37 @@ if "--child" in sys.argv:
             print(f"{tag:12s} B={B} S={S}: fused {res['ms_per_step']:.4f} ms/step {res['step_TBps']:.3f} TB/s  same={res['bit_identical_to_serial']}  "
                   f"eager {res['eager']['ms_per_step']:.4f} stages {res['eager']['stages_ms']}", flush=True)
             torch.cuda.empty_cache()
+    elif target == "u8":       # the integer uint8 resample alone and inside the one-launch chain steps (uniform + ragged)
+        import remap_bench as rb, time
+        for (B, S) in ((256, 336), (256, 1024)):
+            g = torch.Generator(device=dev).manual_seed(1)
+            img = torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g)
+            px = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.5, 1); py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.5, 1)
+            mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S), (500, 500))
+            out = torch.empty(B, 500, 500, 3, device=dev, dtype=torch.uint8)
+            from attwarp_amd import checkpoint_utils as cu
+            for _ in range(5): cu.remap_separable(img, mx, my, mode="cv2", channels_last=True, out=out)
+            torch.cuda.synchronize(); ts = []
+            for _ in range(40):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); cu.remap_separable(img, mx, my, mode="cv2", channels_last=True, out=out); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            print(f"{tag:22s} u8 cv2 B={B} {S}->500: {sorted(ts)[20]*1e3:.1f} us", flush=True)
+            del img, out
+        for (B, S, K) in ((32, 336, 64), (256, 1024, 32)):
+            n = 6 if S == 1024 else 16
+            g = torch.Generator(device=dev).manual_seed(B + S)
+            images = [torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+            masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+            mc = pipeline.MaskChainStream(images, masks, (500, 500), pattern="fused")
+            def run():
+                mc.reset(); mc.prime(); mc.run(K); mc.drain()
+            run(); torch.cuda.synchronize(); best = 1e9
+            for rep in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); run(); torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / (K + mc.depth))
+            print(f"{tag:22s} chain step B={B} {S}->500: {best*1e6:.1f} us", flush=True)
+            del mc, images, masks; torch.cuda.empty_cache()
     else:
         raise SystemExit(__doc__)
 else:
