@@ -144,7 +144,10 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
     // block uniform: source dwords per thread (rows requested ahead: as launch_u8i_depth, remap_u8.hip) x whether THIS image's
     // rows are dword aligned -- the unaligned form holds two aligned dwords per row dword until the row is consumed, so it
     // requests its rows half as far ahead to stay inside the kernel's register budget
-    const bool ua = ((p.row_len | (int)(reinterpret_cast<uintptr_t>(im.image) & 3u)) & 3) != 0;
+    // (an output row that is not a multiple of 4 bytes -- or an output image that does not start on a dword -- needs the
+    //  unaligned form too: only it stores a row's last 1..3 bytes)
+    const bool ua = ((p.row_len | p.orow_len | (int)(reinterpret_cast<uintptr_t>(im.image) & 3u) |
+                      (int)(reinterpret_cast<uintptr_t>(dst_b) & 3u)) & 3) != 0;
 #define ATTWARP_RAGGED_R(KI_, PD_, UA_) \
     u8k::remap_rows_u8i_rows<KI_, KD, true, PD_, UA_>(p, im.image, img_bytes, dst_b, oimg_bytes, mx_b, my_b, rb0, smem)
     if (!ua) {

@@ -2961,6 +2961,12 @@ def test_ragged_stream_equals_serial_launches(dev):
     from attwarp_amd import pipeline
     comps = [(5, 1, [(683, 512)]), (3, 2, []), (8, 3, [(100, 77), (1365, 40)]), (1, 4, []), (6, 5, [(501, 333)]), (4, 6, []), (7, 7, [])]
     batches = [ragged_batch(dev, B, seed, extra) for (B, seed, extra) in comps]
+    # output rows that are NOT a multiple of 4 bytes (319 x 3 = 957) from aligned and unaligned images alike: every image
+    # against the per-image drop-in (the resample of an aligned image must take the form that stores the row's last bytes)
+    for (i, a) in batches[:3]:
+        odd = pipeline.warp_from_masks_ragged(i, a, (41, 319))
+        for b in range(len(i)):
+            assert torch.equal(odd[b], pipeline.warp_from_masks(i[b][None], a[b:b + 1], (41, 319))[0]), b
     want = [pipeline.warp_from_masks_ragged(i, a, (120, 136)) for (i, a) in batches]
     for n in (1, 3, 4, 5, 7):
         st = pipeline.RaggedMaskChainStream(out_size=(120, 136))
