@@ -3030,6 +3030,27 @@ def test_upload_images_packs_host_images_for_the_ragged_chain(dev):
     assert torch.equal(a, b)
 
 
+def test_ragged_large_batch_of_small_images(dev):
+    """A ragged batch of 1500 small images (more images than the chip has workgroup slots, more than 8 bits of image index,
+    a batch size that is not a multiple of 8: the resample's plain block order): a sample of images against the per-image
+    drop-in, the whole output against a second run and against the stream form."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(1500)
+    B = 1500
+    hs = torch.randint(25, 70, (B,), generator=torch.Generator().manual_seed(1)).tolist()
+    ws = torch.randint(25, 70, (B,), generator=torch.Generator().manual_seed(2)).tolist()
+    images = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for h, w in zip(hs, ws)]
+    att = torch.rand(B, 24, 24, device=dev, generator=g) ** 2
+    out = pipeline.warp_from_masks_ragged(images, att, (48, 52))
+    assert torch.equal(out, pipeline.warp_from_masks_ragged(images, att, (48, 52)))
+    for b in list(range(0, B, 97)) + [255, 256, 257, B - 1]:
+        assert torch.equal(out[b], pipeline.warp_from_masks(images[b][None], att[b:b + 1], (48, 52))[0]), b
+    st = pipeline.RaggedMaskChainStream(out_size=(48, 52))
+    got = [st.push(images, att) for _ in range(5)]
+    got = [d for d in got if d is not None] + st.flush()
+    assert len(got) == 5 and all(torch.equal(d.out, out) for d in got)
+
+
 def test_ragged_falls_back_per_image_outside_its_limits(dev):
     """Images the ragged kernel does not take (rows wider than 4096 bytes, a side <= 24) run through warp_from_masks one by
     one inside warp_from_masks_ragged; the rest of the batch still runs ragged; results are those of the per-image path."""
