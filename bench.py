@@ -767,7 +767,45 @@ def leg_main_batched_ragged(dev, torch, pipeline, K):
     ref = out["cases"][0]
     out["value"] = max(ref["stream"]["eager"]["images_per_s"], ref["stream"]["graphs"]["images_per_s"])
     out["value_is"] = "the ragged stream step at the reference's batch size (B=32), one launch per batch"
+    out["cpu_baseline"] = chain_cpu_baseline(dev, torch, pipeline, So)
     return out
+
+
+def chain_cpu_baseline(dev, torch, pipeline, So, budget_s: float = 8.0):
+    """The reference's CPU chain for the same images, timed beside the GPU path (kind "port": oracle/warp_oracle.py -- numpy --
+    for revise_mask, the x255 truncation, Pillow's LANCZOS arithmetic and the float64 map construction, oracle/warp_ref.c for
+    the uint8 cv2 resample), one thread, on a BOUNDED sample: the first images of the TextVQA-like mix, cycled until the budget
+    is spent.  Doubles as a check: every image it processes is compared with the GPU's output for that image."""
+    import numpy as np
+    from oracle import c_oracle, warp_oracle as O
+    sizes = [TEXTVQA_LIKE_WH[b % len(TEXTVQA_LIKE_WH)] for b in range(6)]
+    g = torch.Generator(device=dev).manual_seed(4242)
+    imgs = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes]
+    att = torch.rand(len(imgs), 24, 24, device=dev, generator=g) ** 2
+    gpu = pipeline.warp_from_masks_ragged(imgs, att, (So, So)).cpu().numpy()
+    imgs_h = [i.cpu().numpy() for i in imgs]
+    att_h = att.cpu().numpy()
+    worst, n, t0 = 0, 0, time.perf_counter()
+    while True:
+        b = n % len(imgs_h)
+        h, w = imgs_h[b].shape[:2]
+        with np.errstate(all="ignore"):
+            mota = O.lanczos_resize_u8(O.mask_to_u8(O.revise_mask(att_h[b], 3, 10)), w, h)
+        mx, my = O.maps_from_attention(mota, So, So, "identity")
+        ref = c_oracle.remap_bilinear_u8(imgs_h[b], mx, my, "cv2")
+        if n < len(imgs_h):
+            worst = max(worst, int(np.abs(ref.astype(np.int16) - gpu[b].astype(np.int16)).max()))
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= len(imgs_h):
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{n} image passes over {len(imgs_h)} images of the mix {sizes} (W x H) -> {So} x {So} through the oracle's chain "
+                      f"(numpy revise_mask / x255 / LANCZOS / float64 maps + oracle/warp_ref.c resample), 1 thread, {dt:.1f} s",
+            "max_abs_diff_vs_gpu_grey_levels": worst,
+            "note": "the GPU's revised mask may differ from the oracle's by 1 ulp, which can move a x255-truncated mask cell by one "
+                    "grey level (DESIGN 4): a difference of at most 1 grey level in a few pixels is expected, bit-exactness GIVEN the "
+                    "revised mask is what the tests assert"}
 
 
 def leg_pool_input(dev, torch, pipeline, B, S, mode, K):
