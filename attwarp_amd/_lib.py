@@ -78,7 +78,9 @@ SIGNATURES = {
     "attwarp_mask_chain_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                         c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+                                         c_void_p, c_int, c_int, c_float, c_void_p,
+                                         c_int, c_double, c_double, c_int, c_void_p, c_void_p]),
+    "attwarp_attention_transform_lut": (c_int, [c_int, c_double, c_double, c_void_p, c_void_p]),
     "attwarp_pil_coeffs_8bpc": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_int]),
     "attwarp_ragged_table_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "attwarp_ragged_plan": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t]),
@@ -86,7 +88,8 @@ SIGNATURES = {
                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+                                           c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                           c_int, c_double, c_double, c_int, c_void_p, c_void_p]),
     "attwarp_axis_maps_from_steps_t": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "attwarp_resize_linear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -156,6 +159,8 @@ def load_tuning():
         _tuning = _open(TUNING_LIB_PATH)
         _tuning.attwarp_debug_set.restype = c_int
         _tuning.attwarp_debug_set.argtypes = [c_char_p, c_int, ctypes.POINTER(c_int)]
+        _tuning.attwarp_debug_stream_copy.restype = c_int
+        _tuning.attwarp_debug_stream_copy.argtypes = [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
     return _tuning
 
 

@@ -63,10 +63,12 @@ struct RaggedStepArgs {
   const float* masks; float* rev_out;
   // L(k+3)
   const RaggedImage* l_img; const uint32_t* l_map; const float* rev_in; uint8_t* mota_out;
-  // P(k+2)
+  // P(k+2): p_lut null = identity / square (p_square) in registers, else the table of the transformed byte values (sqrt / exp / log)
   const RaggedImage* p_img; const RaggedPlan* p_plans; const uint32_t* p_map; const uint8_t* mota_in; double* sums_out;
+  const double* p_lut; int p_square;
   // F(k+1)
   const RaggedImage* f_img; const RaggedPlan* f_plans; const uint32_t* f_order; const double* sums_in; float* map_x_next; float* map_y_next;
+  int transform, apply_inverse; double exp_scale, exp_divisor;
   // R(k)
   const RaggedImage* r_img; const uint32_t* r_order; uint8_t* out; const float* map_x; const float* map_y;
   int r_rows, r_nblk;                       // output rows per resample block, blocks per image
@@ -76,7 +78,9 @@ struct RaggedStepArgs {
 };
 
 // one block of the step; returns the kind of work it did (CHAIN_F .. CHAIN_R, CHAIN_PAD)
-template <int KD>
+// XT ("extended transforms"): false = the identity transform only (what both reference drivers pass: the kernel without any
+// transform code), true = identity / square in registers or a table (sqrt / exp / log), block uniform
+template <int KD, bool XT>
 __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_t* pool) {
   int j;
   const int kind = chain_order_decode(a.ord, blockIdx.x, j);
@@ -87,7 +91,8 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
     const RaggedPlan& Pw = a.f_plans[im.plan_w];
     const RaggedPlan& Ph = a.f_plans[im.plan_h];
     const double* col = a.sums_in + im.sums_off;
-    MapsFinalizeArgs fa{col, col + im.W, im.H, im.W, a.Wo, a.Ho, ATTWARP_T_IDENTITY, 1.0, 1.0, 0,
+    MapsFinalizeArgs fa{col, col + im.W, im.H, im.W, a.Wo, a.Ho, XT ? a.transform : (int)ATTWARP_T_IDENTITY, XT ? a.exp_scale : 1.0,
+                        XT ? a.exp_divisor : 1.0, XT ? a.apply_inverse : 0,
                         a.map_x_next + (size_t)b * a.Wo, a.map_y_next + (size_t)b * a.Ho, Pw.depth};
 #ifdef ATTWARP_TUNING
     fa.trace = a.trace;
@@ -105,8 +110,17 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
     const RaggedImage& im = a.p_img[b];
     const RaggedPlan& Pw = a.p_plans[im.plan_w];
     double* col = a.sums_out + im.sums_off;
-    profiles_u8_block<ATTWARP_T_IDENTITY, true>(a.mota_in + im.mota_off, im.H, im.W, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0},
-                                                Pw.off[leaf], Pw.len[leaf], Pw.nleaves, leaf, col, col + im.W, pool);
+    const uint8_t* att = a.mota_in + im.mota_off;
+    // (block uniform: the transform of new_method.py:134-179 the caller selected; identity is what both drivers pass)
+    if (XT && a.p_lut)
+      profiles_u8_block<ATTWARP_T_LUT, true>(att, im.H, im.W, XfAttention<ATTWARP_T_LUT>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf], Pw.nleaves,
+                                             leaf, col, col + im.W, pool, a.p_lut);
+    else if (XT && a.p_square)
+      profiles_u8_block<ATTWARP_T_SQUARE, true>(att, im.H, im.W, XfAttention<ATTWARP_T_SQUARE>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf],
+                                                Pw.nleaves, leaf, col, col + im.W, pool);
+    else
+      profiles_u8_block<ATTWARP_T_IDENTITY, true>(att, im.H, im.W, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf],
+                                                  Pw.nleaves, leaf, col, col + im.W, pool);
   } else if (kind == CHAIN_L) {
     const uint32_t e = a.l_map[j];
     const int b = (int)(e & 0xffffu), bx = (int)(e >> 16);
@@ -170,15 +184,15 @@ __device__ __forceinline__ int ragged_step_block(const RaggedStepArgs& a, uint8_
   return kind;
 }
 
-template <int KD>
+template <int KD, bool XT>
 __global__ __launch_bounds__(RAGGED_NT, RAGGED_WAVES) void mask_chain_ragged_kernel(const RaggedStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
 #ifdef ATTWARP_TUNING
   const TraceStart t0 = trace_now();
-  const int kind = ragged_step_block<KD>(a, pool);
+  const int kind = ragged_step_block<KD, XT>(a, pool);
   trace_block(a.trace, t0, kind);
 #else
-  ragged_step_block<KD>(a, pool);
+  ragged_step_block<KD, XT>(a, pool);
 #endif
 }
 
@@ -334,7 +348,10 @@ static const attwarp_ragged_header* checked_header(const void* host, const char*
 
 template <int KD>
 static int launch_ragged(const RaggedStepArgs& a, size_t lds, unsigned grid, hipStream_t st) {
-  hipLaunchKernelGGL((mask_chain_ragged_kernel<KD>), dim3(grid), dim3(RAGGED_NT), lds, st, a);
+  if (a.p_lut || a.p_square || a.apply_inverse)
+    hipLaunchKernelGGL((mask_chain_ragged_kernel<KD, true>), dim3(grid), dim3(RAGGED_NT), lds, st, a);
+  else
+    hipLaunchKernelGGL((mask_chain_ragged_kernel<KD, false>), dim3(grid), dim3(RAGGED_NT), lds, st, a);
   return check_launch("mask_chain_ragged_kernel");
 }
 
@@ -421,8 +438,12 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
                                          const void* p_host, const void* p_dev, const uint8_t* mota_in, void* sums_out,
                                          const void* l_host, const void* l_dev, const float* rev_in, uint8_t* mota_out,
                                          const float* masks, int B_masks, int g, int kernel_size, float enhance_coe, float* rev_out,
-                                         void* stream) {
+                                         int transform, double exp_scale, double exp_divisor, int apply_inverse,
+                                         const double* transform_lut, void* stream) {
   ATTWARP_REQUIRE(r_host || f_host || p_host || l_host || masks, "mask_chain_ragged: no stage given");
+  ATTWARP_REQUIRE(transform >= ATTWARP_T_IDENTITY && transform <= ATTWARP_T_LOG, "mask_chain_ragged: unknown transform %d", transform);
+  ATTWARP_REQUIRE(!p_host || transform <= ATTWARP_T_SQUARE || transform_lut,
+                  "mask_chain_ragged: the sqrt / exp / log transforms need transform_lut (attwarp_attention_transform_lut) in the P stage");
   RaggedStepArgs a;
   memset(&a, 0, sizeof(a));
   size_t lds = mask_postproc_lds_bytes();
@@ -461,6 +482,7 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
     a.f_plans = reinterpret_cast<const RaggedPlan*>(t + h->off_plans);
     a.f_order = reinterpret_cast<const uint32_t*>(t + h->off_order);
     a.sums_in = static_cast<const double*>(sums_in); a.map_x_next = map_x_next; a.map_y_next = map_y_next;
+    a.transform = transform; a.exp_scale = exp_scale; a.exp_divisor = exp_divisor; a.apply_inverse = apply_inverse ? 1 : 0;
     a.ord.nF = 2 * h->B;
   }
   if (p_host) {
@@ -473,6 +495,9 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
     a.p_plans = reinterpret_cast<const RaggedPlan*>(t + h->off_plans);
     a.p_map = reinterpret_cast<const uint32_t*>(t + h->off_pmap);
     a.mota_in = mota_in; a.sums_out = static_cast<double*>(sums_out);
+    a.p_lut = transform > ATTWARP_T_SQUARE ? transform_lut : nullptr;
+    a.p_square = transform == ATTWARP_T_SQUARE;
+    if (a.p_lut) lds = std::max(lds, profiles_u8_lds_bytes<ATTWARP_T_LUT>());
     a.ord.nP = h->nP;
   }
   if (l_host) {
@@ -508,6 +533,7 @@ extern "C" int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, 
 #endif
   const long long octs = chain_order_octets(a.ord);
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_ragged: grid too large");
+  if (lds > LDS_DEFAULT_MAX) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_ragged: %zu bytes of LDS per workgroup (> %zu)", lds, LDS_DEFAULT_MAX);
   if (octs == 0) return ATTWARP_OK;
   hipStream_t st = as_stream(stream);
   const unsigned grid = (unsigned)(octs * 8);

@@ -39,8 +39,9 @@ struct ChainStepArgs {
   const float* masks; int g, ks; float coe; float* rev_out;
   // L: la.mf (the rev of batch k+3) -> la.out (mota)
   LanczosStripArgs la; int l_bx;            // l_bx = nstrips * nchunks blocks per image
-  // P: mota_in [B,H,W] -> col_out, ls_out
-  const uint8_t* mota_in; double* col_out; double* ls_out;
+  // P: mota_in [B,H,W] -> col_out, ls_out; p_lut: null = identity / square (p_square) in registers, else the 256-entry
+  // table of the transformed byte values (sqrt / exp / log: attwarp_attention_transform_lut)
+  const uint8_t* mota_in; double* col_out; double* ls_out; const double* p_lut; int p_square;
   // F: fa.col / fa.ls -> fa.map_x / fa.map_y
   MapsFinalizeArgs fa;
   // R
@@ -52,7 +53,9 @@ struct ChainStepArgs {
 };
 
 // one block of the step; returns the kind of work it did (CHAIN_F .. CHAIN_R, CHAIN_PAD)
-template <int KI, int KD, int PD>
+// XT ("extended transforms"): false = the identity transform only -- what both reference drivers pass; the kernel then is the
+// one without any transform code -- true = identity / square in registers or a table (sqrt / exp / log), block uniform
+template <int KI, int KD, int PD, bool XT>
 __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const PairwisePlan& Pw, const PairwisePlan& Ph, uint8_t* pool) {
   int j;
   const int kind = chain_order_decode(a.ord, blockIdx.x, j);
@@ -72,9 +75,19 @@ __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const Pa
 #else
     const int bsrc = b;
 #endif
-    profiles_u8_block<ATTWARP_T_IDENTITY>(a.mota_in + (size_t)bsrc * a.fa.h * a.fa.w, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0},
-                                          Pw.off[leaf], Pw.len[leaf], Pw.nleaves, leaf, a.col_out + (size_t)b * a.fa.w,
-                                          a.ls_out + (size_t)b * a.fa.h * Pw.nleaves, pool);
+    const uint8_t* att = a.mota_in + (size_t)bsrc * a.fa.h * a.fa.w;
+    double* col = a.col_out + (size_t)b * a.fa.w;
+    double* ls = a.ls_out + (size_t)b * a.fa.h * Pw.nleaves;
+    // (block uniform: the transform of new_method.py:134-179 the caller selected; identity is what both drivers pass)
+    if (XT && a.p_lut)
+      profiles_u8_block<ATTWARP_T_LUT>(att, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_LUT>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf], Pw.nleaves,
+                                       leaf, col, ls, pool, a.p_lut);
+    else if (XT && a.p_square)
+      profiles_u8_block<ATTWARP_T_SQUARE>(att, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_SQUARE>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf],
+                                          Pw.nleaves, leaf, col, ls, pool);
+    else
+      profiles_u8_block<ATTWARP_T_IDENTITY>(att, a.fa.h, a.fa.w, XfAttention<ATTWARP_T_IDENTITY>{1.0, 1.0}, Pw.off[leaf], Pw.len[leaf],
+                                            Pw.nleaves, leaf, col, ls, pool);
   } else if (kind == CHAIN_L) {
     const int b = j / a.l_bx, bx = j - b * a.l_bx;
 #ifdef ATTWARP_TUNING
@@ -89,16 +102,16 @@ __device__ __forceinline__ int chain_step_block(const ChainStepArgs& a, const Pa
   return kind;
 }
 
-template <int KI, int KD, int PD, int MINW>
+template <int KI, int KD, int PD, int MINW, bool XT>
 __global__ __launch_bounds__(CHAIN_NT, MINW) void mask_chain_step_kernel(const ChainStepArgs a, const PairwisePlan Pw,
                                                                          const PairwisePlan Ph) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pool[];
 #ifdef ATTWARP_TUNING
   const TraceStart t0 = trace_now();
-  const int kind = chain_step_block<KI, KD, PD>(a, Pw, Ph, pool);
+  const int kind = chain_step_block<KI, KD, PD, XT>(a, Pw, Ph, pool);
   trace_block(a.trace, t0, kind);
 #else
-  chain_step_block<KI, KD, PD>(a, Pw, Ph, pool);
+  chain_step_block<KI, KD, PD, XT>(a, Pw, Ph, pool);
 #endif
 }
 
@@ -108,11 +121,14 @@ static int launch_chain_kikd(const ChainStepArgs& a, const PairwisePlan& Pw, con
   constexpr int PD = KI <= 2 ? 4 : 2;       // as launch_u8i_depth (remap_u8.hip)
 #ifdef ATTWARP_TUNING
   if (tune(TUNE_CHAIN_WAVES) == 14 - CHAIN_WAVES_DEFAULT) {     // the other of {6, 8}
-    hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, 14 - CHAIN_WAVES_DEFAULT>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
+    hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, 14 - CHAIN_WAVES_DEFAULT, false>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
     return check_launch("mask_chain_step_kernel");
   }
 #endif
-  hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, CHAIN_WAVES_DEFAULT>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
+  if (a.p_lut || a.p_square || a.fa.apply_inverse)
+    hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, CHAIN_WAVES_DEFAULT, true>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
+  else
+    hipLaunchKernelGGL((mask_chain_step_kernel<KI, KD, PD, CHAIN_WAVES_DEFAULT, false>), dim3(grid), dim3(CHAIN_NT), lds, st, a, Pw, Ph);
   return check_launch("mask_chain_step_kernel");
 }
 template <int KI>
@@ -135,8 +151,12 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
                                        const float* rev_in, const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
                                        const int32_t* bounds_y, const int32_t* kk_y, int ksize_y, uint8_t* mota_out,
                                        const float* masks, int g, int kernel_size, float enhance_coe, float* rev_out,
-                                       void* stream) {
+                                       int transform, double exp_scale, double exp_divisor, int apply_inverse,
+                                       const double* transform_lut, void* stream) {
   ATTWARP_REQUIRE(images && out && map_x && map_y, "mask_chain_step: null image / map pointer");
+  ATTWARP_REQUIRE(transform >= ATTWARP_T_IDENTITY && transform <= ATTWARP_T_LOG, "mask_chain_step: unknown transform %d", transform);
+  ATTWARP_REQUIRE(transform <= ATTWARP_T_SQUARE || transform_lut,
+                  "mask_chain_step: the sqrt / exp / log transforms need transform_lut (attwarp_attention_transform_lut)");
   ATTWARP_REQUIRE(sums_in && map_x_next && map_y_next && mota_in && sums_out && rev_in && bounds_x && kk_x && bounds_y && kk_y &&
                   mota_out && masks && rev_out, "mask_chain_step: null stage pointer");
   ATTWARP_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && H_out > 0 && W_out > 0 && g > 0, "mask_chain_step: non-positive size");
@@ -179,8 +199,10 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
   a.col_out = static_cast<double*>(sums_out);
   a.ls_out = a.col_out + (size_t)B * W;
   const double* col_in = static_cast<const double*>(sums_in);
-  a.fa = MapsFinalizeArgs{col_in, col_in + (size_t)B * W, H, W, W_out, H_out, ATTWARP_T_IDENTITY, 1.0, 1.0, 0, map_x_next, map_y_next,
-                          pw_depth(Pw)};
+  a.p_lut = transform > ATTWARP_T_SQUARE ? transform_lut : nullptr;
+  a.p_square = transform == ATTWARP_T_SQUARE;
+  a.fa = MapsFinalizeArgs{col_in, col_in + (size_t)B * W, H, W, W_out, H_out, transform, exp_scale, exp_divisor, apply_inverse ? 1 : 0,
+                          map_x_next, map_y_next, pw_depth(Pw)};
   a.ord.nF = 2 * B; a.ord.nV = B;
   a.ord.nF8 = (2 * B + 7) / 8;
   a.ord.nV8 = (B + 7) / 8;
@@ -196,7 +218,7 @@ extern "C" int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int 
 #endif
   const long long octs = chain_order_octets(a.ord);
   if (octs * 8 > 2147483647LL) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: grid too large");
-  size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
+  size_t lds = std::max(std::max(u8k::u8i_lds_bytes(), a.p_lut ? profiles_u8_lds_bytes<ATTWARP_T_LUT>() : profiles_u8_lds_bytes<ATTWARP_T_IDENTITY>()),
                         std::max(maps_finalize_lds_bytes(H, W, Pw, Ph), std::max(lanczos_strip_lds_bytes(g, g), mask_postproc_lds_bytes())));
   if (lds > LDS_DEFAULT_MAX) return fail(ATTWARP_E_UNSUPPORTED, "mask_chain_step: %zu bytes of LDS per workgroup (> %zu)", lds, LDS_DEFAULT_MAX);
   const int ki = ((a.rp.VL >> 2) + u8k::NT - 1) / u8k::NT, kd = ((a.rp.OVL >> 2) + u8k::NT - 1) / u8k::NT;

@@ -377,6 +377,28 @@ extern "C" int attwarp_adaptive_avg_pool(const float* A, int B, int H, int W, in
   return check_launch("adaptive_pool_kernel");
 }
 
+// ---- the 256-entry table of the transformed byte values: XfAttention<TR>(0 .. 255), by the device functions the uint8 profile
+// kernel uses for its own per-workgroup table (bit-identical), for the one-launch chain steps (chain_step.hip, chain_ragged.hip)
+__global__ __launch_bounds__(256) void attention_lut_kernel(int transform, double exp_scale, double exp_divisor, double* __restrict__ lut) {
+  const double v = (double)threadIdx.x;
+  double r;
+  switch (transform) {
+    case ATTWARP_T_SQUARE: r = XfAttention<ATTWARP_T_SQUARE>{exp_scale, exp_divisor}(v); break;
+    case ATTWARP_T_SQRT: r = XfAttention<ATTWARP_T_SQRT>{exp_scale, exp_divisor}(v); break;
+    case ATTWARP_T_EXP: r = XfAttention<ATTWARP_T_EXP>{exp_scale, exp_divisor}(v); break;
+    case ATTWARP_T_LOG: r = XfAttention<ATTWARP_T_LOG>{exp_scale, exp_divisor}(v); break;
+    default: r = XfAttention<ATTWARP_T_IDENTITY>{exp_scale, exp_divisor}(v); break;
+  }
+  lut[threadIdx.x] = r;
+}
+
+extern "C" int attwarp_attention_transform_lut(int transform, double exp_scale, double exp_divisor, double* lut, void* stream) {
+  ATTWARP_REQUIRE(lut, "attention_transform_lut: null pointer");
+  ATTWARP_REQUIRE(transform >= ATTWARP_T_IDENTITY && transform <= ATTWARP_T_LOG, "attention_transform_lut: unknown transform %d", transform);
+  hipLaunchKernelGGL(attention_lut_kernel, dim3(1), dim3(256), 0, as_stream(stream), transform, exp_scale, exp_divisor, lut);
+  return check_launch("attention_lut_kernel");
+}
+
 extern "C" int attwarp_axis_maps_from_attention(const void* att, int dtype, int B, int h, int w, int new_w, int new_h,
                                                 int transform, double exp_scale, double exp_divisor,
                                                 int apply_inverse, float* map_x, float* map_y, void* ws,

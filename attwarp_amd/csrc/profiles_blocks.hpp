@@ -20,6 +20,10 @@ struct XfClampPos {  // gt_marginals: A.clamp_min(0)
   __device__ __forceinline__ double operator()(double v) const { return (v != v) ? v : (v > 0.0 ? v : 0.0); }  // NaN propagates
   __device__ __forceinline__ double from_f32(float v) const { return (double)clamp_pos_f32(v); }
 };
+// (internal) the uint8 block with its 256-entry table of XfAttention<TR>(byte) handed in by the caller instead of built per
+// workgroup: the one-launch chain steps serve sqrt / exp / log from a table computed ONCE per (transform, exp_scale,
+// exp_divisor) by attwarp_attention_transform_lut with the same device functions -- no exp / log code in those kernels
+constexpr int ATTWARP_T_LUT = 100;
 template <int TR>
 struct XfAttention {  // new_method: max(att,0) -> transform -> + BASE_ATTENTION   (TR = ATTWARP_T_*, compile time)
   double exp_scale, exp_divisor;
@@ -242,16 +246,18 @@ constexpr size_t profiles_u8_lds_bytes() {
 }
 // img: ONE image's [H,W] bytes; (coff, len) = leaf `leaf` of the row plan of W (nleaves leaves); col: that image's [W]
 // column sums, ls: its [H,nleaves] per-leaf row sums
+// TR == ATTWARP_T_LUT: ext_lut = 256 doubles in global memory, XfAttention<TR>(0 .. 255) of the caller's transform (xf unused)
 template <int TR, bool UA = false>
 __device__ __forceinline__ void profiles_u8_block(const uint8_t* __restrict__ img, int H, int W, const XfAttention<TR>& xf,
                                                   int coff, int len, int nleaves, int leaf, double* __restrict__ col,
-                                                  double* __restrict__ ls, uint8_t* lds) {
+                                                  double* __restrict__ ls, uint8_t* lds, const double* __restrict__ ext_lut = nullptr) {
   constexpr bool ARITH = (TR == ATTWARP_T_IDENTITY || TR == ATTWARP_T_SQUARE);
   uint8_t (*tile)[U8_RB * U8_STR] = reinterpret_cast<uint8_t (*)[U8_RB * U8_STR]>(lds);
   double* lut = reinterpret_cast<double*>(lds + 2 * U8_RB * U8_STR);
   const int tid = threadIdx.x;
   const int m = len >> 3;                                          // steps of the stride-8 accumulators
-  if (!ARITH) lut[tid] = xf((double)tid);
+  if (TR == ATTWARP_T_LUT) lut[tid] = ext_lut[tid];
+  else if (!ARITH) lut[tid] = xf((double)tid);
   const uint8_t* base = img + coff;
   // element transform of a byte held as float (exact)
   auto tf = [&](float f) -> double {

@@ -180,9 +180,7 @@ def save_warped_image(image_path, att_map, original_image_save_path, masked_over
             except Exception:
                 raise ValueError(f"Could not read image: {image_path}")
         else:
-            image = np.array(image_path)
-            if image.ndim == 3 and image.shape[2] >= 3:
-                image = image[:, :, :3][:, :, ::-1]       # RGB -> BGR
+            image = _cvt_rgb2bgr(np.array(image_path))
         image = np.ascontiguousarray(image)
         if original_image_save_path:
             _imwrite(original_image_save_path, image)
@@ -200,6 +198,21 @@ def save_warped_image(image_path, att_map, original_image_save_path, masked_over
     except Exception as e:  # noqa: BLE001 - reference behaviour
         print(f"Error during processing: {e}", file=sys.stderr)
         return False
+
+
+def _cvt_rgb2bgr(image: np.ndarray) -> np.ndarray:
+    """``cv2.cvtColor(image, cv2.COLOR_RGB2BGR)`` as the reference applies it to ``np.array(PIL image)`` (:421-422), with
+    OpenCV's input checks: the conversion takes 3- or 4-channel sources of depth uint8 / uint16 / float32 (OpenCV
+    ``cvtColorBGR2BGR``: ``CvtHelper<Set<3, 4>, Set<3, 4>, Set<CV_8U, CV_16U, CV_32F>>``, destination 3 channels) and raises
+    ``cv2.error`` for everything else -- a mode-"L" / "1" / "I" / "F" image arrives as a 2-D array and FAILS there, so the
+    reference's ``save_warped_image`` prints the error and returns False (:504-506); an RGBA image loses its alpha channel.
+    The same conditions raise here (ValueError standing in for cv2.error)."""
+    if image.ndim != 3 or image.shape[2] not in (3, 4):
+        raise ValueError(f"cvtColor(COLOR_RGB2BGR): invalid number of channels in input image: shape {image.shape} "
+                         "(3 or 4 channels expected)")
+    if image.dtype not in (np.uint8, np.uint16, np.float32):
+        raise ValueError(f"cvtColor(COLOR_RGB2BGR): unsupported depth of input image: {image.dtype}")
+    return image[:, :, 2::-1]                          # R,G,B[,A] -> B,G,R
 
 
 def _imwrite(path, bgr: np.ndarray):

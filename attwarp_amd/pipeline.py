@@ -804,36 +804,59 @@ class MaskChainStream:
         self._dev = dev
         lib = _lib.load()
         self.outs = [torch.empty(B, self.Ho, self.Wo, C, device=dev, dtype=torch.uint8) for _ in range(self.n)]
-        # parity-indexed intermediates (batch j uses slot j % 2 of each)
-        self.rev = [torch.empty(B, self.g, self.g, device=dev, dtype=torch.float32) for _ in (0, 1)]
-        self.mota = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in (0, 1)]
-        self.ws = [torch.empty(lib.attwarp_axis_sums_workspace_bytes(B, H, W), device=dev, dtype=torch.uint8) for _ in (0, 1)]
-        self.maps = [(torch.empty(B, self.Wo, device=dev, dtype=torch.float32),
-                      torch.empty(B, self.Ho, device=dev, dtype=torch.float32)) for _ in (0, 1)]
-        self._tmp = torch.empty(B, self.g, W, device=dev, dtype=torch.uint8)       # two-pass Lanczos forms only
-        self._tx = _tables.lanczos_tables(self.g, W, dev) if W != self.g else (None, None, 0)
-        self._ty = _tables.lanczos_tables(self.g, H, dev) if H != self.g else (None, None, 0)
         self.k = 0
         self._graphs = {}
         self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.pattern = pattern
-        if pattern in ("auto", "fused"):
-            try:
-                self._fused_launch(0, dry=True)
-                self.pattern = "fused"
-            except (_lib.AttWarpError, AttributeError):
-                if pattern == "fused":
-                    raise
-                self.pattern = "branches"
-        if pattern == "ragged" or (pattern == "auto" and self.pattern == "branches"):
-            ok = (self.mode == "cv2" and self.transform == "identity" and not self.apply_inverse
-                  and ragged_eligible(H, W, C, self.g) and self.Wo * C <= RAGGED_MAX_ROW_BYTES)
-            if ok:
-                self.pattern = "ragged"
-                self._rb = {}                 # (ring slot, batch parity) -> RaggedBatch: the slot's images / masks / output,
-            elif pattern == "ragged":         # intermediates of that parity
+        # the table of the transformed byte values the one-launch steps read for sqrt / exp / log (a constant of the stream)
+        self._lut = _tables.attention_transform_lut(self.transform, self.exp_scale, self.exp_divisor, dev)
+        if pattern == "ragged":               # (the uniform path's intermediates are not needed: every batch brings its own)
+            if not (self.mode == "cv2" and ragged_eligible(H, W, C, self.g) and self.Wo * C <= RAGGED_MAX_ROW_BYTES):
                 raise _lib.AttWarpError("MaskChainStream: this shape / these options do not run on the ragged chain kernel")
+            self._build_ragged()
+        else:
+            # parity-indexed intermediates (batch j uses slot j % 2 of each)
+            self.rev = [torch.empty(B, self.g, self.g, device=dev, dtype=torch.float32) for _ in (0, 1)]
+            self.mota = [torch.empty(B, H, W, device=dev, dtype=torch.uint8) for _ in (0, 1)]
+            self.ws = [torch.empty(lib.attwarp_axis_sums_workspace_bytes(B, H, W), device=dev, dtype=torch.uint8) for _ in (0, 1)]
+            self.maps = [(torch.empty(B, self.Wo, device=dev, dtype=torch.float32),
+                          torch.empty(B, self.Ho, device=dev, dtype=torch.float32)) for _ in (0, 1)]
+            self._tmp = torch.empty(B, self.g, W, device=dev, dtype=torch.uint8)       # two-pass Lanczos forms only
+            self._tx = _tables.lanczos_tables(self.g, W, dev) if W != self.g else (None, None, 0)
+            self._ty = _tables.lanczos_tables(self.g, H, dev) if H != self.g else (None, None, 0)
+            if pattern in ("auto", "fused"):
+                try:
+                    self._fused_launch(0, dry=True)
+                    self.pattern = "fused"
+                except (_lib.AttWarpError, AttributeError):
+                    if pattern == "fused":
+                        raise
+                    self.pattern = "branches"
+            if pattern == "auto" and self.pattern == "branches":
+                if self.mode == "cv2" and ragged_eligible(H, W, C, self.g) and self.Wo * C <= RAGGED_MAX_ROW_BYTES:
+                    self.pattern = "ragged"
+                    del self.rev, self.mota, self.ws, self.maps, self._tmp
+                    self._build_ragged()
         self.depth = {"serial": 0, "branches": 2, "fused": 4, "ragged": 4}[self.pattern]
+
+    def _build_ragged(self):
+        """Every (ring slot, batch parity) RaggedBatch of the stream, built HERE -- before any capture: building one plans
+        a table on the host and uploads it, which must never become a node of a HIP graph (it would be re-executed, from a
+        staging buffer that has been reused since, on every replay).  Batch j of the stream lives in ring slot j % n and
+        uses the intermediates of parity j & 1: one RaggedBatch per (slot, parity) that occurs -- n for an even ring, 2 n for
+        an odd one -- each with its own table (the table names the slot's images), all batches of one parity SHARING one set
+        of intermediates (rev / mota / sums / maps: two sets in all, as the uniform step)."""
+        import math
+        self._rb = {}
+        first = {}
+        for j in range(math.lcm(2, self.n)):
+            key = (j % self.n, j & 1)
+            img = self.images[key[0]]
+            rb = RaggedBatch([img[b] for b in range(self.B)], (self.Ho, self.Wo), self.g, out=self.outs[key[0]],
+                             share=first.get(key[1]))
+            rb.masks = self.masks[key[0]]
+            first.setdefault(key[1], rb)
+            self._rb[key] = rb
 
     # ---- the stages on static buffers (same entry points as warp_from_masks) ----
     def _V(self, j):
@@ -862,8 +885,8 @@ class MaskChainStream:
         """R(k) | F(k+1) | P(k+2) | L(k+3) | V(k+4) as ONE launch (attwarp_mask_chain_step).  ``dry``: the eligibility
         trial of the constructor -- the stages write the buffers of the parities they would write in step k, from whatever
         the inputs hold; prime() overwrites all of it."""
-        if self.mode != "cv2" or self.transform != "identity" or self.apply_inverse:
-            raise _lib.AttWarpError("mask chain step: cv2 mode and the identity transform only (what main_batched.py passes)")
+        if self.mode != "cv2":
+            raise _lib.AttWarpError("mask chain step: cv2 mode only (the integer uint8 resample; what both reference drivers compute)")
         (bx, kx, ksx), (by, ky, ksy) = self._tx, self._ty
         if bx is None or by is None:
             raise _lib.AttWarpError("mask chain step: the mask must be up-sampled on both axes")
@@ -877,22 +900,18 @@ class MaskChainStream:
                  ptr(self.mota[p]), ptr(self.ws[p]),                      # P(k+2)
                  ptr(self.rev[q]), ptr(bx), ptr(kx), ksx, ptr(by), ptr(ky), ksy, ptr(self.mota[q]),   # L(k+3)
                  ptr(self.masks[(k + 4) % self.n]), self.g, self.kernel_size, self.enhance_coe, ptr(self.rev[p]),   # V(k+4)
+                 _lib.TRANSFORM_IDS[self.transform], self.exp_scale, self.exp_divisor, int(self.apply_inverse), ptr(self._lut),
                  stream_ptr(self._dev))
 
     def _ragged(self, j):
-        """Batch j of the stream as a RaggedBatch over slot j % n (its images, masks and output buffer) with the
-        intermediates of parity j & 1 -- built once per (slot, parity)."""
-        key = (j % self.n, j & 1)
-        rb = self._rb.get(key)
-        if rb is None:
-            img = self.images[key[0]]
-            rb = RaggedBatch([img[b] for b in range(self.B)], (self.Ho, self.Wo), self.g, out=self.outs[key[0]])
-            rb.masks = self.masks[key[0]]
-            self._rb[key] = rb
-        return rb
+        """Batch j of the stream: the RaggedBatch of slot j % n (its images, masks and output buffer) with the
+        intermediates of parity j & 1 (all built by the constructor)."""
+        return self._rb[(j % self.n, j & 1)]
 
     def _ragged_launch(self, **stages):
-        ragged_chain_launch(**{s: self._ragged(j) for s, j in stages.items()}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+        ragged_chain_launch(**{s: self._ragged(j) for s, j in stages.items()}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size,
+                            transform=self.transform, exp_scale=self.exp_scale, exp_divisor=self.exp_divisor,
+                            apply_inverse=self.apply_inverse)
 
     # ---- driving ----
     def prime(self):
@@ -1010,7 +1029,7 @@ def ragged_eligible(h: int, w: int, c: int, g: int = GRID) -> bool:
 _RAGGED_IMAGE_DTYPE = np.dtype([("image", "<u8"), ("bounds_x", "<u8"), ("kk_x", "<u8"), ("bounds_y", "<u8"), ("kk_y", "<u8"),
                                 ("H", "<i4"), ("W", "<i4"), ("ksize_x", "<i4"), ("reserved", "<i4")])      # attwarp_ragged_image
 _AXIS_TABLES: dict = {}
-_STAGING: list = []                   # pinned staging buffers: [tensor, event of the last copy out of it]
+_STAGING: dict = {}                   # device index -> pinned staging buffers: [tensor, event of the last copy out of it, free]
 _STAGING_LOCK = __import__("threading").Lock()     # (host threads on their own streams share the pool)
 
 
@@ -1024,34 +1043,45 @@ def _axis_tables(g: int, n: int, dev: torch.device):
     t = _AXIS_TABLES.get(key)
     if t is None:
         b, k, ks = _tables.lanczos_tables(g, n, dev)
-        while len(_AXIS_TABLES) >= _AXIS_TABLES_MAX:
-            _AXIS_TABLES.pop(next(iter(_AXIS_TABLES)))
-        t = _AXIS_TABLES[key] = (b.data_ptr(), k.data_ptr(), ks, b, k)
+        t = (b.data_ptr(), k.data_ptr(), ks, b, k)
+        with _STAGING_LOCK:                   # (host threads share the cache: insert + evict under one lock)
+            while len(_AXIS_TABLES) >= _AXIS_TABLES_MAX:
+                _AXIS_TABLES.pop(next(iter(_AXIS_TABLES)), None)
+            _AXIS_TABLES[key] = t
     return t
 
 
 def _upload(host: "np.ndarray", dst: torch.Tensor):
-    """host bytes -> dst (device uint8), asynchronously on the current stream through a pooled pinned buffer."""
+    """host bytes -> dst (device uint8), asynchronously on the current stream of dst's device through a pooled pinned buffer
+    (one pool per device: a slot's event is recorded on, and queried against, the stream that carries its copy).
+    Refuses to run inside a stream capture: the copy would become a graph node and be re-executed on every replay from a
+    staging buffer that has long been reused."""
+    dev = dst.device
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("attwarp_amd: a host-to-device table upload inside a stream capture (build RaggedBatch objects / call "
+                           "upload_images before capturing; a captured copy would replay from a reused staging buffer)")
     n = host.size
-    with _STAGING_LOCK:
-        slot = None
-        for s in _STAGING:
-            if s[0].numel() >= n and s[2] and s[1].query():
-                slot = s
-                break
-        if slot is None:
-            if len(_STAGING) >= 64:           # (only if nothing ever completes: keep the pool bounded)
-                torch.cuda.synchronize()
-                del _STAGING[1:]
-            slot = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event(), True]
-            _STAGING.append(slot)
-        slot[2] = False                       # taken: nobody else may pick it until its copy has been enqueued and recorded
-    try:
-        slot[0][:n].numpy()[:] = host
-        dst.copy_(slot[0][:n], non_blocking=True)
-        slot[1].record()
-    finally:
-        slot[2] = True
+    with torch.cuda.device(dev):
+        with _STAGING_LOCK:
+            pool = _STAGING.setdefault(dev.index, [])
+            slot = None
+            for s in pool:
+                if s[0].numel() >= n and s[2] and s[1].query():
+                    slot = s
+                    break
+            if slot is None:
+                if len(pool) >= 64:               # (only if nothing ever completes: keep the pool bounded)
+                    torch.cuda.synchronize(dev)
+                    del pool[1:]
+                slot = [torch.empty(max(n, 1 << 16), dtype=torch.uint8).pin_memory(), torch.cuda.Event(), True]
+                pool.append(slot)
+            slot[2] = False                       # taken: nobody else may pick it until its copy has been enqueued and recorded
+        try:
+            slot[0][:n].numpy()[:] = host
+            dst.copy_(slot[0][:n], non_blocking=True)
+            slot[1].record(torch.cuda.current_stream(dev))
+        finally:
+            slot[2] = True
 
 
 class RaggedBatch:
@@ -1060,7 +1090,10 @@ class RaggedBatch:
     ``rev`` [B,g,g], ``mota`` (the up-sampled masks, packed), ``sums`` (axis sums), ``maps`` and ``out`` [B,H_out,W_out,C].
     The images are referenced, not copied: keep them alive and unchanged until the batch's resample has run."""
 
-    def __init__(self, images, out_size=(500, 500), g: int = GRID, out: Optional[torch.Tensor] = None):
+    def __init__(self, images, out_size=(500, 500), g: int = GRID, out: Optional[torch.Tensor] = None,
+                 share: Optional["RaggedBatch"] = None):
+        """``share``: a RaggedBatch of the SAME image sizes whose intermediates (rev / mota / sums / maps) this batch adopts
+        instead of allocating its own -- the batches of one parity of a stream never have two stages in flight at once."""
         import ctypes
         images = list(images)
         if not images:
@@ -1099,11 +1132,17 @@ class RaggedBatch:
         self.table_dev = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         _upload(self.table_host, self.table_dev)
         h = self.header
-        self.rev = torch.empty(self.B, self.g, self.g, device=dev, dtype=torch.float32)
-        self.mota = torch.empty(int(h.mota_bytes), device=dev, dtype=torch.uint8)
-        self.sums = torch.empty(int(h.sums_bytes) // 8, device=dev, dtype=torch.float64)
-        self.map_x = torch.empty(self.B, self.Wo, device=dev, dtype=torch.float32)
-        self.map_y = torch.empty(self.B, self.Ho, device=dev, dtype=torch.float32)
+        if share is not None:
+            if (share.B, share.g, share.Ho, share.Wo, int(share.header.mota_bytes), int(share.header.sums_bytes)) != \
+                    (self.B, self.g, self.Ho, self.Wo, int(h.mota_bytes), int(h.sums_bytes)) or share._dev != dev:
+                raise ValueError("RaggedBatch: `share` must be a batch of the same image sizes on the same device")
+            self.rev, self.mota, self.sums, self.map_x, self.map_y = share.rev, share.mota, share.sums, share.map_x, share.map_y
+        else:
+            self.rev = torch.empty(self.B, self.g, self.g, device=dev, dtype=torch.float32)
+            self.mota = torch.empty(int(h.mota_bytes), device=dev, dtype=torch.uint8)
+            self.sums = torch.empty(int(h.sums_bytes) // 8, device=dev, dtype=torch.float64)
+            self.map_x = torch.empty(self.B, self.Wo, device=dev, dtype=torch.float32)
+            self.map_y = torch.empty(self.B, self.Ho, device=dev, dtype=torch.float32)
         if out is None:
             out = torch.empty(self.B, self.Ho, self.Wo, C, device=dev, dtype=torch.uint8)
         elif tuple(out.shape) != (self.B, self.Ho, self.Wo, C) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != dev:
@@ -1165,12 +1204,17 @@ def upload_images(images, device=None):
 
 
 def ragged_chain_launch(R: Optional[RaggedBatch] = None, F: Optional[RaggedBatch] = None, P: Optional[RaggedBatch] = None,
-                        L: Optional[RaggedBatch] = None, V: Optional[RaggedBatch] = None, enhance_coe=10, kernel_size=3):
+                        L: Optional[RaggedBatch] = None, V: Optional[RaggedBatch] = None, enhance_coe=10, kernel_size=3,
+                        transform="identity", exp_scale=1.0, exp_divisor=1.0, apply_inverse=False):
     """ONE launch of ``attwarp_mask_chain_ragged``: the resample of batch R, the map construction of F, the marginals of P,
     the mask up-sampling of L and revise_mask of V (``V.masks`` [B,g,g] float32) -- five different batches of a stream, or
-    any subset (one batch alone: five launches, V -> L -> P -> F -> R)."""
+    any subset (one batch alone: five launches, V -> L -> P -> F -> R).  ``transform`` .. ``apply_inverse``:
+    save_warped_image's keyword arguments (new_method.py:405-411), used by P and F; unknown names mean identity (:400-403)."""
     some = next(b for b in (R, F, P, L, V) if b is not None)
     dev = some._dev
+    if transform not in nm._KNOWN:
+        transform = "identity"
+    lut = _tables.attention_transform_lut(transform, exp_scale, exp_divisor, dev) if P is not None else None
     def tab(b):
         return (None, None) if b is None else (b.table_host.ctypes.data, ptr(b.table_dev))
     if V is not None and (V.masks is None or V.masks.dtype != torch.float32 or tuple(V.masks.shape) != (V.B, V.g, V.g)
@@ -1183,26 +1227,41 @@ def ragged_chain_launch(R: Optional[RaggedBatch] = None, F: Optional[RaggedBatch
              *tab(P), ptr(P.mota) if P else None, ptr(P.sums) if P else None,
              *tab(L), ptr(L.rev) if L else None, ptr(L.mota) if L else None,
              ptr(V.masks) if V else None, V.B if V else 0, some.g, int(kernel_size), float(enhance_coe), ptr(V.rev) if V else None,
+             _lib.TRANSFORM_IDS[transform], float(exp_scale), float(exp_divisor), int(bool(apply_inverse)), ptr(lut),
              stream_ptr(dev))
 
 
 def warp_from_masks_ragged(images, attn24: torch.Tensor, out_size=(500, 500), enhance_coe=10, kernel_size=3,
+                           transform="identity", exp_scale=1.0, exp_divisor=1.0, apply_inverse=False, mode: str = "cv2",
                            return_batch: bool = False):
     """The ``main_batched.py:243-287`` chain for a batch of DIFFERENTLY sized images, as that driver holds them:
     ``images``: list of uint8 [H_i,W_i,C] GPU tensors (any sizes, any width -- 683 x 1024 like 1024 x 768); ``attn24``
     [B,24,24] -> dense uint8 [B,H_out,W_out,C].  Five launches for the whole batch (revise_mask, LANCZOS up-sampling to
-    every image's own size, float64 marginals, CDF / np.interp maps, cv2 resample), each over all images at once;
-    identity transform and cv2 arithmetic (what main_batched.py passes).  Images outside the ragged kernel's limits
-    (rows wider than 4096 bytes, sides <= 24 or > 8192) run through :func:`warp_from_masks` one by one."""
+    every image's own size, float64 marginals, CDF / np.interp maps, cv2 resample), each over all images at once.
+    ``transform`` / ``exp_scale`` / ``exp_divisor`` / ``apply_inverse``: save_warped_image's own keyword arguments
+    (new_method.py:405-411; the driver passes "identity", 1.0, 1.0, False); same signature as :func:`warp_from_masks`.
+    Images outside the ragged kernel's limits (rows wider than 4096 bytes, sides <= 24 or > 8192) and ``mode="exact"``
+    (the ragged resample is the integer cv2 one) run through :func:`warp_from_masks` one by one."""
     images = list(images)
     B = len(images)
-    if attn24.shape[0] != B:
-        raise ValueError("warp_from_masks_ragged: one 24 x 24 map per image expected")
+    if B == 0:
+        raise ValueError("warp_from_masks_ragged: empty batch")
+    if attn24.dim() != 3 or attn24.shape[0] != B or attn24.shape[1] != attn24.shape[2]:
+        raise ValueError("warp_from_masks_ragged: one square [g,g] map per image expected ([B,g,g])")
     dev = require_gpu(attn24, *images)
+    if any(i.dim() != 3 or i.dtype != torch.uint8 for i in images):
+        raise TypeError("warp_from_masks_ragged: images must be uint8 [H,W,C] tensors")
+    C = int(images[0].shape[2])
+    if any(int(i.shape[2]) != C for i in images):
+        raise ValueError("warp_from_masks_ragged: the images of one batch must share their channel count "
+                         f"(got {sorted({int(i.shape[2]) for i in images})}): the output is one dense [B,H_out,W_out,C] tensor")
+    if mode not in ("cv2", "exact"):
+        raise ValueError(f"warp_from_masks_ragged: unknown mode {mode!r}")
     g = int(attn24.shape[-1])
     Ho, Wo = int(out_size[0]), int(out_size[1])
-    ok = [ragged_eligible(int(i.shape[0]), int(i.shape[1]), int(i.shape[2]), g) for i in images]
-    if Wo * int(images[0].shape[2]) > RAGGED_MAX_ROW_BYTES:
+    xf = dict(transform=transform, exp_scale=exp_scale, exp_divisor=exp_divisor, apply_inverse=apply_inverse)
+    ok = [mode == "cv2" and ragged_eligible(int(i.shape[0]), int(i.shape[1]), C, g) for i in images]
+    if Wo * C > RAGGED_MAX_ROW_BYTES:
         ok = [False] * B
     masks = attn24.float().contiguous()
     rb = None
@@ -1214,16 +1273,16 @@ def warp_from_masks_ragged(images, attn24: torch.Tensor, out_size=(500, 500), en
     if rb is not None:
         rb.masks = masks
         for stage in "VLPFR":
-            ragged_chain_launch(**{stage: rb}, enhance_coe=enhance_coe, kernel_size=kernel_size)
+            ragged_chain_launch(**{stage: rb}, enhance_coe=enhance_coe, kernel_size=kernel_size, **xf)
         return (rb.out, rb) if return_batch else rb.out
-    out = torch.empty(B, Ho, Wo, int(images[0].shape[2]), device=dev, dtype=torch.uint8)
+    out = torch.empty(B, Ho, Wo, C, device=dev, dtype=torch.uint8)
     idx = [b for b in range(B) if ok[b]]
     if idx:
-        sub = warp_from_masks_ragged([images[b] for b in idx], masks[idx], out_size, enhance_coe, kernel_size)
+        sub = warp_from_masks_ragged([images[b] for b in idx], masks[idx], out_size, enhance_coe, kernel_size, **xf)
         out[idx] = sub
     for b in range(B):
         if not ok[b]:
-            out[b] = warp_from_masks(images[b][None], masks[b:b + 1], out_size, enhance_coe, kernel_size)[0]
+            out[b] = warp_from_masks(images[b][None], masks[b:b + 1], out_size, enhance_coe, kernel_size, mode=mode, **xf)[0]
     return (out, None) if return_batch else out
 
 
@@ -1242,16 +1301,23 @@ class RaggedMaskChainStream:
 
     DEPTH = 4
 
-    def __init__(self, out_size=(500, 500), enhance_coe=10, kernel_size=3, g: int = GRID):
+    def __init__(self, out_size=(500, 500), enhance_coe=10, kernel_size=3, g: int = GRID, transform="identity", exp_scale=1.0,
+                 exp_divisor=1.0, apply_inverse=False):
         self.out_size = (int(out_size[0]), int(out_size[1]))
         self.enhance_coe, self.kernel_size, self.g = float(enhance_coe), int(kernel_size), int(g)
+        # save_warped_image's keyword arguments (new_method.py:405-411), constants of the stream
+        self._xf = dict(transform=transform if transform in nm._KNOWN else "identity", exp_scale=float(exp_scale),
+                        exp_divisor=float(exp_divisor), apply_inverse=bool(apply_inverse))
         self._q = []                       # the batches in flight, oldest first: [k-4 .. k]
         self._graphs = {}
+
+    def _stages(self, **stages):
+        ragged_chain_launch(**stages, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size, **self._xf)
 
     def _launch(self, q):
         """q: the five batches [R, F, P, L, V] of this step (None where the stream has none)."""
         if any(b is not None for b in q):
-            ragged_chain_launch(R=q[0], F=q[1], P=q[2], L=q[3], V=q[4], enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+            self._stages(R=q[0], F=q[1], P=q[2], L=q[3], V=q[4])
 
     def push(self, images, attn24: torch.Tensor, out: Optional[torch.Tensor] = None):
         rb = RaggedBatch(images, self.out_size, self.g, out=out)
@@ -1292,7 +1358,7 @@ class RaggedMaskChainStream:
         r = self._ring
         for j, stages in ((0, "VLPF"), (1, "VLP"), (2, "VL"), (3, "V")):
             for s in stages:
-                ragged_chain_launch(**{s: r[j]}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+                self._stages(**{s: r[j]})
 
     def _step(self, k):
         r, n = self._ring, len(self._ring)
@@ -1319,7 +1385,7 @@ class RaggedMaskChainStream:
         r, n, k = self._ring, len(self._ring), self.k
         for j, stages in ((k, "R"), (k + 1, "FR"), (k + 2, "PFR"), (k + 3, "LPFR")):
             for s in stages:
-                ragged_chain_launch(**{s: r[j % n]}, enhance_coe=self.enhance_coe, kernel_size=self.kernel_size)
+                self._stages(**{s: r[j % n]})
         self.k += self.DEPTH
 
 

@@ -470,6 +470,26 @@ def time_overlapped(ow, K: int, W: int, D, prewarm_s: float = 0.0):
     return D.max_over_ranks(wall), wall
 
 
+def rank_fields(D, world: int, units_per_rank: float, wall_local: float, wall: float, ok: bool = True) -> dict:
+    """What a secondary leg reports when it ran on EVERY rank of a process group (the main line's discipline: barrier +
+    synchronize on both sides of exactly K steps, `wall` = max over ranks): the whole-job rate, every rank's own rate, the
+    job's rate against N x the mean rank (1.0 = the ranks lose nothing to each other beyond their own spread), and the AND over
+    ranks of the leg's own bit-identity check.  All ranks must call it (two collectives)."""
+    per = D.all_gather_counters({"rate": units_per_rank / wall_local, "ok": 1.0 if ok else 0.0})
+    rates = per["rate"]
+    value = world * units_per_rank / wall
+    return {"value": round(value, 1), "n_gpus": world, "per_rank_images_per_s": [round(v, 1) for v in rates],
+            "scaling_efficiency_vs_rank_mean": round(value / (world * sum(rates) / len(rates)), 4),
+            "bit_identical_to_serial": all(v == 1.0 for v in per["ok"])}
+
+
+def agree(D, ok: bool) -> bool:
+    """True when EVERY rank says ok -- a collective OUTSIDE any try block: construction and warm-up of a leg can fail on one
+    rank only (out of memory, an ineligible shape); the ranks first agree that all of them are ready and only then enter the
+    timed collectives together (or skip the leg together)."""
+    return D.max_over_ranks(0.0 if ok else 1.0) == 0.0
+
+
 def step_bytes(B: int, S: int, attn_esize: int = 4) -> float:
     """Algorithmic bytes of one step: the resample's 2*S*S*3*4 per image + the attention rows the reduce
     reads, T*heads*576*esize per image."""
@@ -591,6 +611,40 @@ def _event_ms(torch, fn, n, warm=3):
     return ts[len(ts) // 2]
 
 
+def copy_calibration(torch, dev, read_bytes: int, write_bytes: int, n: int = 40):
+    """The ruler of a chain step: ONE launch of a plain streaming kernel (csrc/calib.hip, tuning flavour of the library) that
+    reads `read_bytes` and writes `write_bytes` -- the step's algorithmic bytes at the same batch size -- rotating over
+    >= 2 GiB of source and destination so that every launch streams from HBM like the step does; mean of n launches timed as
+    ONE region with HIP events (back to back, as the stream's steps run).  None when the tuning library is missing."""
+    from attwarp_amd import _lib
+    import ctypes
+    try:
+        tl = _lib.load_tuning()
+    except ImportError:
+        return None
+    rb, wb = (int(read_bytes) + 15) // 16 * 16, (int(write_bytes) + 15) // 16 * 16
+    slots = max(2, min(64, -(-(2 << 30) // (rb + wb))))
+    src = torch.empty(slots * rb, device=dev, dtype=torch.uint8).random_(0, 256)
+    dst = torch.empty(slots * wb, device=dev, dtype=torch.uint8)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    def run(k):
+        for i in range(k):
+            j = i % slots
+            rc = tl.attwarp_debug_stream_copy(ctypes.c_void_p(src.data_ptr() + j * rb), rb, ctypes.c_void_p(dst.data_ptr() + j * wb), wb, st)
+            if rc != 0:
+                raise RuntimeError(tl.attwarp_last_error().decode())
+    run(8)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); run(n); e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    del src, dst
+    return {"kernel": "debug_stream_copy_kernel (csrc/calib.hip): one launch, reads read_bytes + writes write_bytes, rotating over "
+                      f"{slots} slots (>= 2 GiB)", "read_bytes": int(read_bytes), "write_bytes": int(write_bytes),
+            "ms": round(ms, 4), "frac_of_hbm_peak": round((read_bytes + write_bytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def leg_main_batched(dev, torch, pipeline, K):
     """The chain the reference's batched driver runs per image (AGW/main_batched.py:243-287, BATCH_SIZE = 32 at :42, 500 x 500
     output at :62-63): revise_mask -> x255 uint8 -> PIL LANCZOS -> float64 marginals -> CDF -> np.interp -> uint8 cv2.remap,
@@ -648,7 +702,13 @@ def leg_main_batched(dev, torch, pipeline, K):
             two = {"ms_per_batch": round(t_two * 1e3, 4), "images_per_s": round(B / t_two, 1),
                    "step_frac_of_hbm_peak": round(B * bytes_img / t_two / 1e9 / HBM_PEAK_GBS, 4), "bit_identical_to_serial": same2}
             del mc2
+        calib = copy_calibration(torch, dev, B * 5 * S * S, B * 3 * So * So)
+        if calib:
+            calib["step_over_copy"] = round(t_stream * 1e3 / calib["ms"], 3)
+            if two:
+                calib["two_batches_per_launch_over_copy"] = round(two["ms_per_batch"] / calib["ms"], 3)
         case = {"B": B, "S": S, "S_out": So, "ring_batches": n, "pattern": mc.pattern, "two_batches_per_launch": two,
+                "calibration": calib,
                 "chain_algorithmic_bytes_per_image": bytes_img,
                 "stream": {"ms_per_step": round(t_stream * 1e3, 4), "images_per_s": round(B / t_stream, 1),
                            "step_TBps": round(B * bytes_img / t_stream / 1e12, 3),
@@ -663,111 +723,154 @@ def leg_main_batched(dev, torch, pipeline, K):
     out["value"] = ref["stream"]["images_per_s"]
     out["value_is"] = ("the stream step at the reference's own scale: B=32, 336 -> 500, one batch per launch "
                        "(`two_batches_per_launch` beside it)")
+    out["step_over_copy"] = (ref.get("calibration") or {}).get("step_over_copy")
+    out["step_over_copy_is"] = ("stream ms per step / the ms of ONE plain streaming launch that reads 5*S*S and writes 3*S_out*S_out bytes "
+                                "per image at the same B (`calibration` of each case): what the chain costs over a copy of its bytes")
     return out
 
 
 TEXTVQA_LIKE_WH = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]      # W x H as PIL reports them
 
 
-def leg_main_batched_ragged(dev, torch, pipeline, K):
+def leg_main_batched_ragged(dev, torch, pipeline, K, D=None, rank=0, world=1, grouped=False):
     """The same chain on what the reference's driver actually holds (AGW/main_batched.py:243-287): batches of DIFFERENTLY
     sized images (`b_images[j]` at native size; a TextVQA-like mix of 1024 x 768, 683 x 1024, 1024 x 1024, 500 x 375,
     333 x 500, 640 x 427), every mask up-sampled to its image's own size, dense [B,500,500,3] output.  Per case:
+      `stream`     pipeline.RaggedMaskChainStream over a ring of prebuilt batches: ONE launch per batch (R(k) | F(k+1) |
+                   P(k+2) | L(k+3) | V(k+4)), eager and replayed as HIP graphs -- timed between barrier + synchronize, max over
+                   ranks; in a process group EVERY rank runs it on its own batches (per-rank rates reported);
+      `calibration`  one plain streaming launch of the same bytes (copy_calibration) and `step_over_copy`;
+    and, on one GPU without a process group, beside it:
       `per_image`  the loop a driver had to write before: pipeline.warp_from_masks on one image at a time (5 launches each);
       `serial`     pipeline.warp_from_masks_ragged: table build + upload + five ragged launches per batch;
-      `stream`     pipeline.RaggedMaskChainStream over a ring of prebuilt batches: ONE launch per batch (R(k) | F(k+1) |
-                   P(k+2) | L(k+3) | V(k+4)), eager and replayed as HIP graphs;
-      `equal_size_stream`  pipeline.MaskChainStream on B images of S x S with S*S = the mix's mean pixel count (the round-4
+      `equal_size_stream`  pipeline.MaskChainStream on B images of S x S with S*S = the mix's mean pixel count (the
                    one-launch step for equally sized images): the bar is ragged <= 1.3 x that.
     Rings of >= 2 GiB of independent batches, exactly K batches through every stage in each timed region; chain-level
     algorithmic bytes as `also_main_batched`."""
+    from attwarp_amd import dist as D0
+    D = D or D0
     K = max(K + (K & 1), 10)
     So = 500
+    full = world == 1 and not grouped
     out = {"workload": "uint8 images of different sizes [H_i,W_i,3] + attention maps [B,24,24] -> main_batched chain -> "
                        "[B,500,500,3] uint8, mode=cv2, transform=identity", "unit": "images/s", "steps": K,
            "sizes_WxH": TEXTVQA_LIKE_WH, "cases": []}
-    for B in (32, 64, 256):      # (64: two of the driver's batches of 32 as ONE ragged batch -- free for ragged batches, any sizes mix)
+    for B in ((32, 64, 256) if full else (32, 256)):   # (64: two of the driver's batches of 32 as ONE ragged batch -- any sizes mix)
         sizes = [TEXTVQA_LIKE_WH[b % len(TEXTVQA_LIKE_WH)] for b in range(B)]
         px = sum(w * h for (w, h) in sizes)
         slot = 3 * px + 3 * B * So * So
         n = max(6, min(40, -(-(2 << 30) // slot)))
-        g = torch.Generator(device=dev).manual_seed(99 + B)
-        ring_imgs = [[torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes]
-                     for _ in range(n)]
-        masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
         bytes_batch = 5 * px + 3 * B * So * So
-        # the drop-in for one batch at a time (table build + upload + five launches)
-        for i in range(2):
-            pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(K):
-            o = pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
-        torch.cuda.synchronize()
-        t_serial = (time.perf_counter() - t0) / K
-        want0 = o if (K - 1) % n == 0 else pipeline.warp_from_masks_ragged(ring_imgs[0], masks[0], (So, So))
-        # what a driver had to do without it: image by image (timed on a bounded sample of batches)
-        kk = 2 if B > 64 else 4
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(kk):
-            for b in range(B):
-                o = pipeline.warp_from_masks(ring_imgs[i % n][b][None], masks[i % n][b:b + 1], (So, So))
-        torch.cuda.synchronize()
-        t_per_image = (time.perf_counter() - t0) / kk
-        # stream over prebuilt batches
-        ring = []
-        for i in range(n):
-            rb = pipeline.RaggedBatch(ring_imgs[i], (So, So)); rb.masks = masks[i]
-            ring.append(rb)
-        st = pipeline.RaggedMaskChainStream(out_size=(So, So))
-        st.ring(ring)
-        res = {}
-        for name, unroll in (("eager", 0), ("graphs", n)):
-            def run():
+        st = ring = ring_imgs = masks = None
+        err = ""
+        try:
+            g = torch.Generator(device=dev).manual_seed(99 + B + 1000 * rank)
+            ring_imgs = [[torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (w, h) in sizes]
+                         for _ in range(n)]
+            masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+            ring = []
+            for i in range(n):
+                rb = pipeline.RaggedBatch(ring_imgs[i], (So, So)); rb.masks = masks[i]
+                ring.append(rb)
+            st = pipeline.RaggedMaskChainStream(out_size=(So, So))
+            st.ring(ring)
+            def run(unroll):
                 st.k = 0
                 st.prime(); st.run(K - st.DEPTH, unroll=unroll); st.drain_ring()      # exactly K batches through every stage
-            run(); run()
+            for unroll in (0, n):                      # warm-up: every graph the timed passes replay is captured here
+                run(unroll); run(unroll)
             torch.cuda.synchronize()
+        except Exception as e:                         # noqa: BLE001 -- one rank only may fail (memory): agree below
+            st, err = None, f"{type(e).__name__}: {str(e)[:200]}"
+        if not agree(D, st is not None):
+            out["cases"].append({"B": B, "unavailable": err or "another rank could not build this case"})
+            del st, ring, ring_imgs, masks
+            torch.cuda.empty_cache()
+            continue
+        res, walls = {}, {}
+        for name, unroll in (("eager", 0), ("graphs", n)):
+            D.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run()
-            torch.cuda.synchronize()
-            t = (time.perf_counter() - t0) / K
-            res[name] = {"ms_per_batch": round(t * 1e3, 4), "images_per_s": round(B / t, 1),
-                         "step_frac_of_hbm_peak": round(bytes_batch / t / 1e9 / HBM_PEAK_GBS, 4)}
+            run(unroll)
+            torch.cuda.synchronize(); D.barrier()
+            wl = time.perf_counter() - t0
+            w = D.max_over_ranks(wl)
+            walls[name] = (w, wl)
+            res[name] = {"ms_per_batch": round(w / K * 1e3, 4), "images_per_s": round(B * K / w, 1),
+                         "step_frac_of_hbm_peak": round(bytes_batch / (w / K) / 1e9 / HBM_PEAK_GBS, 4)}
+        want0 = pipeline.warp_from_masks_ragged(ring_imgs[0], masks[0], (So, So))
         same = bool(torch.equal(ring[0].out, want0)) and all(
             bool(torch.equal(ring[i].out, pipeline.warp_from_masks_ragged(ring_imgs[i], masks[i], (So, So)))) for i in range(1, min(n, 4)))
+        best = "graphs" if walls["graphs"][0] <= walls["eager"][0] else "eager"
+        case = {"B": B, "pixels_per_batch": px, "ring_batches": n, "chain_algorithmic_bytes_per_batch": bytes_batch,
+                "stream": res, "bit_identical_to_serial": same}
+        if grouped:
+            case.update(rank_fields(D, world, B * K, walls[best][1], walls[best][0], same))
+            case["value_is"] = f"whole-job images/s of the `{best}` stream (weak scaling: every rank its own batches of {B})"
+        calib = copy_calibration(torch, dev, 5 * px, 3 * B * So * So)
+        if calib:
+            calib["step_over_copy"] = round(res[best]["ms_per_batch"] / calib["ms"], 3)
+        case["calibration"] = calib
         del ring, st
-        # the equal-size stream step at the same total pixels
-        S = int(round((px / B) ** 0.5 / 4)) * 4
-        ne = n + (n & 1)
-        images_e = list(torch.randint(0, 256, (ne, B, S, S, 3), device=dev, dtype=torch.uint8, generator=g))
-        masks_e = list(torch.rand(ne, B, 24, 24, device=dev, generator=g))
-        mc = pipeline.MaskChainStream(images_e, masks_e, (So, So))
-        def run_e():
-            mc.reset(); mc.prime(); mc.run(K - mc.depth); mc.drain()
-        run_e(); run_e()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run_e()
-        torch.cuda.synchronize()
-        t_eq = (time.perf_counter() - t0) / K
-        best = min(res["eager"]["ms_per_batch"], res["graphs"]["ms_per_batch"])
-        out["cases"].append({
-            "B": B, "pixels_per_batch": px, "ring_batches": n, "chain_algorithmic_bytes_per_batch": bytes_batch,
-            "stream": res, "bit_identical_to_serial": same,
-            "serial": {"ms_per_batch": round(t_serial * 1e3, 4), "images_per_s": round(B / t_serial, 1),
-                       "includes": "table build on the host, its upload, buffer allocation, five launches"},
-            "per_image": {"ms_per_batch": round(t_per_image * 1e3, 4), "images_per_s": round(B / t_per_image, 1)},
-            "equal_size_stream": {"S": S, "pattern": mc.pattern, "ms_per_batch": round(t_eq * 1e3, 4),
-                                  "images_per_s": round(B / t_eq, 1)},
-            "ragged_over_equal_size": round(best / (t_eq * 1e3), 3)})
-        del mc, images_e, masks_e, ring_imgs, masks
+        if full:
+            # the drop-in for one batch at a time (table build + upload + five launches)
+            for i in range(2):
+                pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(K):
+                o = pipeline.warp_from_masks_ragged(ring_imgs[i % n], masks[i % n], (So, So))
+            torch.cuda.synchronize()
+            t_serial = (time.perf_counter() - t0) / K
+            # what a driver had to do without it: image by image (timed on a bounded sample of batches)
+            kk = 2 if B > 64 else 4
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(kk):
+                for b in range(B):
+                    o = pipeline.warp_from_masks(ring_imgs[i % n][b][None], masks[i % n][b:b + 1], (So, So))
+            torch.cuda.synchronize()
+            t_per_image = (time.perf_counter() - t0) / kk
+            del o
+            # the equal-size stream step at the same total pixels
+            S = int(round((px / B) ** 0.5 / 4)) * 4
+            ne = n + (n & 1)
+            images_e = list(torch.randint(0, 256, (ne, B, S, S, 3), device=dev, dtype=torch.uint8, generator=g))
+            masks_e = list(torch.rand(ne, B, 24, 24, device=dev, generator=g))
+            mc = pipeline.MaskChainStream(images_e, masks_e, (So, So))
+            def run_e():
+                mc.reset(); mc.prime(); mc.run(K - mc.depth); mc.drain()
+            run_e(); run_e()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_e()
+            torch.cuda.synchronize()
+            t_eq = (time.perf_counter() - t0) / K
+            case.update({
+                "serial": {"ms_per_batch": round(t_serial * 1e3, 4), "images_per_s": round(B / t_serial, 1),
+                           "includes": "table build on the host, its upload, buffer allocation, five launches"},
+                "per_image": {"ms_per_batch": round(t_per_image * 1e3, 4), "images_per_s": round(B / t_per_image, 1)},
+                "equal_size_stream": {"S": S, "pattern": mc.pattern, "ms_per_batch": round(t_eq * 1e3, 4),
+                                      "images_per_s": round(B / t_eq, 1)},
+                "ragged_over_equal_size": round(res[best]["ms_per_batch"] / (t_eq * 1e3), 3)})
+            del mc, images_e, masks_e
+        out["cases"].append(case)
+        del ring_imgs, masks
         torch.cuda.empty_cache()
-    ref = out["cases"][0]
-    out["value"] = max(ref["stream"]["eager"]["images_per_s"], ref["stream"]["graphs"]["images_per_s"])
-    out["value_is"] = "the ragged stream step at the reference's batch size (B=32), one launch per batch"
-    out["cpu_baseline"] = chain_cpu_baseline(dev, torch, pipeline, So)
+    ref = next((c for c in out["cases"] if c["B"] == 32 and "stream" in c), None)
+    if ref is None:
+        out["value"] = None
+        return out
+    if grouped:
+        for k in ("value", "n_gpus", "per_rank_images_per_s", "scaling_efficiency_vs_rank_mean", "bit_identical_to_serial"):
+            out[k] = ref[k]
+        out["value_is"] = "whole-job rate of the ragged stream step at the reference's batch size (B=32 per rank), one launch per batch"
+    else:
+        out["value"] = max(ref["stream"]["eager"]["images_per_s"], ref["stream"]["graphs"]["images_per_s"])
+        out["value_is"] = "the ragged stream step at the reference's batch size (B=32), one launch per batch"
+    out["step_over_copy"] = (ref.get("calibration") or {}).get("step_over_copy")
+    if rank == 0 and full:
+        out["cpu_baseline"] = chain_cpu_baseline(dev, torch, pipeline, So)
     return out
 
 
@@ -935,30 +1038,60 @@ def leg_distributions(step, args, D, torch, pipeline, B):
         keep = step.sets
         step.sets = [(img, rows, o) for (img, _, o) in keep]
         w4, _ = time_steps(step, args.steps, args.warmup, D)
-        note = ("all-zero attention collapses the CDF (clamp_min(1e-6), MN/checkpoint_utils.py:36): every output pixel "
-                "maps to the last source rows, the kernel reads almost nothing and is bound by its writes alone -- "
-                "`frac` is against the nominal 2*S*S*3*4 bytes and exceeds what was moved") if name == "zero_attention" else \
+        note = ("all-zero attention collapses the CDF (clamp_min(1e-6), MN/checkpoint_utils.py:36-40): every output pixel "
+                "samples the LAST source row and column, so the kernel reads two source rows per image and is bound by its "
+                "writes -- `roofline` therefore counts the bytes actually moved (the S*S*3*4 written per image), not the nominal "
+                "2*S*S*3*4") if name == "zero_attention" else \
                "one 3x3 hot spot x100 per image: magnified there, minified elsewhere (two source rows per output row)"
+        roof = traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{name}")))
+        if name == "zero_attention":
+            moved = 1.0 * step.S * step.S * 3 * 4 * step.B
+            ach = moved / (roof["kernel_ms_mean"] * 1e-3) / 1e9
+            roof.update({"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": moved,
+                         "bytes_are": "writes only: S*S*3*4 per image (the two source rows read per image are < 0.2 %)"})
         out[f"also_{name}"] = {"workload": f"same images, {name.replace('_', ' ')} rows, mode={args.mode}", "note": note,
                                "value": round(B * args.steps / w4, 1), "unit": "images/s",
-                               "ms_per_step": round(w4 / args.steps * 1e3, 4),
-                               "roofline": traffic_note(roofline_of(step, load_pmc_traffic(args.workload, f"{args.mode}_{name}")))}
+                               "ms_per_step": round(w4 / args.steps * 1e3, 4), "roofline": roof}
         step.sets = keep
         del rows
     return out
 
 
-def leg_small(wl, dev, args, K, D, torch, pipeline, attn_dtype=None):
-    """BASELINE configs[1] / configs[3]'s per-rank batch as a secondary line of the 1024 run (graph-replayed stream step)."""
+def leg_small(wl, dev, args, K, D, torch, pipeline, attn_dtype=None, rank=0, world=1, grouped=False):
+    """BASELINE configs[1] / configs[3]'s per-rank batch as a secondary line of the 1024 run (graph-replayed stream step).
+    In a process group EVERY rank runs it on its own batches (weak scaling: `value` is the whole job's rate)."""
     B2, S2, cfg2 = WORKLOADS[wl]
-    res, _, _, st, ow = small_workload(B2, S2, dev, 99, args.mode, args.layout, K, args.warmup, D, torch, pipeline,
-                                       attn_dtype=attn_dtype)
+    res, wall, wall_local, st, ow = small_workload(B2, S2, dev, 99 + rank, args.mode, args.layout, K, args.warmup, D, torch,
+                                                   pipeline, attn_dtype=attn_dtype)
     what = (f"batch-{B2} {S2}x{S2} per GPU (BASELINE configs[{cfg2}]), mode={args.mode}" if attn_dtype is None else
             f"batch-{B2} {S2}x{S2} per GPU, attention rows float16 (images float32), mode={args.mode}")
     out = dict({"workload": what, "value": res["images_per_s"], "unit": "images/s", "steps": K}, **res)
+    if grouped:
+        out.update(rank_fields(D, world, B2 * K, wall_local, wall, res["bit_identical_to_serial"]))
+        out["images_per_s_per_gpu"] = out.pop("images_per_s")
+        out["global_batch"] = world * B2
     del st, ow
     torch.cuda.empty_cache()
     return out
+
+
+SCALING_CURVE_NOTE = ("one point per run: `value` is the whole-job rate at n_gpus = N (and `also_336x256` -- BASELINE configs[3], 256 images "
+                      "per rank -- and `also_main_batched_ragged` carry theirs); the 1/2/4/8 curve and its efficiency are computed by the "
+                      "driver from the per-N lines, never reported here")
+
+
+def dist_leg_plan(workload: str, want, grouped: bool):
+    """(key, images per rank per step) of the secondary legs that run on EVERY rank of a process group behind the main 1024
+    line: BASELINE configs[3] (batch-2048 at 336 x 336 over 8 ranks = 256 per rank, the only config BASELINE names for the
+    scaling curve) and the reference driver's own uint8 chain on differently sized images."""
+    if workload != "1024" or not grouped:
+        return []
+    plan = []
+    if "336" in want:
+        plan.append(("also_336x256", 256))
+    if "main_batched_ragged" in want:
+        plan.append(("also_main_batched_ragged", 32))
+    return plan
 
 
 # secondary measurements attached to the default (1024) line on one GPU; `--legs a,b` selects, `--list-legs` prints
@@ -1062,6 +1195,15 @@ def main():
         local = args.device
     _lib.load()
     ranks_seen = [int(v) for v in D.all_gather_counters({"rank": float(rank)})["rank"]]
+    # a line labelled n_gpus = N must come from N ranks that all see each other, over RCCL on a GPU run: anything else exits
+    # non-zero (the launcher / torchrun then ends the other ranks) instead of printing a number
+    if ranks_seen != list(range(world)):
+        raise SystemExit(f"bench.py: the process group gathered ranks {ranks_seen}, expected {list(range(world))}")
+    if grouped and not args.dry_run:
+        backend = torch.distributed.get_backend()
+        if backend != "nccl" and args.dist_backend is None:
+            raise SystemExit(f"bench.py: GPU run over backend {backend!r}; RCCL ('nccl') expected (pass --dist-backend explicitly "
+                             "to smoke-test another one)")
 
     if args.dry_run:
         from attwarp_amd.model import MarginalNet
@@ -1073,12 +1215,24 @@ def main():
         wall_local = time.perf_counter() - t0
         wall = D.max_over_ranks(wall_local)
         per = D.all_gather_counters({"images": float(B * args.steps), "wall_s": wall_local})
+        line = {"metric": "warped images/sec", "value": None, "unit": "images/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                "weights_broadcast": {"bytes": nbytes}, "per_rank_images": per["images"],
+                "ranks_seen": ranks_seen, "rccl_ranks_seen": ranks_seen, "cpu_affinity_rank0": affinity,
+                "max_wall_s": wall, "config": {"workload": args.workload, "batch_per_gpu": B},
+                "scaling_curve": SCALING_CURVE_NOTE}
+        # the secondary legs every rank of a group runs behind the main line (same collectives, same keys, no GPU work):
+        # agree-on-eligibility, barrier-bracketed timed region, max over ranks, gathered per-rank rates
+        for key, units in dist_leg_plan(args.workload, want, grouped):
+            ok = agree(D, True)
+            D.barrier()
+            t0 = time.perf_counter()
+            time.sleep(0.005 * (1 + rank))
+            D.barrier()
+            wl = time.perf_counter() - t0
+            line[key] = dict(rank_fields(D, world, float(units * args.steps), wl, D.max_over_ranks(wl), ok), dry_run=True)
         if rank == 0:
-            print(json.dumps({"metric": "warped images/sec", "value": None, "unit": "images/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
-                              "weights_broadcast": {"bytes": nbytes}, "per_rank_images": per["images"],
-                              "ranks_seen": ranks_seen, "cpu_affinity_rank0": affinity,
-                              "max_wall_s": wall, "config": {"workload": args.workload, "batch_per_gpu": B}}), flush=True)
+            print(json.dumps(line), flush=True)
         D.shutdown()
         return
 
@@ -1241,16 +1395,27 @@ def main():
     torch.cuda.empty_cache()
 
     n2 = max(args.steps, 48)
+    result["scaling_curve"] = SCALING_CURVE_NOTE
+    rk = dict(rank=rank, world=world, grouped=grouped)
+    if world > 1:
+        # every rank of the group runs the legs of dist_leg_plan on its own batches (no try around them: a failure inside a
+        # timed collective region must end the job -- the launcher / torchrun kills the other ranks -- not hang it)
+        for key, _ in dist_leg_plan(args.workload, want, grouped):
+            if key == "also_336x256":
+                result[key] = leg_small("336x256", dev, args, n2, D, torch, pipeline, **rk)
+            else:
+                result[key] = leg_main_batched_ragged(dev, torch, pipeline, n2, D, **rk)
+            torch.cuda.empty_cache()
     if world == 1 and args.workload == "1024" and "336" in want:
         for key, wl in (("also", "336"), ("also_336x256", "336x256")):
-            result[key] = leg_small(wl, dev, args, n2, D, torch, pipeline)
+            result[key] = leg_small(wl, dev, args, n2, D, torch, pipeline, **rk)
     if world == 1 and args.workload == "1024" and "fp16_attention" in want:
         # configs[3]'s per-rank batch with the attention rows in float16, the dtype LLaVA-1.5 emits (half the reduce's bytes)
         result["also_336x256_fp16_attention"] = leg_small("336x256", dev, args, n2, D, torch, pipeline, attn_dtype=torch.float16)
     if world == 1 and args.workload == "1024":
         # (a failure inside one of these legs -- e.g. `transformers` missing for the vision tower -- must not cost the main line)
         for key, leg in (("main_batched", lambda: leg_main_batched(dev, torch, pipeline, n2)),
-                         ("main_batched_ragged", lambda: leg_main_batched_ragged(dev, torch, pipeline, n2)),
+                         ("main_batched_ragged", lambda: leg_main_batched_ragged(dev, torch, pipeline, n2, D, **rk)),
                          ("pool_input", lambda: leg_pool_input(dev, torch, pipeline, B, S, args.mode, args.steps)),
                          ("config5", lambda: leg_config5(dev, torch, pipeline, 32, 3))):
             if key in want:

@@ -73,6 +73,9 @@ ATTWARP_API const char* attwarp_last_error(void);
  * test only. */
 #ifdef ATTWARP_TUNING
 ATTWARP_API int attwarp_debug_set(const char* key, int value, int* previous);
+/* measurement yardstick (csrc/calib.hip): ONE launch that reads read_bytes from src and writes write_bytes to dst (16-byte
+ * aligned device buffers) -- a plain streaming kernel for the bytes of a chain step, the ruler of bench.py's `step_over_copy` */
+ATTWARP_API int attwarp_debug_stream_copy(const void* src, size_t read_bytes, void* dst, size_t write_bytes, void* stream);
 #endif
 
 /* ---- A1: BatchMaskHookLogger._process_attention, AGW/attention_extraction/llava.py:385-396
@@ -266,16 +269,22 @@ ATTWARP_API int attwarp_attn_reduce_and_maps(int attn_dtype, const void* rows, i
                                  const double* inv_x, const double* inv_y, float* map_x, float* map_y, void* stream);
 
 /* ---- one step of the main_batched chain (AGW/main_batched.py:243-287: revise_mask -> x255 uint8 -> PIL LANCZOS ->
- * float64 marginals -> CDF -> np.interp -> uint8 cv2.remap, transform "identity" as that driver passes it) for a STREAM
- * of equally shaped batches, as ONE launch.  The five stages run on five different batches (block ranges of one grid):
+ * float64 marginals -> CDF -> np.interp -> uint8 cv2.remap) for a STREAM of equally shaped batches, as ONE launch, with
+ * save_warped_image's own keyword arguments (AGW/new_method.py:405-411: transform, exp_scale, exp_divisor, apply_inverse;
+ * :134-191 the five transforms and their inverses, :219-226 the inverse on the marginals; main_batched.py:280-287 passes
+ * "identity", 1.0, 1.0, False; the module default is "sqrt", :191).  The five stages run on five different batches (block
+ * ranges of one grid):
  *   R(k)    images [B,H,W,C] uint8 + map_x [B,W_out], map_y [B,H_out]         -> out [B,H_out,W_out,C]   (mode cv2)
  *   F(k+1)  sums_in (axis sums of the mask of batch k+1, written by P)        -> map_x_next, map_y_next
  *   P(k+2)  mota_in [B,H,W] uint8 (up-sampled mask of batch k+2)              -> sums_out
  *   L(k+3)  rev_in [B,g,g] float32 (revised mask of batch k+3) + Pillow tables (ksize_y == 8, zero padded) -> mota_out
  *   V(k+4)  masks [B,g,g] float32 (aggregated attention of batch k+4)         -> rev_out
  * sums_*: attwarp_axis_sums_workspace_bytes(B,H,W) bytes each.  An output buffer must not alias the buffer the next
- * stage reads in the same launch (double buffer each intermediate by batch parity).  Every stage computes what
- * attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8, identity) /
+ * stage reads in the same launch (double buffer each intermediate by batch parity).  transform = ATTWARP_T_* applies in
+ * P (element transform) and F (apply_inverse: the inverse on the marginals); transform_lut: for ATTWARP_T_SQRT / EXP / LOG
+ * the 256 doubles attwarp_attention_transform_lut wrote for the same (transform, exp_scale, exp_divisor) -- a constant of the
+ * stream, computed once -- NULL allowed for identity / square.  Every stage computes what
+ * attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8, transform, ...) /
  * attwarp_remap_bilinear(U8, HWC, CV2) compute, bit for bit.  ATTWARP_E_UNSUPPORTED when one of the stages would not
  * run on its staged kernel for this shape (rows wider than 4096 bytes, W not a multiple of 4, W or H equal to g, ...):
  * use the separate entry points, or attwarp_mask_chain_ragged (below: any width), then. */
@@ -286,7 +295,13 @@ ATTWARP_API int attwarp_mask_chain_step(const uint8_t* images, uint8_t* out, int
                             const float* rev_in, const int32_t* bounds_x, const int32_t* kk_x, int ksize_x,
                             const int32_t* bounds_y, const int32_t* kk_y, int ksize_y, uint8_t* mota_out,
                             const float* masks, int g, int kernel_size, float enhance_coe, float* rev_out,
-                            void* stream);
+                            int transform, double exp_scale, double exp_divisor, int apply_inverse,
+                            const double* transform_lut, void* stream);
+
+/* The 256-entry table of the transformed byte values of a uint8 attention map: lut[v] = transform(max(v, 0)) + 1e-9 for
+ * v = 0 .. 255 (AGW/new_method.py:134-179,208-215), by the very device functions attwarp_axis_maps_from_attention(U8) uses
+ * (bit-identical).  lut: 256 doubles on the device.  Needed by the one-launch chain steps for ATTWARP_T_SQRT / EXP / LOG. */
+ATTWARP_API int attwarp_attention_transform_lut(int transform, double exp_scale, double exp_divisor, double* lut, void* stream);
 
 /* ---- the same chain for batches of DIFFERENTLY sized images: what AGW/main_batched.py:243-287 actually holds (`b_images[j]`
  * are PIL images at their native sizes; blend_mask up-samples the mask to `image.size`, llava.py:253; save_warped_image warps
@@ -345,15 +360,17 @@ ATTWARP_API int attwarp_ragged_plan(const attwarp_ragged_image* images, int B, i
  *   P(k+2)  p_*: mota_in (mota_bytes of that table, written by L)               -> sums_out
  *   L(k+3)  l_*: rev_in [B,g,g] float32 (written by V) + the images' Pillow tables -> mota_out
  *   V(k+4)  masks [B_masks,g,g] float32                                          -> rev_out
+ * transform / exp_scale / exp_divisor / apply_inverse / transform_lut: as attwarp_mask_chain_step (used by the P and F stages).
  * Every stage computes what attwarp_mask_postproc / attwarp_mask_upsample_lanczos / attwarp_axis_maps_from_attention(U8,
- * identity) / attwarp_remap_bilinear(U8, HWC, CV2) compute on that image alone, bit for bit.  The batches of one launch
- * share C, g and the output size; their B and image sizes are free. */
+ * transform, ...) / attwarp_remap_bilinear(U8, HWC, CV2) compute on that image alone, bit for bit.  The batches of one
+ * launch share C, g and the output size; their B and image sizes are free. */
 ATTWARP_API int attwarp_mask_chain_ragged(const void* r_host, const void* r_dev, uint8_t* out, const float* map_x, const float* map_y,
                               const void* f_host, const void* f_dev, const void* sums_in, float* map_x_next, float* map_y_next,
                               const void* p_host, const void* p_dev, const uint8_t* mota_in, void* sums_out,
                               const void* l_host, const void* l_dev, const float* rev_in, uint8_t* mota_out,
                               const float* masks, int B_masks, int g, int kernel_size, float enhance_coe, float* rev_out,
-                              void* stream);
+                              int transform, double exp_scale, double exp_divisor, int apply_inverse,
+                              const double* transform_lut, void* stream);
 
 /* ---- A13: grid construction of warp_image_by_attention, AGW/new_method.py:206-265
  * att [B,h,w] (U8/F32/F64) -> map_x [B,new_w], map_y [B,new_h] float32.

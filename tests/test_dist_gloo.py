@@ -11,6 +11,10 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -75,6 +79,53 @@ def test_bench_self_launches_two_ranks():
     assert d["weights_broadcast"]["bytes"] > 0
     assert d["per_rank_images"] == [256.0 * 3, 256.0 * 3]
     assert d["config"]["batch_per_gpu"] == 256
+    assert "also_336x256" not in d             # the legs ride on the default 1024 line only
+
+
+def _check_dist_legs(d, n):
+    """The legs EVERY rank of a group runs behind the main 1024 line: BASELINE configs[3] (256 images of
+    336 x 336 per rank) and the ragged main_batched chain, each with the job rate, every rank's rate, the rate against N x the
+    mean rank, and the AND over ranks of its bit-identity check."""
+    assert "driver" in d["scaling_curve"] and d["rccl_ranks_seen"] == list(range(n))
+    for key in ("also_336x256", "also_main_batched_ragged"):
+        leg = d[key]
+        assert leg["n_gpus"] == n and len(leg["per_rank_images_per_s"]) == n and all(v > 0 for v in leg["per_rank_images_per_s"])
+        assert leg["bit_identical_to_serial"] is True and 0.0 < leg["scaling_efficiency_vs_rank_mean"] <= 1.0 + 1e-6
+        mean = sum(leg["per_rank_images_per_s"]) / n
+        # (the fields are rounded to 0.1 image/s: compare with that slack)
+        assert abs(leg["scaling_efficiency_vs_rank_mean"] - leg["value"] / (n * mean)) < 1e-3 + 0.2 / mean
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_default_workload_carries_the_dist_legs(n):
+    """The command the driver runs for the scaling curve is `bench.py --gpus N` with the DEFAULT workload: its line must carry
+    configs[3] and the ragged main_batched leg from every rank, not the 1024 x 1024 workload alone."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", "--dry-run",
+                        "--steps", "2"], env=_clean_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == n and d["config"]["workload"] == "1024"
+    _check_dist_legs(d, n)
+    # --legs narrows them like every other leg
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--dry-run",
+                        "--steps", "2", "--legs", "336"], env=_clean_env(), capture_output=True, text=True, timeout=280)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "also_336x256" in d and "also_main_batched_ragged" not in d
+
+
+def test_bench_exits_nonzero_when_a_rank_is_missing_from_the_gather(monkeypatch):
+    """`rccl_ranks_seen` is asserted, not only reported: a group whose gather does not return ranks 0 .. N-1 ends the run."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); sys.argv = ['bench.py', '--gpus', '1', '--force-dist', '--dry-run', '--dist-backend', 'gloo']\n"
+            "import bench\nfrom attwarp_amd import dist as D\n"
+            "orig = D.all_gather_counters\n"
+            "D.all_gather_counters = lambda v: {k: [7.0] for k in v} if 'rank' in v else orig(v)\n"
+            "bench.main()") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "gathered ranks [7]" in (r.stderr + r.stdout), r.stderr[-1500:]
 
 
 def test_bench_refuses_world_size_mismatch():
@@ -84,10 +135,6 @@ def test_bench_refuses_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
-
-
-def _clean_env():
-    return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
 
 
 @pytest.mark.timeout(400)

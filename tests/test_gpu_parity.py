@@ -1324,6 +1324,14 @@ def test_warp_image_by_attention_and_save(dev, golden, tmp_path):
     # attention map of another size -> image is resized to it first (reference :478)
     ok = nm.save_warped_image(Image.fromarray(img), np.ones((100, 120), np.float32), None, None, str(out_path))
     assert ok and np.array(Image.open(out_path)).shape == (500, 500, 3)
+    # the reference fails where cv2.cvtColor(COLOR_RGB2BGR) fails (new_method.py:421-422 -> :504-506 returns False): a mode-L
+    # PIL image is a 2-D array there; an RGBA image is a 4-channel source OpenCV accepts (alpha dropped, 3 channels out)
+    gone = tmp_path / "never.png"
+    assert nm.save_warped_image(Image.fromarray(img[:, :, 0], mode="L"), att, None, None, str(gone), width=500, height=500) is False
+    assert not gone.exists()
+    rgba = np.concatenate([img, rng.integers(0, 256, (336, 336, 1), dtype=np.uint8)], axis=2)
+    assert nm.save_warped_image(Image.fromarray(rgba, mode="RGBA"), att, None, None, str(out_path), width=500, height=500) is True
+    assert np.array_equal(np.array(Image.open(out_path)), expect)
 
 
 def test_pipeline_attention_stack_end_to_end(dev):
@@ -2098,6 +2106,34 @@ def test_bench_force_dist_goes_through_rccl_on_one_gpu(dev):
     assert abs(d["scaling_efficiency_vs_rank_mean"] - 1.0) < 1e-3 and d["bit_identical_to_serial"] is True
 
 
+def test_bench_force_dist_default_workload_carries_the_dist_legs(dev):
+    """The command the driver runs for the scaling curve, on the one GPU of this box: `bench.py --gpus 1 --force-dist` with the
+    DEFAULT (1024 x 1024) workload.  Behind the main line every rank of the group -- here the one rank of a one-rank RCCL group --
+    runs BASELINE configs[3]'s per-rank batch (also_336x256) and the ragged main_batched leg with the per-rank fields of the
+    main line, n_gpus == 1 semantics: one rate, efficiency 1, and the bit-identity checks of both legs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "8", "--warmup", "2",
+                        "--prewarm", "3", "--no-cpu-baseline", "--legs", "336,main_batched_ragged"], env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_ranks_seen"] == [0] and "driver" in d["scaling_curve"]
+    assert d["config"]["image_size"] == 1024 and d["roofline"]["frac"] > 0.3
+    for key, per_rank in (("also_336x256", 256), ("also_main_batched_ragged", 32)):
+        leg = d[key]
+        assert leg["n_gpus"] == 1 and len(leg["per_rank_images_per_s"]) == 1 and leg["bit_identical_to_serial"] is True, key
+        assert abs(leg["scaling_efficiency_vs_rank_mean"] - 1.0) < 2e-3 and leg["value"] > 0, key
+        assert abs(leg["value"] - leg["per_rank_images_per_s"][0]) <= 2e-3 * leg["value"], key
+    assert d["also_336x256"]["global_batch"] == 256
+    rag = d["also_main_batched_ragged"]
+    assert [c["B"] for c in rag["cases"]] == [32, 256] and all(c["bit_identical_to_serial"] for c in rag["cases"])
+    assert rag["step_over_copy"] is not None and rag["cases"][0]["calibration"]["ms"] > 0
+
+
 def test_wide_rows_sorted_random_maps(dev):
     """Rows wider than one staged LDS row (4500 floats / bytes) with irregular but sorted maps: column tiles; same bits."""
     from attwarp_amd import checkpoint_utils as cu
@@ -2724,8 +2760,144 @@ def test_mask_chain_stream_unaligned_shapes_take_the_ragged_step(dev, shape, n):
         pipeline.MaskChainStream(imgs, msk, (Ho, Wo), pattern="fused")
 
 
+TRANSFORM_CASES = [("identity", 1.0, 1.0, True), ("square", 1.0, 1.0, False), ("square", 1.0, 1.0, True), ("sqrt", 1.0, 1.0, False),
+                   ("sqrt", 1.0, 1.0, True), ("exp", 0.01, 2.0, False), ("exp", 0.02, 1.5, True), ("log", 1.0, 1.0, False),
+                   ("log", 1.0, 1.0, True), ("bogus", 1.0, 1.0, False)]
+
+
+@pytest.mark.parametrize("tr,es,ed,inv", TRANSFORM_CASES)
+def test_one_launch_chains_take_save_warped_images_transforms(dev, tr, es, ed, inv):
+    """save_warped_image's own keyword arguments (new_method.py:405-411: transform, exp_scale, exp_divisor, apply_inverse; :134-191
+    the five transforms, default "sqrt") on the ONE-LAUNCH steps -- the uniform step (attwarp_mask_chain_step), the ragged step
+    on equally sized unaligned images and on a batch of differently sized images, the ragged stream -- equal the five serial
+    launches of warp_from_masks with the same arguments BIT FOR BIT (sqrt / exp / log read the table
+    attwarp_attention_transform_lut wrote with the stand-alone kernel's device functions), and the serial launches equal the
+    oracle given the revised mask (exp / log: the device libm may move a map entry by one float32 ulp)."""
+    from attwarp_amd import pipeline, attention_extraction as ae
+    kw = dict(transform=tr, exp_scale=es, exp_divisor=ed, apply_inverse=inv)
+    g = torch.Generator(device=dev).manual_seed(len(tr) + int(inv))
+    n, B = 6, 3
+    # (a) the uniform one-launch step
+    imgs = [torch.randint(0, 256, (B, 96, 100, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) ** 2 for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (80, 88), **kw)
+    assert mc.pattern == "fused"
+    mc.prime(); mc.run(2 * n - mc.depth); mc.drain()
+    want = [pipeline.warp_from_masks(imgs[j], msk[j], (80, 88), **kw) for j in range(n)]
+    for j in range(n):
+        assert torch.equal(mc.outs[j], want[j]), j
+    # (b) the ragged step on equally sized images the uniform step refuses (97 pixels: rows of 291 bytes)
+    imgs_u = [torch.randint(0, 256, (B, 70, 97, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    mu = pipeline.MaskChainStream(imgs_u, msk, (80, 88), **kw)
+    assert mu.pattern == "ragged"
+    mu.prime(); mu.run(2 * n - mu.depth); mu.drain()
+    for j in range(n):
+        assert torch.equal(mu.outs[j], pipeline.warp_from_masks(imgs_u[j], msk[j], (80, 88), **kw)), j
+    # (c) a batch of differently sized images: five ragged launches, and the ragged stream
+    sizes = [(70, 61), (52, 96), (96, 75), (130, 40)]
+    rag_i = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (h, w) in sizes]
+    att = torch.rand(len(sizes), 24, 24, device=dev, generator=g) ** 2
+    rag = pipeline.warp_from_masks_ragged(rag_i, att, (80, 88), **kw)
+    for b in range(len(sizes)):
+        assert torch.equal(rag[b], pipeline.warp_from_masks(rag_i[b][None], att[b:b + 1], (80, 88), **kw)[0]), b
+    st = pipeline.RaggedMaskChainStream(out_size=(80, 88), **kw)
+    outs = [st.push(rag_i, att) for _ in range(6)]
+    outs = [o for o in outs if o is not None] + st.flush()
+    assert len(outs) == 6 and all(torch.equal(o.out, rag) for o in outs)
+    # (d) the oracle, given the GPU's revised mask (the x255 truncation is sensitive to its last ulp: DESIGN 4)
+    rev = N(ae.revise_mask(att, 3, 10))
+    for b, (h, w) in enumerate(sizes):
+        mota = O.lanczos_resize_u8(O.mask_to_u8(rev[b]), w, h)
+        ref = O.warp_image_by_attention(N(rag_i[b]), mota, 88, 80, tr if tr != "bogus" else "identity", es, ed, inv)
+        got = N(rag[b])
+        if tr in ("exp", "log"):
+            assert (got != ref).mean() <= 2e-3 and np.abs(got.astype(int) - ref.astype(int)).max() <= 255, (b, tr)
+        else:
+            assert np.array_equal(got, ref), (b, tr)
+
+
+def test_ragged_chain_p_and_f_stages_vs_reference_transform_combos(dev, golden):
+    """The P (marginals) and F (CDF / np.interp) stages of attwarp_mask_chain_ragged -- launched alone on a batch whose
+    up-sampled mask is the fixture's uint8 attention map -- against the float32 maps the REFERENCE handed to cv2.remap for every
+    uint8 combination of maps_from_attention.npz (2 maps x 6 transform names x inverse x 2 output sizes = 48 combos; the other
+    48 are float attention maps, not this chain's dtype): identity / square / sqrt / unknown bit for bit, exp / log within one
+    float32 ulp (device libm) -- and bit-identical to the stand-alone attwarp_axis_maps_from_attention on every combination."""
+    from attwarp_amd import pipeline, new_method as nm
+    g = golden("maps_from_attention")
+    n_elem = n_diff = n_combo = 0
+    for key in [str(c) for c in g["combos"]]:
+        aname, tr, inv, wh, es, ed = key.split("|")
+        att = g[aname]
+        if att.dtype != np.uint8:
+            continue
+        n_combo += 1
+        nw, nh = (int(v) for v in wh.split("x"))
+        h, w = att.shape
+        grid = 24 if min(h, w) > 24 else 16                 # (att_zero is 24 x 40: the ragged plan wants H, W > g)
+        rb = pipeline.RaggedBatch([torch.zeros(h, w, 3, device=dev, dtype=torch.uint8)], (nh, nw), grid)
+        rb.mota_of(0).copy_(T(att, dev))
+        kw = dict(transform=tr, exp_scale=float(es), exp_divisor=float(ed), apply_inverse=bool(int(inv)))
+        pipeline.ragged_chain_launch(P=rb, **kw)
+        pipeline.ragged_chain_launch(F=rb, **kw)
+        sx, sy = nm.attention_axis_maps(T(att, dev)[None], nw, nh, tr, float(es), float(ed), bool(int(inv)))
+        assert torch.equal(rb.map_x, sx) or (torch.isnan(sx).any() and np.array_equal(N(rb.map_x), N(sx), equal_nan=True)), key
+        assert torch.equal(rb.map_y, sy) or (torch.isnan(sy).any() and np.array_equal(N(rb.map_y), N(sy), equal_nan=True)), key
+        for got, ref in ((N(rb.map_x)[0], g[f"mx|{key}"]), (N(rb.map_y)[0], g[f"my|{key}"])):
+            if tr in ("identity", "square", "sqrt", "bogus"):
+                assert np.array_equal(got, ref, equal_nan=True), key
+                continue
+            fin = np.isfinite(ref)
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), key
+            n_elem += fin.sum(); n_diff += (got[fin] != ref[fin]).sum()
+            np.testing.assert_allclose(got[fin], ref[fin], rtol=2.5e-7, atol=1e-30, err_msg=key)
+    assert n_combo == 48 and n_diff <= 1e-3 * max(n_elem, 1), (n_combo, n_diff, n_elem)
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 6])
+def test_ragged_pattern_graphs_replay_more_than_once(dev, n):
+    """MaskChainStream(pattern="ragged") builds every (ring slot, batch parity) RaggedBatch in its constructor -- n of them
+    for an even ring, 2 n for an odd one -- so that no table upload is ever captured into a HIP graph (a captured
+    upload replays from a staging buffer that has been reused, and the resample then reads another slot's images).  Rings of
+    1, 3, 5 and 6 slots with DIFFERENT images per slot: three turns of lcm(2, n) steps as graphs of several sizes (every
+    graph replayed at least three times), then reset() and a second pass over fresh contents of the same buffers; every output
+    equals warp_from_masks on what its slot holds.  The batches of one parity share ONE set of intermediates."""
+    import math
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(100 + n)
+    B, H, W, Ho, Wo = 3, 50, 61, 44, 52
+    imgs = [torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+    msk = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, Wo), pattern="ragged")
+    period = math.lcm(2, n)
+    assert len(mc._rb) == period
+    assert len({id(rb.mota) for rb in mc._rb.values()}) == min(2, period) and len({id(rb.table_dev) for rb in mc._rb.values()}) == period
+    for unroll in (2, 8):
+        for o in mc.outs:
+            o.zero_()
+        mc.reset(); mc.prime(); mc.run(3 * period + 1, unroll=unroll); mc.drain()
+        for j in range(n):
+            assert torch.equal(mc.outs[j], pipeline.warp_from_masks(imgs[j], msk[j], (Ho, Wo))), (unroll, j)
+    # second pass: the same buffers with new contents, the graphs captured above replayed again
+    for t in imgs:
+        t.copy_(torch.randint(0, 256, t.shape, device=dev, dtype=torch.uint8, generator=g))
+    for m in msk:
+        m.copy_(torch.rand(m.shape, device=dev, generator=g))
+    mc.reset(); mc.prime(); mc.run(2 * period + 1, unroll=2); mc.drain()
+    for j in range(n):
+        assert torch.equal(mc.outs[j], pipeline.warp_from_masks(imgs[j], msk[j], (Ho, Wo))), j
+    # a table upload inside a capture is refused, not recorded
+    gr = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="capture"):
+            with torch.cuda.graph(gr, stream=side):
+                pipeline.RaggedBatch([imgs[0][0]], (Ho, Wo))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("case", [dict(S=22, So=33, Ho=47, transform="identity"),          # sides below the 24-pixel mask grid: no staged mask up-sampling
-                                  dict(S=96, So=80, Ho=80, transform="sqrt"),               # a transform the one-launch step does not take
                                   dict(S=24, So=64, Ho=64, transform="identity"),           # no up-sampling of the mask
                                   dict(S=96, So=80, Ho=80, transform="identity", mode="exact")])
 def test_mask_chain_stream_falls_back_to_branches(dev, case):

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "attwarp.h")).read()
     tuning_only = set(re.findall(r"(attwarp_\w+)\s*\(", "".join(re.findall(r"#ifdef ATTWARP_TUNING(.*?)#endif", hdr, re.S))))
     declared = set(re.findall(r"ATTWARP_API\s+[\w\s\*]+?\b(attwarp_\w+)\s*\(", hdr)) - tuning_only
-    assert len(declared) >= 20 and tuning_only == {"attwarp_debug_set"}
+    assert len(declared) >= 20 and tuning_only == {"attwarp_debug_set", "attwarp_debug_stream_copy"}
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/attwarp.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
@@ -163,11 +163,13 @@ def test_mask_chain_step_abi_validation_without_gpu(lib):
     P = [ctypes.c_void_p(base + 1024 * i) for i in range(16)]
     names = ["images", "out", "B", "C", "H", "W", "H_out", "W_out", "map_x", "map_y", "sums_in", "map_x_next", "map_y_next",
              "mota_in", "sums_out", "rev_in", "bounds_x", "kk_x", "ksize_x", "bounds_y", "kk_y", "ksize_y", "mota_out", "masks",
-             "g", "kernel_size", "enhance_coe", "rev_out", "stream"]
+             "g", "kernel_size", "enhance_coe", "rev_out", "transform", "exp_scale", "exp_divisor", "apply_inverse", "transform_lut",
+             "stream"]
     ok = dict(images=P[0], out=P[1], B=2, C=3, H=64, W=64, H_out=80, W_out=80, map_x=P[2], map_y=P[3], sums_in=P[4],
               map_x_next=P[5], map_y_next=P[6], mota_in=P[7], sums_out=P[8], rev_in=P[9], bounds_x=P[10], kk_x=P[11], ksize_x=8,
               bounds_y=P[12], kk_y=P[13], ksize_y=8, mota_out=P[14], masks=P[15], g=24, kernel_size=3, enhance_coe=10.0,
-              rev_out=ctypes.c_void_p(base + 1024 * 16), stream=None)
+              rev_out=ctypes.c_void_p(base + 1024 * 16), transform=0, exp_scale=1.0, exp_divisor=1.0, apply_inverse=0,
+              transform_lut=None, stream=None)
     f = lib.attwarp_mask_chain_step
     def call(**kw):
         a = dict(ok, **kw)
@@ -176,6 +178,11 @@ def test_mask_chain_step_abi_validation_without_gpu(lib):
     assert call(masks=None) == -1
     assert call(B=0) == -1
     assert call(kernel_size=4) == -1 and b"odd" in lib.attwarp_last_error()
+    assert call(transform=5) == -1 and b"unknown transform" in lib.attwarp_last_error()
+    assert call(transform=2) == -1 and b"transform_lut" in lib.attwarp_last_error()      # sqrt / exp / log need the table
+    assert call(transform=3) == -1 and call(transform=4) == -1
+    assert lib.attwarp_attention_transform_lut(2, 1.0, 1.0, None, None) == -1
+    assert lib.attwarp_attention_transform_lut(7, 1.0, 1.0, P[0], None) == -1
     assert call(map_x_next=P[2]) == -1 and b"alias" in lib.attwarp_last_error()
     assert call(sums_out=P[4]) == -1 and call(mota_out=P[7]) == -1 and call(rev_out=P[9]) == -1
     assert call(g=40) == -2
@@ -567,11 +574,12 @@ def test_mask_chain_ragged_abi_validation_without_gpu(lib):
     P = [ctypes.c_void_p(0x100000 + 4096 * i) for i in range(16)]
     names = ["r_host", "r_dev", "out", "map_x", "map_y", "f_host", "f_dev", "sums_in", "map_x_next", "map_y_next", "p_host", "p_dev",
              "mota_in", "sums_out", "l_host", "l_dev", "rev_in", "mota_out", "masks", "B_masks", "g", "kernel_size", "enhance_coe",
-             "rev_out", "stream"]
+             "rev_out", "transform", "exp_scale", "exp_divisor", "apply_inverse", "transform_lut", "stream"]
     T = ctypes.c_void_p(t1.ctypes.data)
     ok = dict(r_host=T, r_dev=P[0], out=P[1], map_x=P[2], map_y=P[3], f_host=T, f_dev=P[0], sums_in=P[4], map_x_next=P[5],
               map_y_next=P[6], p_host=T, p_dev=P[0], mota_in=P[7], sums_out=P[8], l_host=T, l_dev=P[0], rev_in=P[9], mota_out=P[10],
-              masks=P[11], B_masks=2, g=24, kernel_size=3, enhance_coe=10.0, rev_out=P[12], stream=None)
+              masks=P[11], B_masks=2, g=24, kernel_size=3, enhance_coe=10.0, rev_out=P[12], transform=0, exp_scale=1.0,
+              exp_divisor=1.0, apply_inverse=0, transform_lut=None, stream=None)
     f = lib.attwarp_mask_chain_ragged
     def call(**kw):
         a = dict(ok, **kw)
@@ -583,6 +591,8 @@ def test_mask_chain_ragged_abi_validation_without_gpu(lib):
     assert call(map_x_next=P[2]) == -1 and b"alias" in lib.attwarp_last_error()
     assert call(sums_out=P[4]) == -1 and call(mota_out=P[7]) == -1 and call(rev_out=P[9]) == -1
     assert call(kernel_size=4) == -1 and call(g=16) == -1 and call(B_masks=0) == -1
+    assert call(transform=9) == -1 and b"unknown transform" in lib.attwarp_last_error()
+    assert call(transform=4) == -1 and b"transform_lut" in lib.attwarp_last_error()
     assert call(f_host=ctypes.c_void_p(t2.ctypes.data)) == -1 and b"share" in lib.attwarp_last_error()
     junk = np.zeros(n, np.uint8)
     assert call(p_host=ctypes.c_void_p(junk.ctypes.data)) == -1 and b"attwarp_ragged_plan" in lib.attwarp_last_error()
@@ -601,7 +611,8 @@ def test_ragged_stream_schedule_without_gpu(monkeypatch):
             self._dev = None
             self.masks = None
 
-    def fake_launch(R=None, F=None, P=None, L=None, V=None, enhance_coe=10, kernel_size=3):
+    def fake_launch(R=None, F=None, P=None, L=None, V=None, enhance_coe=10, kernel_size=3, **transform_kw):
+        assert set(transform_kw) == {"transform", "exp_scale", "exp_divisor", "apply_inverse"}
         log.append({k: b.id for k, b in (("R", R), ("F", F), ("P", P), ("L", L), ("V", V)) if b is not None})
 
     monkeypatch.setattr(pipeline, "RaggedBatch", FakeBatch)
