@@ -250,9 +250,14 @@ def revise_mask(mask: np.ndarray, kernel_size: int = 3, enhance_coe: float = 10.
 
 def mask_to_u8(mask: np.ndarray) -> np.ndarray:
     """``T.ToPILImage()`` on a float tensor: ``pic.mul(255).byte()`` -- a
-    truncating cast (llava.py:192-193, :243).  Input values are in [0, 1]."""
+    truncating cast (llava.py:192-193, :243).  Input values are in [0, 1] -- or NaN: a CONSTANT attention map (the driver's
+    OOM fallback ``torch.ones(24, 24) / 576``, main_batched.py:231) makes revise_mask divide 0 by 0 (llava.py:207-213), and
+    the float -> uint8 cast of NaN is implementation defined.  The reference's CPU path yields 0 for it (pinned by
+    tests/golden/main_batched_loop.npz, generated by importing the reference: mask of the constant map -> all zeros), stated
+    here explicitly instead of left to numpy's cast (which warns and happens to agree on x86)."""
     v = (np.asarray(mask, dtype=F32) * F32(255.0)).astype(F32)
-    return np.trunc(v).astype(np.int64).astype(np.uint8)
+    nan = np.isnan(v)
+    return np.where(nan, 0, np.trunc(np.where(nan, F32(0), v)).astype(np.int64)).astype(np.uint8)
 
 
 _PIL_PRECISION_BITS = 32 - 8 - 2   # Pillow src/libImaging/Resample.c

@@ -59,6 +59,27 @@ def config1_inputs():
     return img, att
 
 
+MAIN_BATCHED_LOOP_WH = [(683, 1024), (500, 375), (333, 500), (1024, 768), (640, 427)]      # W x H as PIL reports them
+
+
+def main_batched_loop_inputs():
+    """Inputs of tests/golden/main_batched_loop.npz: same recipe as tests/golden/make_golden.py::main_batched_loop_inputs (five
+    RGB images of different sizes and their 24 x 24 attention maps, the last one the constant 1 / 576 map)."""
+    import torch
+    imgs, atts = [], []
+    for i, (w, h) in enumerate(MAIN_BATCHED_LOOP_WH):
+        rng = np.random.default_rng(2600 + i)
+        yy, xx = np.mgrid[0:h, 0:w]
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        im[..., 1] = (127 + 120 * np.sin(xx / (11.0 + i)) * np.cos(yy / (17.0 + 2 * i))).astype(np.uint8)
+        imgs.append(im)
+        a = rng.random((24, 24)) ** 3
+        a[5 + i:8 + i, 9:12] += 4.0
+        atts.append((a / a.sum()).astype(np.float32))
+    atts[-1] = (torch.ones(24, 24) / 576).numpy()
+    return imgs, atts
+
+
 def marginalnet_full_state(shapes: dict) -> dict:
     """Seeded weights of MarginalNet(1024, 4096, hidden=256) (BASELINE configs[4]), same recipe as
     tests/golden/make_golden.py: keys in sorted order, N(0,1)/sqrt(fan_in) weights, small biases.  11 MB of weights

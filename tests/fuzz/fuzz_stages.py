@@ -214,6 +214,14 @@ def g_chain_u8():
     ok = np.array_equal(got, O.warp_image_by_attention(img, att, nw, nh, tr, mode=mode))
     return ok, (h, w, nw, nh, tr, mode)
 
+def rand_transform():
+    """save_warped_image's keyword arguments (new_method.py:405-411), identity half of the time (what both drivers pass)."""
+    if rng.random() < 0.5:
+        return {}
+    tr = str(rng.choice(["identity", "square", "sqrt", "exp", "log", "bogus"]))
+    es, ed = [(1.0, 1.0), (0.01, 2.0), (0.02, 1.5)][int(rng.integers(0, 3))] if tr == "exp" else (1.0, 1.0)
+    return dict(transform=tr, exp_scale=es, exp_divisor=ed, apply_inverse=bool(rng.random() < 0.4))
+
 def g_mask_chain_stream():
     """pipeline.MaskChainStream (the main_batched chain as a batch stream: the one-launch step where the shape is eligible,
     graph branches otherwise) against pipeline.warp_from_masks batch by batch, and the first batch against the oracle."""
@@ -221,14 +229,15 @@ def g_mask_chain_stream():
     n = int(rng.choice([5, 6, 8])); nb = n + int(rng.integers(0, 4))
     imgs = [T(rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8)) for _ in range(n)]
     msk = [T(rng.random((B, 24, 24), dtype=np.float32) ** int(rng.integers(1, 5))) for _ in range(n)]
-    mc = pipeline.MaskChainStream(imgs, msk, (Ho, So))
+    xf = rand_transform()
+    mc = pipeline.MaskChainStream(imgs, msk, (Ho, So), **xf)
     mc.prime(); mc.run(nb - mc.depth if nb > mc.depth else 0, unroll=int(rng.choice([2, 4])));
     if nb >= mc.depth: mc.drain()
     done = min(nb, n) if nb >= mc.depth else 0
     ok = True
     for j in range(max(0, nb - n), nb if nb >= mc.depth else 0):
-        ok = ok and bool(torch.equal(mc.outs[j % n], pipeline.warp_from_masks(imgs[j % n], msk[j % n], (Ho, So))))
-    return ok, (B, S, So, Ho, n, nb, mc.pattern)
+        ok = ok and bool(torch.equal(mc.outs[j % n], pipeline.warp_from_masks(imgs[j % n], msk[j % n], (Ho, So), **xf)))
+    return ok, (B, S, So, Ho, n, nb, mc.pattern, xf)
 
 def g_ragged_chain():
     """pipeline.warp_from_masks_ragged / RaggedMaskChainStream on batches of random sizes (unaligned widths, sides near the
@@ -247,24 +256,27 @@ def g_ragged_chain():
         batches.append(([T(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)) for (h, w) in sizes],
                         T(rng.random((B, 24, 24), dtype=np.float32) ** int(rng.integers(1, 5)))))
     ok = True
-    outs = [pipeline.warp_from_masks_ragged(i, a, (Ho, Wo)) for (i, a) in batches]
+    xf = rand_transform()
+    outs = [pipeline.warp_from_masks_ragged(i, a, (Ho, Wo), **xf) for (i, a) in batches]
     for (imgs, att), out in zip(batches, outs):
         for b in range(B):
-            ok = ok and bool(torch.equal(out[b], pipeline.warp_from_masks(imgs[b][None], att[b:b + 1], (Ho, Wo))[0]))
+            ok = ok and bool(torch.equal(out[b], pipeline.warp_from_masks(imgs[b][None], att[b:b + 1], (Ho, Wo), **xf)[0]))
     imgs, att = batches[0]
     b = int(rng.integers(0, B)); h, w = int(imgs[b].shape[0]), int(imgs[b].shape[1])
     rev = N(ae.revise_mask(att[b:b + 1]))[0]
-    ref = O.warp_image_by_attention(N(imgs[b]), O.lanczos_resize_u8(O.mask_to_u8(rev), w, h), Wo, Ho, "identity")
-    ok = ok and np.array_equal(N(outs[0][b]), ref)
+    if xf.get("transform", "identity") not in ("exp", "log"):          # (exp / log: the device libm may move a map entry by one ulp)
+        ref = O.warp_image_by_attention(N(imgs[b]), O.lanczos_resize_u8(O.mask_to_u8(rev), w, h), Wo, Ho, xf.get("transform", "identity"),
+                                        xf.get("exp_scale", 1.0), xf.get("exp_divisor", 1.0), xf.get("apply_inverse", False))
+        ok = ok and np.array_equal(N(outs[0][b]), ref)
     if all(pipeline.ragged_eligible(int(i.shape[0]), int(i.shape[1]), 3) for (im, _) in batches for i in im) and Wo * 3 <= 4096:
-        st = pipeline.RaggedMaskChainStream(out_size=(Ho, Wo))
+        st = pipeline.RaggedMaskChainStream(out_size=(Ho, Wo), **xf)
         got = []
         for (im, a) in batches:
             d = st.push(im, a)
             if d is not None: got.append(d.out)
         got += [d.out for d in st.flush()]
         ok = ok and len(got) == nb and all(bool(torch.equal(g, o)) for g, o in zip(got, outs))
-    return ok, (B, nb, Ho, Wo, [tuple(i.shape[:2]) for i in imgs])
+    return ok, (B, nb, Ho, Wo, [tuple(i.shape[:2]) for i in imgs], xf)
 
 for name, gen in (("ragged chain vs per-image + oracle", g_ragged_chain), ("MaskChainStream vs warp_from_masks", g_mask_chain_stream), ("clip_preprocess (+pad) (f3)", g_clip), ("probe_last_query (f4)", g_probe), ("MarginalNet tail (f1)", g_mn_tail), ("MarginalNet forward fused vs stock (f1)", g_marginalnet),
                   ("warp_image_by_attention chain", g_chain_u8), ("attention stack -> warp (bench path)", g_stack_chain),

@@ -55,6 +55,10 @@ def _install_stubs():
 
     cv2.remap = remap
     cv2.cvtColor = cvtColor
+    # blend_mask's overlay tail (llava.py:255-270): visualisation only, shape-correct stand-ins
+    cv2.normalize = lambda src, dst, a, b, norm_type: src
+    cv2.applyColorMap = lambda m, cmap: np.zeros(m.shape + (3,), np.uint8)
+    cv2.addWeighted = lambda a, wa, b, wb, g: a
     cv2.imwrite = lambda *a, **k: True
     cv2.imread = lambda *a, **k: None
     cv2.resize = lambda img, size, interpolation=None: img
@@ -225,6 +229,59 @@ def make_config1_golden(llava, new_method):
         out[f"mx_{w}"] = CAPTURED["map_x"][0].copy()
         out[f"my_{h}"] = CAPTURED["map_y"][:, 0].copy()
     np.savez_compressed(os.path.join(OUT, "config1.npz"), **out)
+
+
+MAIN_BATCHED_LOOP_WH = [(683, 1024), (500, 375), (333, 500), (1024, 768), (640, 427)]      # W x H as PIL reports them
+
+
+def main_batched_loop_inputs():
+    """The inputs of main_batched_loop.npz: five RGB images of different sizes (recipe, not stored: smooth content + noise so
+    that a wrong map shows) and their 24 x 24 attention maps -- four seeded maps and, for the LAST image, the constant 1/576 map
+    of the driver's OOM fallback (main_batched.py:231).  Recipe shared with the tests (tests/conftest.py)."""
+    imgs, atts = [], []
+    for i, (w, h) in enumerate(MAIN_BATCHED_LOOP_WH):
+        rng = np.random.default_rng(2600 + i)
+        yy, xx = np.mgrid[0:h, 0:w]
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        im[..., 1] = (127 + 120 * np.sin(xx / (11.0 + i)) * np.cos(yy / (17.0 + 2 * i))).astype(np.uint8)
+        imgs.append(im)
+        a = rng.random((24, 24)) ** 3
+        a[5 + i:8 + i, 9:12] += 4.0
+        atts.append((a / a.sum()).astype(np.float32))
+    atts[-1] = (torch.ones(24, 24) / 576).numpy()
+    return imgs, atts
+
+
+def make_main_batched_loop_golden(llava, new_method):
+    """The composed per-sample loop of the reference's batched driver on DIFFERENTLY sized images, run through the reference's
+    own functions in the driver's order (main_batched.py:243-287): blend_mask (llava.py:240-270: revise_mask -> toImg ->
+    invtrans(LANCZOS) to image.size) -> np.array(mota.convert('L')) -> save_warped_image(image_path=<PIL image>, att_map=mota_np,
+    width=500, height=500, transform="identity", ...) (new_method.py:405-506), whose cv2.remap call the stub records.
+    Stored per image: the uint8 `mota` and the two float32 maps.  The last image gets the constant 1/576 map: revise_mask
+    turns it into NaN (0 / 0), and the fixture records what torch's `.mul(255).byte()` makes of NaN on the reference's CPU path."""
+    imgs, atts = main_batched_loop_inputs()
+    out = {"sizes_wh": np.array(MAIN_BATCHED_LOOP_WH), "torch_version": np.array(torch.__version__),
+           "pillow_version": np.array(Image.__version__)}
+    for i, (im, att) in enumerate(zip(imgs, atts)):
+        pil = Image.fromarray(im)
+        with np.errstate(all="ignore"):
+            _, mota_mask = llava.blend_mask(pil, torch.from_numpy(att), 10, 3, Image.LANCZOS, 0)
+            mota_np = np.array(mota_mask.convert("L"))
+            CAPTURED.clear()
+            ok = new_method.save_warped_image(image_path=pil, att_map=mota_np, original_image_save_path=None,
+                                              masked_overlay_save_path=None, output_path="/dev/null", vis_path=None,
+                                              width=500, height=500, transform="identity", exp_scale=1.0, exp_divisor=1.0,
+                                              apply_inverse=False)
+        assert ok is True and mota_np.shape == im.shape[:2]
+        assert np.all(CAPTURED["map_x"] == CAPTURED["map_x"][0:1]) and np.all(CAPTURED["map_y"] == CAPTURED["map_y"][:, 0:1])
+        out[f"att_{i}"] = att
+        out[f"mota_{i}"] = mota_np
+        out[f"mx_{i}"] = CAPTURED["map_x"][0].copy()
+        out[f"my_{i}"] = CAPTURED["map_y"][:, 0].copy()
+        out[f"img_sum_{i}"] = np.array(int(im.sum()))
+    np.savez_compressed(os.path.join(OUT, "main_batched_loop.npz"), **out)
+    print("main_batched_loop.npz", os.path.getsize(os.path.join(OUT, "main_batched_loop.npz")) / 1024, "KiB; NaN map -> mota values",
+          np.unique(out[f"mota_{len(imgs) - 1}"]))
 
 
 def make_marginalnet_tail_golden(model):
@@ -402,6 +459,14 @@ def main():
         llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
         make_random_cases(new_method, ckpt, llava)
         return
+    if "--only-loop" in sys.argv:
+        _install_stubs()
+        torch.set_num_threads(1)
+        new_method = _load("ref_new_method", os.path.join(AGW, "new_method.py"))
+        sys.path.insert(0, os.path.join(AGW, "attention_extraction"))
+        llava = _load("ref_llava", os.path.join(AGW, "attention_extraction", "llava.py"))
+        make_main_batched_loop_golden(llava, new_method)
+        return
     if "--only-mnfull" in sys.argv:
         _install_stubs()
         torch.set_num_threads(1)
@@ -423,6 +488,7 @@ def main():
     make_config1_golden(llava, new_method)
     if "--only-config1" in sys.argv:
         return
+    make_main_batched_loop_golden(llava, new_method)
     make_marginalnet_tail_golden(model)
     if "--only-mntail" in sys.argv:
         return

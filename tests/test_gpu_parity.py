@@ -12,7 +12,7 @@ import torch
 
 from attwarp_amd import _lib
 from oracle import warp_oracle as O
-from conftest import pool_input, clip_input, clip_digest, config1_inputs
+from conftest import pool_input, clip_input, clip_digest, config1_inputs, main_batched_loop_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -2851,6 +2851,48 @@ def test_ragged_chain_p_and_f_stages_vs_reference_transform_combos(dev, golden):
             n_elem += fin.sum(); n_diff += (got[fin] != ref[fin]).sum()
             np.testing.assert_allclose(got[fin], ref[fin], rtol=2.5e-7, atol=1e-30, err_msg=key)
     assert n_combo == 48 and n_diff <= 1e-3 * max(n_elem, 1), (n_combo, n_diff, n_elem)
+
+
+def test_main_batched_loop_ragged_vs_reference_fixture(dev, golden):
+    """The composed loop of the reference's batched driver on differently sized images (main_batched.py:243-287 -> llava.py:
+    240-253 -> new_method.py:415-488), pinned to what the REFERENCE ITSELF produced (tests/golden/main_batched_loop.npz: five
+    images, 683 x 1024 .. 640 x 427, the last with the constant 1 / 576 map whose revised mask is NaN):
+      * warp_from_masks_ragged's up-sampled masks against the reference's uint8 `mota`: at most one grey level apart, the number
+        of differing cells COUNTED and bounded (device exp in revise_mask is 1 ulp from torch's; x255 truncates), zero for the
+        NaN map (NaN -> 0, as the reference's .byte());
+      * GIVEN the reference's mota, the P and F stages of the ragged kernel reproduce the two float32 maps the reference handed
+        to cv2.remap bit for bit, and the R stage the oracle's pixels on those maps bit for bit;
+      * the composed output differs from that only where a mask cell flipped."""
+    from attwarp_amd import pipeline
+    g = golden("main_batched_loop")
+    imgs, atts = main_batched_loop_inputs()
+    B = len(imgs)
+    d_imgs = pipeline.upload_images(imgs, dev)
+    att = T(np.stack(atts), dev)
+    out, rb = pipeline.warp_from_masks_ragged(d_imgs, att, (500, 500), return_batch=True)
+    out = N(out)
+    flips, cells = 0, 0
+    for b in range(B):
+        ref, got = g[f"mota_{b}"], N(rb.mota_of(b))
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1, (b, int(d.max()))
+        flips += int((d != 0).sum()); cells += d.size
+    print(f"main_batched loop vs the reference fixture: {flips} of {cells} up-sampled mask cells differ by one grey level")
+    assert flips <= 2e-3 * cells, (flips, cells)
+    assert not N(rb.mota_of(B - 1)).any()                      # the NaN mask of the constant map: zeros, as the reference's cast
+    composed_maps = (N(rb.map_x).copy(), N(rb.map_y).copy())
+    # given the reference's masks: maps bit for bit, pixels = the oracle's resample on the reference's maps
+    for b in range(B):
+        rb.mota_of(b).copy_(T(g[f"mota_{b}"], dev))
+    pipeline.ragged_chain_launch(P=rb); pipeline.ragged_chain_launch(F=rb); pipeline.ragged_chain_launch(R=rb)
+    mx, my, px = N(rb.map_x), N(rb.map_y), N(rb.out)
+    for b in range(B):
+        assert np.array_equal(mx[b], g[f"mx_{b}"]) and np.array_equal(my[b], g[f"my_{b}"]), b
+        assert np.array_equal(px[b], O.remap_bilinear(imgs[b], g[f"mx_{b}"], g[f"my_{b}"], "cv2")), b
+    if flips == 0:
+        assert np.array_equal(out, px) and np.array_equal(composed_maps[0], mx) and np.array_equal(composed_maps[1], my)
+    else:                                                       # a flipped mask cell moves the maps by ~1e-6 of a pixel
+        assert np.abs(composed_maps[0] - mx).max() < 1e-2 and np.abs(out.astype(int) - px.astype(int)).max() <= 2
 
 
 @pytest.mark.parametrize("n", [1, 3, 5, 6])

@@ -539,3 +539,36 @@ def test_remap_cv2_fixture_if_present():
     for key in [str(k) for k in g["cases"]]:
         got = O.remap_bilinear(g[f"{key}|img"], g[f"{key}|mx"], g[f"{key}|my"], "cv2")
         assert np.array_equal(got.reshape(g[f"{key}|out"].shape), g[f"{key}|out"]), (key, str(g["opencv_build"]))
+
+
+def test_main_batched_loop_on_differently_sized_images_vs_reference(golden):
+    """tests/golden/main_batched_loop.npz: the COMPOSED per-sample loop of the reference's batched driver (main_batched.py:243-287:
+    blend_mask -> np.array(mota.convert('L')) -> save_warped_image(PIL image, mota, 500 x 500, "identity")) run through the
+    reference itself on five images of different sizes (683 x 1024, 500 x 375, 333 x 500, 1024 x 768, 640 x 427), the last one with
+    the constant 1 / 576 map of the driver's OOM fallback (:231).  The oracle chain reproduces the reference's uint8 masks
+    -- the NaN -> uint8 cast of the constant map included -- and, from them, the two float32 maps it handed to cv2.remap, bit
+    for bit."""
+    from conftest import main_batched_loop_inputs, MAIN_BATCHED_LOOP_WH
+    g = golden("main_batched_loop")
+    imgs, atts = main_batched_loop_inputs()
+    assert [tuple(v) for v in g["sizes_wh"]] == MAIN_BATCHED_LOOP_WH
+    flips = 0
+    for i, (im, att) in enumerate(zip(imgs, atts)):
+        h, w = im.shape[:2]
+        assert int(im.sum()) == int(g[f"img_sum_{i}"]) and np.array_equal(att, g[f"att_{i}"])
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)          # the NaN cast is explicit in the oracle: no warning
+            with np.errstate(invalid="ignore", divide="ignore"):    # (the 0 / 0 of the constant map itself is the reference's)
+                rev = O.revise_mask(att, 3, 10)
+            mota = O.lanczos_resize_u8(O.mask_to_u8(rev), w, h)
+        assert mota.shape == g[f"mota_{i}"].shape
+        flips += int((mota != g[f"mota_{i}"]).sum())
+        mx, my = O.maps_from_attention(g[f"mota_{i}"], 500, 500, "identity")
+        assert np.array_equal(mx, g[f"mx_{i}"]) and np.array_equal(my, g[f"my_{i}"]), i
+    assert flips == 0, flips                                        # every mask cell of every image, the all-zero mask of the NaN map too
+    last = len(imgs) - 1
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert np.isnan(O.revise_mask(atts[last], 3, 10)).all() and not g[f"mota_{last}"].any()
+    # the all-zero mask takes the uniform maps of the near-zero fallback (new_method.py:231-239): a plain resize
+    assert np.allclose(g[f"mx_{last}"], np.interp(np.arange(500), np.arange(641) * 500 / 640, np.arange(641)), atol=1e-3)

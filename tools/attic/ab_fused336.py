@@ -1,6 +1,6 @@
 """Dev tool: block-order variants of the resample INSIDE the fused step (B=256 / B=64 336x336 ring), same process."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from attwarp_amd import dist as D, pipeline, _lib
 dev = torch.device("cuda:0")

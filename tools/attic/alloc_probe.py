@@ -3,7 +3,7 @@
  (batch size), (3) a per-XCD start skew inside the contiguous ranges.   python tools/alloc_probe.py"""
 import os, statistics, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import checkpoint_utils as cu, _lib
 from remap_bench import maps
 

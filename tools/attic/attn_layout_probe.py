@@ -1,6 +1,6 @@
 """Dev tool: does the attention reduce depend on the slice layout (alignment of the 576-token window, gap between rows)?"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline
 dev = torch.device("cuda:0")
 def timeit(fn, n=30):

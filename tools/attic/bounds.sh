@@ -17,5 +17,5 @@ for rep in range(4):
             res[b].append(rb.bench(256, 1024, "hwc", "uniform", "cv2", 10, **({"bound": 1} if b else {})))
 print("E1 headline cv2 resample 256x1024x1024x3: baseline ms", [round(v, 4) for v in res[0]], " top-row-only, 3-row LDS pool ms", [round(v, 4) for v in res[1]], flush=True)
 PY
-for t in "" "bound:2"; do python tools/chain_stream_bench.py patterns=fused cases=256:1024:500 tune=$t; done
-for t in "" "bound:4" "bound:8" ""; do python tools/chain_stream_bench.py patterns=fused cases=32:336:500,64:336:500 tune=$t; done
+for t in "" "bound:2"; do python tools/attic/chain_stream_bench.py patterns=fused cases=256:1024:500 tune=$t; done
+for t in "" "bound:4" "bound:8" ""; do python tools/attic/chain_stream_bench.py patterns=fused cases=32:336:500,64:336:500 tune=$t; done

@@ -1,6 +1,6 @@
 """Dev tool: one line per lease -- device properties, the resample kernel (cv2, B=256 1024x1024 HWC) and torch.add."""
 import os, sys, statistics, subprocess, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import checkpoint_utils as cu
 from remap_bench import maps
 dev = torch.device("cuda:0")

@@ -2,7 +2,7 @@
 against the serial launches of pipeline.warp_from_masks, over a ring of independent batches larger than the Infinity
 Cache.  usage: python tools/chain_stream_bench.py [patterns=serial,branches,fused] [cases=32:336:500,...]"""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline, _lib
 dev = torch.device("cuda:0")
 args = dict(a.split("=") for a in sys.argv[1:])

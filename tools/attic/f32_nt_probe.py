@@ -1,7 +1,7 @@
 """Dev tool: nontemporal stores / loads of the float32 resample (tuning flavour, remap_nt bits) on batches that do not fit
 the Infinity Cache, and inside the one-launch stream step at 336x336."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline, checkpoint_utils as cu, _lib
 dev = torch.device("cuda:0")
 def t(fn, n=15):

@@ -2,7 +2,7 @@
 group size at 1024x1024x3 B=256 (uniform maps), exact mode and torch.add beside them, alternating in one process.
 One line per lease: run it on several (`gpurun -- python tools/lease_orders.py`) and compare the worst cases."""
 import os, sys, io, contextlib, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import remap_bench as rb
 kind = sys.argv[1] if len(sys.argv) > 1 else "uniform"
 vars_ = [("cv2", dict(remap_rows=3, remap_cpw=c, remap_noswz=g)) for c, g in ((1, 4),)] + \

@@ -1,7 +1,7 @@
 """Dev tool: the 336x336 stream step as one launch per batch (pipeline.OverlappedWarp, pattern "fused") against one launch
 per TWO batches (pipeline.PairedStepWarp), same ring of independent batches (>= 2 GiB), same process, alternating."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline
 dev = torch.device("cuda:0")
 K = 96

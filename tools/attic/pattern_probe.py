@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline
 dev = torch.device("cuda:0")
 x = torch.empty(1 << 28, device=dev)

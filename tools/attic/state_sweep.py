@@ -4,7 +4,7 @@ bytes in every cycle as the calibration, rocm-smi clocks / power sampled by a ba
     python tools/state_sweep.py [dur_seconds] [kind] [S] [B] ["R3c4:remap_rows=3,remap_cpw=4;..."]"""
 import json, os, statistics, subprocess, sys, threading, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import checkpoint_utils as cu, _lib
 from remap_bench import maps
 

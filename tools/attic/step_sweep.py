@@ -1,7 +1,7 @@
 """Dev tool (round 4): rows per block x row blocks per workgroup of the resample INSIDE the one-launch 336x336 step
 (pipeline.OverlappedWarp, pattern "fused"; graphs are captured under the attwarp_debug_set overrides), one process."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline, _lib
 dev = torch.device("cuda:0")
 K = 96

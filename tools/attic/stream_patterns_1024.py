@@ -1,6 +1,6 @@
 """Dev tool: the stream patterns of pipeline.OverlappedWarp at B=256 1024x1024 float32 (graph replay, cycled in one process)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline
 dev = torch.device("cuda:0")
 B, S = 256, 1024

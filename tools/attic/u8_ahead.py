@@ -1,7 +1,7 @@
 """Dev tool: integer uint8 cv2 resample, rows requested ahead (1 / 2 / 4) x (rows per block, blocks per workgroup), cycled
 in one process so that every variant sees the same lease and clock state (medians over the cycles)."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline, checkpoint_utils as cu, _lib
 dev = torch.device("cuda:0")
 def t(fn, n=12):

@@ -2,7 +2,7 @@
 256-entry LDS table for sqrt / exp / log.  Which is faster?  (attention_axis_maps = marginals + finalize; the finalize is the
 same for both.)"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import new_method as nm
 dev = torch.device("cuda:0")
 def t(fn, n=20):

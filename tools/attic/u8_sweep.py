@@ -1,6 +1,6 @@
 """Dev tool: rows-per-block x row-blocks-per-workgroup sweep of the integer uint8 cv2 resample."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import pipeline, checkpoint_utils as cu, _lib
 dev = torch.device("cuda:0")
 def t(fn, n=20):

@@ -1,7 +1,7 @@
 """round 5: where does the unaligned uint8 resample lose?  684-wide images (aligned) on the aligned kernel, on the UA
 instantiation (forced: tuning key bound=16), from a view that starts 1 byte in (every row misaligned by 1), and 683-wide."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import checkpoint_utils as cu, pipeline, _lib
 dev = torch.device("cuda:0")
 def t(fn, n=20):

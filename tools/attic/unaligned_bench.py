@@ -2,7 +2,7 @@
 images 683 wide (rows of 2049 bytes / 2049 floats: the portrait TextVQA case) against 684 wide, same process, alternating;
 the generic gather kernel (where these shapes ran until round 4) beside them."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from attwarp_amd import checkpoint_utils as cu, pipeline, _lib
 dev = torch.device("cuda:0")
 

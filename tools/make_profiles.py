@@ -3,8 +3,9 @@ under profiles/: kernel-stats table, HBM traffic of the resample kernel from the
 bench lines, stage / chain benches.   usage: make_profiles.py [src_tag] [name]   (default r2 round2)"""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src_tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
-tag = sys.argv[2] if len(sys.argv) > 2 else "round5"
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+src_tag = pos[0] if len(pos) > 0 else "r6"
+tag = pos[1] if len(pos) > 1 else "round6"
 SRC = os.path.join(ROOT, "gpurun_out", src_tag)
 DST = os.path.join(ROOT, "profiles")
 
@@ -13,6 +14,37 @@ def one(pattern):
     assert files, pattern
     return max(files, key=os.path.getmtime)      # gpurun merges into gpurun_out/: older leases' files may still lie there
 
+def pmc(dirname, counter):
+    vals = []
+    for r in csv.DictReader(open(one(f"keep/{dirname}/*counter_collection.csv"))):
+        if "remap_rows_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.append(float(r["Counter_Value"]))
+    return vals
+B, S = 256, 1024
+alg = 2 * B * S * S * 3 * 4
+traffic = {}
+for mode in ("cv2", "exact", "cv2_chw"):
+    fetch, write = pmc(f"pmc_fetch_{mode}", "FETCH_SIZE"), pmc(f"pmc_write_{mode}", "WRITE_SIZE")
+    f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+    total = (2 * f_kb + w_kb) * 1024
+    traffic[f"1024_{mode}"] = {
+        "remap_rows_kernel_bytes_per_launch": total, "ratio_to_algorithmic": total / alg, "FETCH_SIZE_KB_raw": f_kb,
+        "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": min(len(fetch), len(write)),
+        "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline "
+                f"--no-also --steps 5 --mode {mode.split('_')[0]}{' --layout chw' if mode.endswith('_chw') else ''}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
+                f"MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}
+    print(mode, "traffic ratio", total / alg)
+lease = open(os.path.join(SRC, "lease.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(SRC, "lease.txt")) else "unrecorded"
+for v in traffic.values():
+    v["lease"] = lease
+    v["same_lease_as"] = (f"profiles/{tag}_bench.json, {tag}_bench_kernel_stats.* (one run of tools/refresh_profiles.sh {src_tag}: the counter passes "
+                          "ran FIRST, the bench line that quotes them right behind on the same box)")
+json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+if "--pmc-only" in sys.argv:
+    # (refresh_profiles.sh runs this ON THE GPU BOX between the counter passes and the bench line, so that the line's
+    #  `roofline.traffic` -- read from profiles/pmc_traffic.json -- quotes the lease it was measured on)
+    shutil.copy(os.path.join(DST, "pmc_traffic.json"), os.path.join(SRC, "pmc_traffic.json"))
+    sys.exit(0)
 stats = one("keep/trace/*kernel_stats.csv")
 shutil.copy(stats, os.path.join(DST, f"{tag}_bench_kernel_stats.csv"))
 full = glob.glob(os.path.join(SRC, "keep/trace_full/*kernel_stats.csv"))
@@ -50,40 +82,17 @@ with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
             f"roofline {json.dumps(prof['roofline'])}, "
             f"stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
 
-def pmc(dirname, counter):
-    vals = []
-    for r in csv.DictReader(open(one(f"keep/{dirname}/*counter_collection.csv"))):
-        if "remap_rows_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            vals.append(float(r["Counter_Value"]))
-    return vals
-B, S = 256, 1024
-alg = 2 * B * S * S * 3 * 4
-traffic = {}
-for mode in ("cv2", "exact", "cv2_chw"):
-    fetch, write = pmc(f"pmc_fetch_{mode}", "FETCH_SIZE"), pmc(f"pmc_write_{mode}", "WRITE_SIZE")
-    f_kb, w_kb = sum(fetch) / len(fetch), sum(write) / len(write)
-    total = (2 * f_kb + w_kb) * 1024
-    traffic[f"1024_{mode}"] = {
-        "remap_rows_kernel_bytes_per_launch": total, "ratio_to_algorithmic": total / alg, "FETCH_SIZE_KB_raw": f_kb,
-        "WRITE_SIZE_KB_raw": w_kb, "launches_averaged": min(len(fetch), len(write)),
-        "note": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --no-cpu-baseline "
-                f"--no-also --steps 5 --mode {mode.split('_')[0]}{' --layout chw' if mode.endswith('_chw') else ''}`, mean over the launches of remap_rows_kernel; FETCH_SIZE doubled per "
-                f"MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced streaming read); KB -> bytes x1024"}
-    print(mode, "traffic ratio", total / alg)
-lease = open(os.path.join(SRC, "lease.txt")).read().strip().replace("\n", "; ") if os.path.exists(os.path.join(SRC, "lease.txt")) else "unrecorded"
-for v in traffic.values():
-    v["lease"] = lease
-    v["same_lease_as"] = f"profiles/{tag}_bench.json, {tag}_bench_kernel_stats.* (one run of tools/refresh_profiles.sh {src_tag})"
-json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
 bench_line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(DST, f"{tag}_bench.json"), "w").write(bench_line)
+if os.path.exists(os.path.join(SRC, "pmc_traffic.json")):      # the file the bench line read on the box
+    shutil.copy(os.path.join(SRC, "pmc_traffic.json"), os.path.join(DST, "pmc_traffic.json"))
 for name in ("bench_336", "bench_336x256", "bench_main_batched", "bench_main_batched_ragged", "bench_config5", "bench_force_dist"):
     if os.path.exists(os.path.join(SRC, f"{name}.json")):
         open(os.path.join(DST, f"{tag}_{name}.json"), "w").write([l for l in open(os.path.join(SRC, f"{name}.json")) if l.startswith("{")][-1])
 for name in ("stage_bench", "chain_bench", "probe_bench", "remap_bench", "chain_kernel_stats", "attn_bench", "u8_bench", "chain_stream",
              "pair_step", "chain_step_kernel_stats", "remap_lines", "timeline_chain_32_336_500", "timeline_chain_64_336_500",
              "timeline_chain_256_1024_500", "timeline_step_64_336", "timeline_step_256_336", "timeline_remap_256_1024",
-             "timeline_remap_256_336", "timeline_ragged_32", "timeline_ragged_256", "bounds", "ragged_kernel_stats"):
+             "timeline_remap_256_336", "timeline_ragged_32", "timeline_ragged_256", "bounds", "ragged_kernel_stats", "lease"):
     if os.path.exists(os.path.join(SRC, f"{name}.txt")):
         shutil.copy(os.path.join(SRC, f"{name}.txt"), os.path.join(DST, f"{tag}_{name}.txt"))
 print(bench_line)

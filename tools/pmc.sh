@@ -17,6 +17,7 @@ P7="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRR
 i=0
 for P in "$P1" "$P2" "$P3" "FETCH_SIZE" "WRITE_SIZE" "$P4" "$P5" "$P6" "$P7"; do
   i=$((i+1))
+  [ $i -gt ${PMC_PASSES:-9} ] && break      # PMC_PASSES=5: the SQ passes + FETCH_SIZE / WRITE_SIZE only
   rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT/p$i -- python3 $ROOT/tools/"$@" > $OUT/p$i.log 2>&1 || echo "pass $i ($P) failed" >> $OUT/errors.txt
 done
 {

@@ -5,6 +5,7 @@ targets
   remap [B S] [peaked] [key=value ...]   float32 resample at BASELINE configs[2]; key=value: attwarp_debug_set overrides
   chain [B S So]             every kernel of the main_batched chain (pipeline.warp_from_masks), default 256 1024 500
   chain_step [B S So]        the one-launch chain step (pipeline.MaskChainStream pattern "fused")
+  u8 [B S So [W]]            the integer uint8 cv2 resample alone, [B,S,W,3] -> [B,So,So,3] (default 256 1024 1024)
   ragged [B]                 the ragged chain (TextVQA-like size mix -> 500 x 500): five launches per batch, then the one-launch stream step
   attn                       attention reduce, float32 + float16 rows, bench shape
   steps                      attention reduce + axis_maps_from_steps at the bench shapes
@@ -79,6 +80,18 @@ elif target == "ragged":
         pipeline.warp_from_masks_ragged(ring[0].images, ring[0].masks, (500, 500))
     st = pipeline.RaggedMaskChainStream(out_size=(500, 500))
     st.ring(ring); st.prime(); st.run(24); st.drain_ring()
+elif target == "u8":
+    # the integer uint8 cv2 resample alone (remap_rows_u8i_kernel), maps from a mildly peaked 24-bin PDF
+    B, S, So = ints[:3] if len(ints) >= 3 else (256, 1024, 1024)
+    W = ints[3] if len(ints) >= 4 else S                     # e.g. `u8 256 1024 500 683`: 683-pixel-wide rows (the unaligned form)
+    g = torch.Generator(device=dev).manual_seed(1)
+    px = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.3, 1)
+    py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.3, 1)
+    mx, my = pipeline.axis_maps_from_pdf(px, py, (S, W), (So, So))
+    img = torch.randint(0, 256, (B, S, W, 3), device=dev, dtype=torch.uint8, generator=g)
+    out = torch.empty(B, So, So, 3, device=dev, dtype=torch.uint8)
+    for _ in range(8):
+        cu.remap_separable(img, mx, my, channels_last=True, out=out)
 elif target == "attn":
     B = 256
     rows = torch.softmax(torch.randn(20, B, 32, 640, device=dev), -1)
