@@ -410,7 +410,8 @@ def load_pmc_traffic(workload: str, mode: str):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
-        return d.get(f"{workload}_{mode}", d.get(workload, {})).get("remap_rows_kernel_bytes_per_launch")
+        e = d.get(f"{workload}_{mode}", d.get(workload, {}))
+        return e.get("remap_rows_kernel_bytes_per_launch", e.get("bytes_per_launch"))
     except Exception:
         return None
 
@@ -911,6 +912,54 @@ def chain_cpu_baseline(dev, torch, pipeline, So, budget_s: float = 8.0):
                     "revised mask is what the tests assert"}
 
 
+def leg_u8(dev, torch, pipeline, K):
+    """The resample the reference's drivers actually run: uint8 BGR in, uint8 out (AGW/new_method.py:268-271), the integer cv2
+    kernel (`remap_rows_u8i_kernel`) ALONE -- maps from a mildly peaked 24-bin PDF, HIP events around every launch, rotating
+    over >= 2 GiB of independent batches so every launch streams from HBM.  `roofline` per case on the algorithmic bytes
+    (S_in*W_in + S_out*S_out) * 3 per image (uint8 variant); `unaligned_over_aligned`: 683-pixel-wide rows (2049
+    bytes: the portrait TextVQA case, the kernel's unaligned form) against 684-pixel-wide ones."""
+    from attwarp_amd import checkpoint_utils as cu
+    out = {"workload": "uint8 [B,H,W,3] -> [B,S_out,S_out,3], mode=cv2: the integer resample alone", "unit": "images/s", "cases": []}
+    ms_of = {}
+    for (B, H, W, So) in ((256, 1024, 1024, 1024), (256, 1024, 1024, 500), (64, 336, 336, 500), (256, 1024, 684, 500), (256, 1024, 683, 500)):
+        per = B * (H * W * 3 + So * So * 3)
+        n = max(1, min(16, -(-(2 << 30) // per)))
+        g = torch.Generator(device=dev).manual_seed(B + W + So)
+        imgs = [torch.randint(0, 256, (B, H, W, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
+        outs = [torch.empty(B, So, So, 3, device=dev, dtype=torch.uint8) for _ in range(n)]
+        px = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.3, 1)
+        py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.3, 1)
+        mx, my = pipeline.axis_maps_from_pdf(px, py, (H, W), (So, So))
+        for i in range(3):
+            cu.remap_separable(imgs[i % n], mx, my, mode="cv2", channels_last=True, out=outs[i % n])
+        torch.cuda.synchronize()
+        evs = []
+        for i in range(K):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); cu.remap_separable(imgs[i % n], mx, my, mode="cv2", channels_last=True, out=outs[i % n]); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) for a, b in evs]
+        ms = sum(ts) / len(ts)
+        ms_of[(B, H, W, So)] = ms
+        ach = per / (ms * 1e-3) / 1e9
+        out["cases"].append({"B": B, "H": H, "W": W, "S_out": So, "rotating_batches": n, "images_per_s": round(B / (ms * 1e-3), 1),
+                             "roofline": {"bound": "hbm", "kernel": "remap_rows_u8i_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": per,
+                                          "kernel_ms_mean": round(ms, 4), "kernel_ms_min": round(min(ts), 4), "launches_timed": K,
+                                          "traffic": None,
+                                          "traffic_source": "null: this kernel loads ONE dword per lane, an access width for which FETCH_SIZE is "
+                                                            "uncalibrated on gfx950 (MI355X_MICROARCH.md, HBM); the raw FETCH_SIZE / WRITE_SIZE passes "
+                                                            "are in profiles/round6_u8_pmc_*.txt (1024 -> 1024: 2 x FETCH + WRITE = 1.028 x algorithmic)"}})
+        del imgs, outs
+        torch.cuda.empty_cache()
+    out["unaligned_over_aligned"] = round(ms_of[(256, 1024, 683, 500)] / ms_of[(256, 1024, 684, 500)], 3)
+    out["value"] = out["cases"][0]["images_per_s"]
+    out["value_is"] = "B=256, 1024 x 1024 x 3 -> 1024 x 1024 x 3 (the headline size in the dtype the reference's drivers use)"
+    out["roofline"] = out["cases"][0]["roofline"]
+    return out
+
+
 def leg_pool_input(dev, torch, pipeline, B, S, mode, K):
     """SURVEY 8d config 3's other input form: full-resolution attention [B,1,S,S] float32 -> F.adaptive_avg_pool2d to 24 x 24
     (MN/trainer.py:197 + sanitise :202) -> gt_marginals (MN/checkpoint_utils.py:43-51) -> right-inverse PDF -> CDF ->
@@ -1104,6 +1153,7 @@ LEGS = {
     "fp16_attention": "configs[3]'s per-rank batch with float16 attention rows (also_336x256_fp16_attention)",
     "main_batched": "the reference's own uint8 chain (main_batched.py:243-287) as a stream step vs its serial launches (also_main_batched)",
     "main_batched_ragged": "the same chain on batches of DIFFERENTLY sized images, as that driver holds them: one ragged launch per batch vs the per-image loop and vs the equal-size stream step (also_main_batched_ragged)",
+    "u8": "the uint8 integer cv2 resample alone (what the reference's drivers run: new_method.py:268-271) with its own roofline block, and 683- against 684-pixel-wide rows (also_u8)",
     "pool_input": "configs[2]'s other input form: full-resolution attention [B,1,S,S] -> 24x24 pool -> maps -> warp (also_pool_input)",
     "config5": "configs[4] data flow with a random-weight CLIP ViT-L/14-336 tower, per-leg ms (also_config5)",
 }
@@ -1416,6 +1466,7 @@ def main():
         # (a failure inside one of these legs -- e.g. `transformers` missing for the vision tower -- must not cost the main line)
         for key, leg in (("main_batched", lambda: leg_main_batched(dev, torch, pipeline, n2)),
                          ("main_batched_ragged", lambda: leg_main_batched_ragged(dev, torch, pipeline, n2, D, **rk)),
+                         ("u8", lambda: leg_u8(dev, torch, pipeline, args.steps)),
                          ("pool_input", lambda: leg_pool_input(dev, torch, pipeline, B, S, args.mode, args.steps)),
                          ("config5", lambda: leg_config5(dev, torch, pipeline, 32, 3))):
             if key in want:

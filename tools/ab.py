@@ -56,12 +56,12 @@ if "--child" in sys.argv:
             torch.cuda.empty_cache()
     elif target == "u8":       # the integer uint8 resample alone and inside the one-launch chain steps (uniform + ragged)
         import remap_bench as rb, time
-        for (B, S) in ((256, 336), (256, 1024)):
+        for (B, S, So) in ((64, 336, 500), (256, 336, 500), (256, 1024, 500), (256, 1024, 1024), (256, 683, 500)):
             g = torch.Generator(device=dev).manual_seed(1)
-            img = torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g)
+            img = torch.randint(0, 256, (B, S if S != 683 else 1024, S, 3), device=dev, dtype=torch.uint8, generator=g)
             px = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.5, 1); py = torch.softmax(torch.randn(B, 24, device=dev, generator=g) * 0.5, 1)
-            mx, my = pipeline.axis_maps_from_pdf(px, py, (S, S), (500, 500))
-            out = torch.empty(B, 500, 500, 3, device=dev, dtype=torch.uint8)
+            mx, my = pipeline.axis_maps_from_pdf(px, py, (img.shape[1], S), (So, So))
+            out = torch.empty(B, So, So, 3, device=dev, dtype=torch.uint8)
             from attwarp_amd import checkpoint_utils as cu
             for _ in range(5): cu.remap_separable(img, mx, my, mode="cv2", channels_last=True, out=out)
             torch.cuda.synchronize(); ts = []
@@ -69,7 +69,7 @@ if "--child" in sys.argv:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(); cu.remap_separable(img, mx, my, mode="cv2", channels_last=True, out=out); e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1))
-            print(f"{tag:22s} u8 cv2 B={B} {S}->500: {sorted(ts)[20]*1e3:.1f} us", flush=True)
+            print(f"{tag:22s} u8 cv2 B={B} W={S}->{So}: {sorted(ts)[20]*1e3:.1f} us", flush=True)
             del img, out
         for (B, S, K) in ((32, 336, 64), (256, 1024, 32)):
             n = 6 if S == 1024 else 16
