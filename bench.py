@@ -52,7 +52,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 T_STEPS, HEADS, KV, NTOK = 20, 32, 640, 576
 WORKLOADS = {"1024": (256, 1024, 2), "336": (64, 336, 1), "336x256": (256, 336, 3)}   # B per GPU, S, BASELINE config
-PREWARM_STEPS = 25             # untimed device pre-conditioning before the W warm-up steps (see main())
+PREWARM_STEPS = 0              # extra untimed device pre-conditioning in front of the W warm-up steps: NONE by default (--prewarm N adds it)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -497,7 +497,7 @@ def step_bytes(B: int, S: int, attn_esize: int = 4) -> float:
     return float(B) * (2.0 * S * S * 3 * 4 + T_STEPS * HEADS * NTOK * attn_esize)
 
 
-PREWARM_SMALL_S = 0.5          # seconds of untimed graph replays before the warm-up steps of the 336 workloads
+PREWARM_SMALL_S = 0.0          # seconds of extra untimed graph replays before the warm-up steps of the 336 workloads (--prewarm, tenths of a second)
 
 
 def small_workload(B, S, dev, seed, mode, layout, K, W, D, torch, pipeline, attn_dtype=None, prewarm_s=0.0):
@@ -1164,13 +1164,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3,
-                    help="W untimed warm-up steps of the timed loop itself.  They run BEHIND the device pre-conditioning of "
-                         "--prewarm (also untimed, reported as `prewarm_steps` in the JSON line): the untimed work in front of "
-                         "the K timed steps is prewarm + W, and `--prewarm 0` makes it exactly W")
+                    help="W untimed warm-up steps in front of the K timed steps (the contract's warm-up; `--prewarm` can add more, "
+                         "none by default)")
     ap.add_argument("--prewarm", type=int, default=-1,
-                    help="untimed device pre-conditioning in front of the warm-up: steps of the 1024 workload (default "
-                         f"{PREWARM_STEPS}: the first ~20 launches of a process run 1-2 %% slower, clock ramp) / tenths of a second of "
-                         "graph replays for the 336 workloads (default 5); 0 = none")
+                    help="EXTRA untimed device pre-conditioning in front of the W warm-up steps: steps of the 1024 workload / tenths "
+                         "of a second of graph replays for the 336 workloads.  Default: none (the untimed work in front of the K timed "
+                         "steps of the main line is the pipeline priming + W; the three-launch `also_eager` measurement, itself W + K "
+                         "steps, runs before it).  The first ~20 launches of a process run 1-2 %% slower (clock ramp): a run that times "
+                         "a 336 workload as its FIRST work can add `--prewarm 5`; reported as `prewarm_steps`")
     ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["config5", "main_batched", "main_batched_ragged"], default="1024")
     ap.add_argument("--mode", choices=["cv2", "exact"], default="cv2", help="resample arithmetic of the main line")
     ap.add_argument("--layout", choices=["hwc", "chw"], default="hwc")
@@ -1326,8 +1327,7 @@ def main():
         del ow
     else:
         step = Step(B, S, dev, seed=1234 + rank, mode=args.mode, layout=args.layout)
-        # device pre-conditioning, untimed and outside the contract's W warm-up steps: the first ~20 launches after
-        # start-up run 1-2 % slower (clock ramp), which would only penalise whichever measurement comes first.
+        # optional extra pre-conditioning (--prewarm; none by default: the contract's W warm-up steps are the warm-up)
         n_prewarm = PREWARM_STEPS if args.prewarm < 0 else args.prewarm
         for _ in range(n_prewarm):
             step()

@@ -2117,7 +2117,7 @@ def test_bench_force_dist_default_workload_carries_the_dist_legs(dev):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "8", "--warmup", "2",
-                        "--prewarm", "3", "--no-cpu-baseline", "--legs", "336,main_batched_ragged"], env=env, capture_output=True,
+                        "--no-cpu-baseline", "--legs", "336,main_batched_ragged"], env=env, capture_output=True,
                        text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
