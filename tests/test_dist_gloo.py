@@ -180,3 +180,21 @@ def test_pin_to_local_cores_is_harmless_without_a_gpu():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr[-1500:]
     assert "cores" in r.stdout
+
+
+@pytest.mark.timeout(400)
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- RANK is set, so bench.py is simply one of the ranks (no self-launch);
+    rank 0 prints the one JSON line with the dist legs."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--dist-backend", "gloo", "--dry-run"], env=_clean_env(), capture_output=True, text=True, timeout=380)
+    assert r.returncode == 0, (r.stderr[-2000:], r.stdout[-500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == [0, 1]
+    _check_dist_legs(d, 2)

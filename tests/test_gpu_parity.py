@@ -2052,6 +2052,36 @@ def test_bench_gpus2_self_launch_on_one_gpu(dev):
     assert abs(d["scaling_efficiency_vs_rank_mean"] - d["value"] / (2 * sum(rates) / 2)) < 2e-3
 
 
+def test_bench_gpus2_default_workload_runs_the_dist_legs_on_every_rank(dev):
+    """world_size 2 through the REAL N > 1 path with GPU work: `python bench.py --gpus 2` on the default (1024 x 1024) workload,
+    both ranks sharing this box's one GPU over gloo (`--device 0 --dist-backend gloo`: the explicit smoke-test override of the
+    RCCL requirement).  The line must carry, from BOTH ranks, BASELINE configs[3]'s per-rank batch and the ragged main_batched
+    leg -- barrier-bracketed, max over ranks, per-rank rates, bit-identity ANDed over the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--device", "0",
+                        "--steps", "6", "--warmup", "2", "--legs", "336,main_batched_ragged"], env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and d["rccl_ranks_seen"] == [0, 1] and d["dist_backend"] == "gloo"
+    assert d["bit_identical_to_serial"] is True and len(d["per_rank_images_per_s"]) == 2
+    for key, per_rank in (("also_336x256", 256), ("also_main_batched_ragged", 32)):
+        leg = d[key]
+        assert leg["n_gpus"] == 2 and len(leg["per_rank_images_per_s"]) == 2 and leg["bit_identical_to_serial"] is True, key
+        rates = leg["per_rank_images_per_s"]
+        assert all(v > 0 for v in rates) and 0.3 < leg["scaling_efficiency_vs_rank_mean"] <= 1.0 + 1e-6, key
+        assert abs(leg["scaling_efficiency_vs_rank_mean"] - leg["value"] / (2 * sum(rates) / 2)) < 2e-3, key
+    assert d["also_336x256"]["global_batch"] == 512
+    assert [c["B"] for c in d["also_main_batched_ragged"]["cases"]] == [32, 256]
+    assert "also_main_batched" not in d and "also_u8" not in d          # one-GPU legs stay off an N > 1 line
+
+
 _RCCL_ONE_RANK = r"""
 import json, sys, torch
 sys.path.insert(0, sys.argv[1])

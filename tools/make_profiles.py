@@ -55,8 +55,8 @@ prof = json.loads([l for l in open(os.path.join(SRC, "bench_profiled.json")) if 
 with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
     f.write(f"# rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline ({tag})\n\n")
     f.write("Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py "
-            "--no-cpu-baseline --no-also` (tools/refresh_profiles.sh): ONLY the main workload, mode=cv2 HWC at B=256 1024x1024 -- 25 "
-            "pre-conditioning steps, the three-launch step (`also_eager`: 3 warm-up + 20 timed), then the MAIN line, the "
+            "--no-cpu-baseline --no-also` (tools/refresh_profiles.sh): ONLY the main workload, mode=cv2 HWC at B=256 1024x1024 -- "
+            "the three-launch step (`also_eager`: 3 warm-up + 20 timed), then the MAIN line, the "
             "two-launch stream step (`attn_maps_kernel` + `remap_rows_kernel`: 2 priming launches, 5 + 3 warm-up + 20 timed "
             "steps) -- so the LAST 20 launches of `remap_rows_kernel<..., 1, true>` in the kernel trace are the ones the main "
             "line times (per-dispatch durations below the table); the table's average runs over all of them.  The stats of the "
@@ -77,7 +77,7 @@ with open(os.path.join(DST, f"{tag}_bench_kernel_stats.md"), "w") as f:
         f.write(f"\nPer-dispatch durations of `remap_rows_kernel` from the kernel trace of the same run (`{tag}_bench_kernel_trace.csv`): all "
                 f"{len(d)} launches average {sum(d) / len(d):.1f} us; the LAST {len(last)} launches -- the ones `bench.py` times -- average "
                 f"**{sum(last) / len(last):.1f} us** (min {min(last):.1f}, max {max(last):.1f}) = {alg / (sum(last) / len(last) * 1e-6) / 8e12:.4f} of 8 TB/s; "
-                f"the first {len(d) - len(last)} are the untimed pre-conditioning / warm-up steps and the three-launch (`also_eager`) measurement.\n")
+                f"the first {len(d) - len(last)} are the untimed warm-up / priming steps and the three-launch (`also_eager`) measurement.\n")
     f.write(f"\nbench.py's own HIP-event measurement in the same (profiled) process: ms_per_step {prof['ms_per_step']}, "
             f"roofline {json.dumps(prof['roofline'])}, "
             f"stages_ms {json.dumps(prof.get('stages_ms'))}.\n")
