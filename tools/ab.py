@@ -71,8 +71,8 @@ if "--child" in sys.argv:
                 ts.append(e0.elapsed_time(e1))
             print(f"{tag:22s} u8 cv2 B={B} W={S}->{So}: {sorted(ts)[20]*1e3:.1f} us", flush=True)
             del img, out
-        for (B, S, K) in ((32, 336, 64), (256, 1024, 32)):
-            n = 6 if S == 1024 else 16
+        for (B, S, K) in ((32, 336, 64), (64, 336, 64), (256, 336, 32), (64, 1024, 32), (256, 1024, 32)):
+            n = 6 if S == 1024 or B == 256 else 16
             g = torch.Generator(device=dev).manual_seed(B + S)
             images = [torch.randint(0, 256, (B, S, S, 3), device=dev, dtype=torch.uint8, generator=g) for _ in range(n)]
             masks = [torch.rand(B, 24, 24, device=dev, generator=g) for _ in range(n)]
@@ -85,6 +85,25 @@ if "--child" in sys.argv:
                 best = min(best, (time.perf_counter() - t0) / (K + mc.depth))
             print(f"{tag:22s} chain step B={B} {S}->500: {best*1e6:.1f} us", flush=True)
             del mc, images, masks; torch.cuda.empty_cache()
+        WH = [(1024, 768), (683, 1024), (1024, 1024), (500, 375), (333, 500), (640, 427)]
+        for (B, K) in ((32, 60), (256, 24)):
+            g = torch.Generator(device=dev).manual_seed(B)
+            ring = []
+            for _ in range(12 if B == 32 else 6):
+                rb = pipeline.RaggedBatch([torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g)
+                                           for (w, h) in (WH[b % 6] for b in range(B))], (500, 500))
+                rb.masks = torch.rand(B, 24, 24, device=dev, generator=g)
+                ring.append(rb)
+            st = pipeline.RaggedMaskChainStream(out_size=(500, 500))
+            st.ring(ring)
+            def run_r():
+                st.k = 0; st.prime(); st.run(K, unroll=len(ring)); st.drain_ring()
+            run_r(); torch.cuda.synchronize(); best = 1e9
+            for rep in range(5):
+                torch.cuda.synchronize(); t0 = time.perf_counter(); run_r(); torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / (K + 4))
+            print(f"{tag:22s} ragged step B={B}: {best*1e6:.1f} us", flush=True)
+            del st, ring; torch.cuda.empty_cache()
     else:
         raise SystemExit(__doc__)
 else:
