@@ -71,6 +71,9 @@ def attention_transform_lut(transform: str, exp_scale: float, exp_divisor: float
     key = ("xf_lut", transform, float(exp_scale), float(exp_divisor), str(device))
     t = _DEV_CACHE.get(key)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("attwarp_amd: the transform table of a one-launch chain step must exist before a stream capture "
+                               "(construct the MaskChainStream / run one eager step first)")
         lut = torch.empty(256, device=device, dtype=torch.float64)
         with torch.cuda.device(device):
             _lib.call("attwarp_attention_transform_lut", _lib.TRANSFORM_IDS[transform], float(exp_scale), float(exp_divisor),

@@ -2846,6 +2846,28 @@ def test_one_launch_chains_take_save_warped_images_transforms(dev, tr, es, ed, i
             assert np.array_equal(got, ref), (b, tr)
 
 
+def test_warp_from_masks_ragged_argument_checks_and_exact_mode(dev):
+    """warp_from_masks_ragged validates up front: an empty batch and images of different channel counts raise
+    ValueError with a clear message instead of an IndexError / a shape mismatch deep inside; `mode="exact"` -- which the ragged
+    kernel (the integer cv2 resample) does not compute -- runs image by image through warp_from_masks and equals it."""
+    from attwarp_amd import pipeline
+    g = torch.Generator(device=dev).manual_seed(3)
+    imgs = [torch.randint(0, 256, (h, w, 3), device=dev, dtype=torch.uint8, generator=g) for (h, w) in ((40, 61), (52, 48))]
+    att = torch.rand(2, 24, 24, device=dev, generator=g)
+    with pytest.raises(ValueError, match="empty"):
+        pipeline.warp_from_masks_ragged([], att[:0], (32, 36))
+    with pytest.raises(ValueError, match="channel"):
+        pipeline.warp_from_masks_ragged([imgs[0], imgs[1][:, :, :1].contiguous()], att, (32, 36))
+    with pytest.raises(ValueError, match="map per image"):
+        pipeline.warp_from_masks_ragged(imgs, att[:1], (32, 36))
+    with pytest.raises(ValueError, match="mode"):
+        pipeline.warp_from_masks_ragged(imgs, att, (32, 36), mode="nearest")
+    ex = pipeline.warp_from_masks_ragged(imgs, att, (32, 36), mode="exact", transform="sqrt")
+    for b in range(2):
+        assert torch.equal(ex[b], pipeline.warp_from_masks(imgs[b][None], att[b:b + 1], (32, 36), mode="exact", transform="sqrt")[0])
+    assert not torch.equal(ex, pipeline.warp_from_masks_ragged(imgs, att, (32, 36), transform="sqrt"))      # (cv2 arithmetic differs)
+
+
 def test_ragged_chain_p_and_f_stages_vs_reference_transform_combos(dev, golden):
     """The P (marginals) and F (CDF / np.interp) stages of attwarp_mask_chain_ragged -- launched alone on a batch whose
     up-sampled mask is the fixture's uint8 attention map -- against the float32 maps the REFERENCE handed to cv2.remap for every
