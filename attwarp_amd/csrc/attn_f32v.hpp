@@ -185,7 +185,7 @@ __device__ __forceinline__ void attn_reduce_v4_block(const AttnStepArgsT<T>& a, 
   // The image-token slice starts at an arbitrary token (35 + ... in LLaVA-1.5 prompts), so the natural load of a lane --
   // its four tokens -- is only element aligned.  For the 16-bit dtypes an ODD token offset makes it a 2-byte aligned 8-byte
   // load, which the texture addresser splits: float16 rows 59.6 us against 47.0 us for an aligned slice (T*B = 5120 rows x
-  // 32 heads, tools/attn_layout_probe.py; a dword-aligned address is as good as an 8-byte aligned one, and float32 rows
+  // 32 heads, tools/attic/attn_layout_probe.py; a dword-aligned address is as good as an 8-byte aligned one, and float32 rows
   // do not care).  In that case a lane loads the four-token chunk one token BELOW its first token (dword aligned: chunk
   // c = 64 i + l of the row counted from there) and assembles its tokens from its own chunk and the first token pair of
   // the next lane's in registers -- same values in the same lanes, only the way they get there: 59.6 -> 48.0 us.  The

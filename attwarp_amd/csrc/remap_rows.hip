@@ -110,7 +110,7 @@ int launch_remap_rows(const float* src, float* dst, int layout, int B, int C, in
     group = 0;
   } else if (!tiled && row_bytes < 5 * 1024 && (long long)B * ((Ho + R - 1) / R) >= 8192) {
     group = 2;        // large batches of small images (336x336x3, B=256): 0.1434 -> 0.1414 ms alone, 0.215 -> 0.209 ms
-  }                   // inside the fused step (tools/ab_fused336.py); B=64 is fastest with the contiguous order
+  }                   // inside the fused step (tools/attic/ab_fused336.py); B=64 is fastest with the contiguous order
   if (const int v = tune(TUNE_REMAP_ROWS); v >= 1 && v <= RMAX) R = v;
   if (R > Ho) R = Ho;
   p.R = R;

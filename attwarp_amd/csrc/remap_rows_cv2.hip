@@ -12,7 +12,7 @@ int launch_rows_cv2(const RowsParams& p, int tile_ko, hipStream_t st, const Step
   // (1024x1024x3, B=256): with the row loop of rounds 1-3 the one-buffer form won (1.157 against 1.181 ms: 48 KB leave 3
   // workgroups per CU); with the loop whose look-ahead overlaps the gather (round 4) a workgroup hides its own load latency
   // and the barrier is what it waits at: five leases, uniform maps 1.111-1.114 ms against 1.17-1.18 (and 1.115 for the best
-  // one-buffer order, which pays 0.98 instead of 0.93 ms on peaked maps): tools/lease_orders.py, docs/experiments.md.
+  // one-buffer order, which pays 0.98 instead of 0.93 ms on peaked maps): tools/attic/lease_orders.py, docs/experiments.md.
   if (ki == 3 && tile_ko == 0 && tune(TUNE_REMAP_CV2_DOUBLE) != 0) return launch_rows_mode<ATTWARP_CV2, false, 3, 3, false>(p, tile_ko, st, nullptr);
   if (ki >= 3) return launch_rows_mode<ATTWARP_CV2, true, 3, 4, false>(p, tile_ko, st, nullptr);
   return launch_rows_mode<ATTWARP_CV2, false, 1, 2, false>(p, tile_ko, st, nullptr);

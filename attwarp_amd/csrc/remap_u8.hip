@@ -328,7 +328,7 @@ static int launch_u8i_ki(const Params& p, hipStream_t st) {
 #undef ATTWARP_U8I_LAUNCH
   return check_launch("remap_rows_u8i_kernel");
 }
-// Rows requested ahead.  Measured on MI355X, one process cycling the variants (tools/u8_ahead.py): rows of <= 2 KB
+// Rows requested ahead.  Measured on MI355X, one process cycling the variants (tools/attic/u8_ahead.py): rows of <= 2 KB
 // (336x3: 1 KB) want 4 -- B=256 336 -> 500: 113.6 us with 1 row ahead, 103.9 with 2, 94.6 with 4; planar 336 -> 336:
 // 53.5 / 51.2 / 48.9 -- rows of 3 KB (1024x3) 2: 1024 -> 500 161.8 / 153.8 / 153.0 at B=256 but 42.6 / 41.5 / 44.4 at B=64;
 // 1024 -> 1024 is the same with all three (it follows the lease: 308 - 357 us).
@@ -435,7 +435,7 @@ static bool plan_u8(u8k::Params& p, const uint8_t* src, uint8_t* dst, int layout
   if (integer_form) {
     // Large rows that are not strongly minified: smaller row blocks, several per workgroup (the column-tap prologue is
     // still paid once per 64 rows, the rows in flight form a compact window).  Measured on MI355X, B=256 1024 -> 1024
-    // x3 uint8 (tools/u8_sweep.py): near-identity maps R=32 x 1: 425 us, R=16 x 4: 370; peaked maps 383 -> 358;
+    // x3 uint8 (tools/attic/u8_sweep.py): near-identity maps R=32 x 1: 425 us, R=16 x 4: 370; peaked maps 383 -> 358;
     // 1024 -> 500 and 336 -> 500 are fastest as they were (R=32 / 16, one block per workgroup).
     int cpw = 1;                                      // row blocks per workgroup (strided inside the image)
     if (OVL >= 2048 && 2LL * H <= 3LL * Ho && tune(TUNE_REMAP_ROWS) < 1) {

@@ -57,7 +57,7 @@ constexpr size_t u8i_lds_bytes() { return (size_t)RMAX * sizeof(float) + 2 * (si
 // (chain_ragged.hip) can fill a Params per image from its descriptor table.  smem: u8i_lds_bytes() of LDS.
 // UA ("unaligned", interleaved images only): rows whose byte length is not a multiple of 4 and images that start anywhere
 // -- e.g. 683 x 3 bytes per row, the portrait TextVQA case.  gfx950 does serve dword loads at any byte address, but at a
-// price: a wave's 64 misaligned dwords cost ~40 % of this kernel's time (tools/ua_cost.py: 684-wide images from a view
+// price: a wave's 64 misaligned dwords cost ~40 % of this kernel's time (tools/attic/ua_cost.py: 684-wide images from a view
 // that starts one byte in: 0.192 ms against 0.138 ms).  So the loads stay ALIGNED: the buffer descriptor starts at the
 // image's base rounded down to a dword, a row's scalar offset is rounded down likewise, every thread loads the aligned
 // dword its row dword starts in AND the next one, and one v_alignbyte_b32 with the row's (block-uniform) byte shift puts

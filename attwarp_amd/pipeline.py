@@ -402,7 +402,7 @@ class OverlappedWarp:
             except _lib.AttWarpError:
                 if self.pattern == "fused":
                     raise
-                # measured (tools/pattern_probe.py, uint8 images): "am" 0.040 / 0.124 ms per step at B=64 / 256 336x336
+                # measured (tools/attic/pattern_probe.py, uint8 images): "am" 0.040 / 0.124 ms per step at B=64 / 256 336x336
                 # against 0.048 / 0.131 ("dag") and 0.048 / 0.125 ("join")
                 self.pattern = "am"
             # the trial step overwrote maps[1] / steps[1] with what they held anyway (same inputs)
